@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.
+
+Runs ONLY in the build container (needs the read-only reference checkout at
+/root/reference); the GPU box replays the committed outputs.  Re-run with
+    python tests/golden/make_golden.py
+
+What it writes
+  snapshot_markov.npz   the reference's four insta snapshots
+                        (tests/snapshots/snapshot__tests__markov_*.snap) parsed
+                        into int32[100,32] arrays — the reference's own golden
+                        vectors for NdArrayMatrix::multiply (tests/snapshot.rs:18-50).
+  whiten_ref.npz        outputs of the reference's OWN Python functions imported
+                        from /root/reference/pycleora/__init__.py:
+                        _normalize(…,"l2") (:942-946), whiten_embeddings (:130-164),
+                        _postprocess_iteration (:963-971), _compute_rmse (:974-976)
+                        on seeded inputs (the seeds are stored with the outputs).
+  karate_ref.npz        config 1: karate_club lines + labels (datasets.py:283-331,
+                        data only) and the result of the reference's embed()
+                        (:51-127, whiten=True and whiten=False) run UNMODIFIED over
+                        a stub SparseMatrix whose propagate is the C oracle.
+
+The reference's Rust core cannot be built here (no rustc/cargo), so
+`pycleora.pycleora` is replaced by a stub module before `import pycleora`.
+"""
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from oracle import refgraph  # noqa: E402
+
+
+def parse_snap(path):
+    body = open(path).read().split("---", 2)[2]
+    nums = [int(t) for t in re.findall(r"-?\d+", body.split("shape=")[0])]
+    arr = np.array(nums, dtype=np.int32)
+    assert arr.size == 3200, (path, arr.size)
+    return arr.reshape(100, 32)
+
+
+class StubSparseMatrix:
+    """Minimal stand-in for pycleora.pycleora.SparseMatrix: graph from the
+    Python builder oracle, propagate from the C oracle."""
+
+    def __init__(self, g):
+        self.g = g
+        self.entity_ids = list(g.entity_ids)
+        self.num_entities = len(g.entity_ids)
+        self.num_edges = int(g.col.shape[0])
+
+    @staticmethod
+    def from_iterator(lines, columns, hyperedge_trim_n=16, num_workers=None):
+        return StubSparseMatrix(refgraph.build_graph(list(lines), columns, hyperedge_trim_n))
+
+    def left_markov_propagate(self, x, num_workers=None):
+        return oracle.spmm(self.g.rowptr, self.g.col, self.g.val_left, x)
+
+    def symmetric_markov_propagate(self, x, num_workers=None):
+        return oracle.spmm(self.g.rowptr, self.g.col, self.g.val_sym, x)
+
+    def initialize_deterministically(self, feature_dim, seed=0):
+        return oracle.init(self.g.entity_hashes, feature_dim, seed)
+
+    def embed_fast(self, feature_dim, num_iterations, propagation="left", seed=0,
+                   residual_weight=0.0, num_workers=None):
+        val = self.g.val_left if propagation == "left" else self.g.val_sym
+        x0 = oracle.init(self.g.entity_hashes, feature_dim, seed)
+        return oracle.embed(self.g.rowptr, self.g.col, val, x0, num_iterations, residual_weight)[0]
+
+    def to_sparse_csr(self, markov_type=None):
+        g = self.g
+        rows = np.repeat(np.arange(self.num_entities, dtype=np.uint32),
+                         np.diff(g.rowptr.astype(np.int64)))
+        vals = g.val_sym if markov_type == "symmetric" else g.val_left
+        return rows, g.col, vals, self.num_entities, self.num_entities
+
+
+def import_reference():
+    stub = types.ModuleType("pycleora.pycleora")
+    stub.SparseMatrix = StubSparseMatrix
+    sys.modules["pycleora.pycleora"] = stub
+    sys.path.insert(0, REF)
+    import pycleora  # the reference's own Python layer, unmodified
+    assert os.path.realpath(pycleora.__file__).startswith(REF)
+    return pycleora
+
+
+def main():
+    # 1. insta snapshots → npz
+    snaps = {}
+    for name in ("left_01", "left_02", "sym_01", "sym_02"):
+        snaps[name] = parse_snap(f"{REF}/tests/snapshots/snapshot__tests__markov_{name}.snap")
+    np.savez_compressed(os.path.join(HERE, "snapshot_markov.npz"), **snaps)
+
+    pc = import_reference()
+
+    # 2. whitening / normalise fixtures from the reference's own numpy code
+    out = {}
+    cases = [("a", 11, 500, 16), ("b", 12, 257, 64), ("c", 13, 3000, 32), ("d", 14, 60001, 8)]
+    for tag, seed, n, d in cases:
+        rng = np.random.default_rng(seed)
+        # anisotropic, non-centred data so the covariance is well conditioned
+        x = (rng.standard_normal((n, d)) * np.linspace(0.5, 3.0, d) + rng.standard_normal(d)
+             ).astype(np.float32)
+        # case "d" crosses the reference's 50 000-row chunk boundary; keep every
+        # 61st row of its outputs so the fixture stays small
+        step = 61 if n > 50000 else 1
+        out[f"{tag}_seed"] = np.array([seed, n, d, step])
+        l2 = pc._normalize(x, "l2")
+        out[f"{tag}_l2"] = l2[::step]
+        out[f"{tag}_whiten"] = pc.whiten_embeddings(x)[::step]
+        out[f"{tag}_post"] = pc._postprocess_iteration(x, "l2", True)[::step]
+        out[f"{tag}_rmse"] = np.array([pc._compute_rmse(l2, x)])
+    rng = np.random.default_rng(15)
+    x = rng.standard_normal((400, 24)).astype(np.float32)
+    out["trunc_seed"] = np.array([15, 400, 24, 1])
+    out["trunc_whiten_k8"] = pc.whiten_embeddings(x, n_components=8)
+    np.savez_compressed(os.path.join(HERE, "whiten_ref.npz"), **out)
+
+    # 3. config 1: karate club through the reference's embed()
+    from pycleora.datasets import load_karate_club
+    ds = load_karate_club()
+    g = StubSparseMatrix.from_iterator(iter(ds["edges"]), ds["columns"])
+    kar = {
+        "edges": np.array(ds["edges"]),
+        "columns": np.array(ds["columns"]),
+        "label_ids": np.array(list(ds["labels"].keys())),
+        "label_vals": np.array(list(ds["labels"].values()), dtype=np.int64),
+        "entity_ids": np.array(g.entity_ids),
+        "rowptr": g.g.rowptr, "col": g.g.col, "val_left": g.g.val_left, "val_sym": g.g.val_sym,
+        "row_sum": g.g.row_sum, "entity_hashes": g.g.entity_hashes,
+    }
+    for d in (16, 128):
+        kar[f"embed_whiten_d{d}"] = pc.embed(g, d, 40)                       # CLI default path
+        kar[f"embed_fast_d{d}"] = pc.embed(g, d, 40, whiten=False)           # all-"Rust" fast path
+        kar[f"embed_sym_d{d}"] = pc.embed(g, d, 8, propagation="symmetric", whiten=False,
+                                          callback=lambda i, e: None)        # slow path, no whiten
+    kar["embed_resid_d16"] = pc.embed(g, 16, 10, residual_weight=0.3, whiten=True)
+    np.savez_compressed(os.path.join(HERE, "karate_ref.npz"), **kar)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

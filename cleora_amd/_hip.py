@@ -1,0 +1,211 @@
+"""ctypes binding of libcleora_hip.so (include/cleora_hip.h).
+
+This is the only place Python touches the HIP library.  There is no CPU
+fallback: if the shared object is missing or a call fails, a RuntimeError /
+ValueError is raised with cleora_last_error().
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcleora_hip.so")
+
+OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4
+LEFT, SYMMETRIC = 0, 1
+F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF = 1, 2, 4, 8
+
+c_u64, c_u32, c_i64, c_int, c_f32 = (ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
+                                     ctypes.c_int, ctypes.c_float)
+vp = ctypes.c_void_p
+
+
+class GraphInfo(ctypes.Structure):
+    _fields_ = [("n_rows", c_u64), ("n_cols", c_u64), ("nnz", c_u64), ("n_hub_rows", c_u64),
+                ("n_hub_segments", c_u64), ("device_bytes", c_u64), ("hub_threshold", c_u32),
+                ("hub_segment", c_u32), ("device", ctypes.c_int32), ("has_symmetric", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/cleora_hip.h one to one
+SIGNATURES = {
+    "cleora_abi_version": (c_int, []),
+    "cleora_last_error": (ctypes.c_char_p, []),
+    "cleora_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "cleora_set_device": (c_int, [c_int]),
+    "cleora_malloc": (c_int, [c_u64, ctypes.POINTER(vp)]),
+    "cleora_free": (c_int, [vp]),
+    "cleora_memcpy_h2d": (c_int, [vp, vp, c_u64, vp]),
+    "cleora_memcpy_d2h": (c_int, [vp, vp, c_u64, vp]),
+    "cleora_memcpy_d2d": (c_int, [vp, vp, c_u64, vp]),
+    "cleora_memset": (c_int, [vp, c_int, c_u64, vp]),
+    "cleora_stream_sync": (c_int, [vp]),
+    "cleora_graph_create": (c_int, [c_int, c_u64, c_u64, c_u64, vp, vp, vp, vp, c_u32, c_u32,
+                                    ctypes.POINTER(vp)]),
+    "cleora_graph_create_dev": (c_int, [c_int, c_u64, c_u64, c_u64, vp, vp, vp, vp, c_u32, c_u32,
+                                        ctypes.POINTER(vp)]),
+    "cleora_graph_destroy": (c_int, [vp]),
+    "cleora_graph_get_info": (c_int, [vp, ctypes.POINTER(GraphInfo)]),
+    "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
+    "cleora_rowops_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
+    "cleora_init_dev": (c_int, [vp, c_u64, c_u32, c_i64, vp, c_u64, vp]),
+    "cleora_reduce_workspace": (c_u64, [c_u64]),
+    "cleora_reduce_sum_f64_dev": (c_int, [vp, c_u64, vp, vp, vp]),
+    "cleora_colsum_workspace": (c_u64, [c_u64, c_u32]),
+    "cleora_colsum_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp]),
+    "cleora_gram_workspace": (c_u64, [c_u64, c_u32]),
+    "cleora_centered_gram_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp, vp]),
+    "cleora_project_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp]),
+    "cleora_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),
+    "cleora_l2_normalize": (c_int, [vp, c_u64, c_u32, vp]),
+    "cleora_init": (c_int, [vp, c_u64, c_u32, c_i64, vp]),
+    "cleora_embed": (c_int, [vp, vp, vp, c_int, c_u32, c_u64, c_i64, c_f32, c_f32, c_u32, vp,
+                             ctypes.POINTER(c_u64)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libcleora_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(cleora_amd/csrc/build.sh).  cleora_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.cleora_abi_version() != 1:
+            raise RuntimeError("libcleora_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().cleora_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Maps a status code to the exceptions the PyO3 class raises (src/lib.rs):
+    bad arguments -> ValueError, everything else -> RuntimeError."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    if rc == E_OOM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().cleora_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(vp)
+
+
+class Graph:
+    """Owns a cleora_graph handle (device CSR shard)."""
+
+    def __init__(self, handle, keepalive=None):
+        self.handle = handle
+        self._keepalive = keepalive
+
+    @classmethod
+    def from_host(cls, rowptr, col, val_left, val_sym=None, n_cols=None, device=0,
+                  hub_threshold=0, hub_segment=0):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        val_left = np.ascontiguousarray(val_left, dtype=np.float32)
+        if val_sym is not None:
+            val_sym = np.ascontiguousarray(val_sym, dtype=np.float32)
+        n_rows = rowptr.shape[0] - 1
+        nnz = col.shape[0]
+        if n_cols is None:
+            n_cols = n_rows
+        if val_left.shape[0] != nnz or (val_sym is not None and val_sym.shape[0] != nnz):
+            raise ValueError("col / val length mismatch")
+        h = vp()
+        check(lib().cleora_graph_create(device, n_rows, n_cols, nnz, ptr(rowptr), ptr(col),
+                                        ptr(val_left), ptr(val_sym), hub_threshold, hub_segment,
+                                        ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, n_rows, n_cols, nnz, rowptr_ptr, col_ptr, val_left_ptr, val_sym_ptr=None,
+                    device=0, hub_threshold=0, hub_segment=0, keepalive=None):
+        """Adopts device arrays (e.g. torch tensors' data_ptr()); keepalive holds their owners."""
+        h = vp()
+        check(lib().cleora_graph_create_dev(device, n_rows, n_cols, nnz, rowptr_ptr, col_ptr,
+                                            val_left_ptr, val_sym_ptr, hub_threshold, hub_segment,
+                                            ctypes.byref(h)))
+        return cls(h, keepalive)
+
+    def info(self):
+        gi = GraphInfo()
+        check(lib().cleora_graph_get_info(self.handle, ctypes.byref(gi)))
+        return gi
+
+    def close(self):
+        if self.handle:
+            lib().cleora_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DevArray:
+    """A device buffer shaped like a numpy array (hipMalloc through the C ABI).  Lets hosts
+    without torch keep matrices resident in HBM across calls."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = vp()
+        check(lib().cleora_malloc(self.nbytes, ctypes.byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        if d.nbytes:
+            check(lib().cleora_memcpy_h2d(d.ptr, ptr(a), d.nbytes, None))
+        return d
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(lib().cleora_memcpy_d2h(ptr(out), self.ptr, self.nbytes, None))
+        return out
+
+    def offset(self, nbytes):
+        return vp(self.ptr.value + int(nbytes))
+
+    def free(self):
+        if self.ptr:
+            lib().cleora_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,444 @@
+// abi.hip — the extern "C" surface of libcleora_hip.so (include/cleora_hip.h):
+// argument checking, graph handles, and the host-pointer entry points that the
+// reference's PyO3 methods (src/lib.rs) would call through FFI.
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace cleora {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    g_last_error = std::string(what) + " failed: " + hipGetErrorString(e) + " (" + file + ":" +
+                   std::to_string(line) + ")";
+    if (e == hipErrorOutOfMemory) return CLEORA_E_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return CLEORA_E_NODEVICE;
+    return CLEORA_E_HIP;
+}
+
+namespace {
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// RAII device buffer for the host-pointer entry points.
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(uint64_t bytes) {
+        CL_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return CLEORA_OK;
+    }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(std::string("no HIP device available (") + hipGetErrorString(e) +
+                  "); libcleora_hip has no CPU fallback");
+        return CLEORA_E_NODEVICE;
+    }
+    return CLEORA_OK;
+}
+
+// Finds hub rows from a host copy of rowptr and uploads the split schedule.
+int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
+    std::vector<uint32_t> hub_rows, seg_row;
+    std::vector<uint64_t> hub_seg_first, seg_begin;
+    for (uint64_t r = 0; r < g->n_rows; ++r) {
+        const uint64_t b = rowptr_host[r], e = rowptr_host[r + 1];
+        if (e - b > g->hub_threshold) {
+            hub_rows.push_back((uint32_t)r);
+            hub_seg_first.push_back(seg_row.size());
+            for (uint64_t s = b; s < e; s += g->hub_segment) {
+                seg_row.push_back((uint32_t)r);
+                seg_begin.push_back(s);
+            }
+        }
+    }
+    hub_seg_first.push_back(seg_row.size());
+    g->n_hub_rows = hub_rows.size();
+    g->n_hub_segments = seg_row.size();
+    if (g->n_hub_rows == 0) return CLEORA_OK;
+    auto up = [&](auto **dst, const auto &v) -> int {
+        const size_t bytes = v.size() * sizeof(v[0]);
+        CL_HIP(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+        CL_HIP(hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
+        g->device_bytes += bytes;
+        return CLEORA_OK;
+    };
+    int rc;
+    if ((rc = up(&g->hub_rows, hub_rows)) != CLEORA_OK) return rc;
+    if ((rc = up(&g->hub_seg_first, hub_seg_first)) != CLEORA_OK) return rc;
+    if ((rc = up(&g->seg_row, seg_row)) != CLEORA_OK) return rc;
+    if ((rc = up(&g->seg_begin, seg_begin)) != CLEORA_OK) return rc;
+    return CLEORA_OK;
+}
+
+int check_csr_host(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, const uint64_t *rowptr,
+                   const uint32_t *col) {
+    CL_REQUIRE(rowptr[0] == 0 && rowptr[n_rows] == nnz, "rowptr[0] != 0 or rowptr[n_rows] != nnz");
+    for (uint64_t r = 0; r < n_rows; ++r)
+        CL_REQUIRE(rowptr[r] <= rowptr[r + 1], "rowptr is not non-decreasing");
+    if (col)
+        for (uint64_t k = 0; k < nnz; ++k) CL_REQUIRE(col[k] < n_cols, "column index out of range");
+    return CLEORA_OK;
+}
+
+void free_graph(cleora_graph *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->owns_csr) {
+        (void)hipFree(const_cast<uint64_t *>(g->rowptr));
+        (void)hipFree(const_cast<uint32_t *>(g->col));
+        (void)hipFree(const_cast<float *>(g->val[0]));
+        (void)hipFree(const_cast<float *>(g->val[1]));
+    }
+    (void)hipFree(g->hub_rows);
+    (void)hipFree(g->hub_seg_first);
+    (void)hipFree(g->seg_row);
+    (void)hipFree(g->seg_begin);
+    (void)hipFree(g->hub_partial);
+    delete g;
+}
+
+}  // namespace
+}  // namespace cleora
+
+using namespace cleora;
+
+extern "C" {
+
+int cleora_abi_version(void) { return CLEORA_ABI_VERSION; }
+
+const char *cleora_last_error(void) { return g_last_error.c_str(); }
+
+int cleora_device_count(int *count) {
+    CL_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return CLEORA_OK;
+}
+
+int cleora_set_device(int device) {
+    CL_HIP(hipSetDevice(device));
+    return CLEORA_OK;
+}
+
+int cleora_malloc(uint64_t bytes, void **dev_ptr) {
+    CL_REQUIRE(dev_ptr != nullptr, "dev_ptr is NULL");
+    CL_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return CLEORA_OK;
+}
+
+int cleora_free(void *dev_ptr) {
+    if (dev_ptr) CL_HIP(hipFree(dev_ptr));
+    return CLEORA_OK;
+}
+
+int cleora_memcpy_h2d(void *dst, const void *src, uint64_t bytes, void *stream) {
+    CL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
+    CL_HIP(hipStreamSynchronize(S(stream)));
+    return CLEORA_OK;
+}
+
+int cleora_memcpy_d2h(void *dst, const void *src, uint64_t bytes, void *stream) {
+    CL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
+    CL_HIP(hipStreamSynchronize(S(stream)));
+    return CLEORA_OK;
+}
+
+int cleora_memcpy_d2d(void *dst, const void *src, uint64_t bytes, void *stream) {
+    CL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(stream)));
+    return CLEORA_OK;
+}
+
+int cleora_memset(void *dst, int value, uint64_t bytes, void *stream) {
+    CL_HIP(hipMemsetAsync(dst, value, bytes, S(stream)));
+    return CLEORA_OK;
+}
+
+int cleora_stream_sync(void *stream) {
+    CL_HIP(hipStreamSynchronize(S(stream)));
+    return CLEORA_OK;
+}
+
+int cleora_graph_create(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
+                        const uint64_t *rowptr, const uint32_t *col, const float *val_left,
+                        const float *val_sym, uint32_t hub_threshold, uint32_t hub_segment,
+                        cleora_graph **out) {
+    CL_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    CL_REQUIRE(rowptr != nullptr, "rowptr is NULL");
+    CL_REQUIRE(nnz == 0 || (col != nullptr && val_left != nullptr), "col / val_left is NULL");
+    CL_REQUIRE(n_rows < (1ull << 32) && n_cols <= (1ull << 32), "more than 2^32 entities (col is u32)");
+    int rc = check_csr_host(n_rows, n_cols, nnz, rowptr, col);
+    if (rc != CLEORA_OK) return rc;
+    if ((rc = require_device()) != CLEORA_OK) return rc;
+    CL_HIP(hipSetDevice(device));
+
+    cleora_graph *g = new (std::nothrow) cleora_graph();
+    if (!g) {
+        set_error("host allocation failed");
+        return CLEORA_E_OOM;
+    }
+    g->device = device;
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    g->owns_csr = true;
+    g->hub_threshold = hub_threshold ? hub_threshold : kDefaultHubThreshold;
+    g->hub_segment = hub_segment ? hub_segment : kDefaultHubSegment;
+
+    auto up = [&](auto **dst, const auto *src, uint64_t count) -> int {
+        const uint64_t bytes = count * sizeof(*src);
+        void *p = nullptr;
+        CL_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        *dst = static_cast<std::remove_reference_t<decltype(**dst)> *>(p);
+        if (bytes) CL_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        g->device_bytes += bytes;
+        return CLEORA_OK;
+    };
+    uint64_t *d_rowptr = nullptr;
+    uint32_t *d_col = nullptr;
+    float *d_vl = nullptr, *d_vs = nullptr;
+    rc = up(&d_rowptr, rowptr, n_rows + 1);
+    g->rowptr = d_rowptr;
+    if (rc == CLEORA_OK) { rc = up(&d_col, col, nnz); g->col = d_col; }
+    if (rc == CLEORA_OK) { rc = up(&d_vl, val_left, nnz); g->val[0] = d_vl; }
+    if (rc == CLEORA_OK && val_sym) { rc = up(&d_vs, val_sym, nnz); g->val[1] = d_vs; }
+    if (rc == CLEORA_OK) rc = build_hub_schedule(g, rowptr);
+    if (rc != CLEORA_OK) {
+        free_graph(g);
+        return rc;
+    }
+    *out = g;
+    return CLEORA_OK;
+}
+
+int cleora_graph_create_dev(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
+                            const uint64_t *rowptr_dev, const uint32_t *col_dev,
+                            const float *val_left_dev, const float *val_sym_dev,
+                            uint32_t hub_threshold, uint32_t hub_segment, cleora_graph **out) {
+    CL_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    CL_REQUIRE(rowptr_dev != nullptr, "rowptr is NULL");
+    CL_REQUIRE(nnz == 0 || (col_dev != nullptr && val_left_dev != nullptr), "col / val_left is NULL");
+    CL_REQUIRE(n_rows < (1ull << 32) && n_cols <= (1ull << 32), "more than 2^32 entities (col is u32)");
+    int rc = require_device();
+    if (rc != CLEORA_OK) return rc;
+    CL_HIP(hipSetDevice(device));
+    std::vector<uint64_t> rp(n_rows + 1);
+    CL_HIP(hipMemcpy(rp.data(), rowptr_dev, (n_rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if ((rc = check_csr_host(n_rows, n_cols, nnz, rp.data(), nullptr)) != CLEORA_OK) return rc;
+
+    cleora_graph *g = new (std::nothrow) cleora_graph();
+    if (!g) {
+        set_error("host allocation failed");
+        return CLEORA_E_OOM;
+    }
+    g->device = device;
+    g->n_rows = n_rows;
+    g->n_cols = n_cols;
+    g->nnz = nnz;
+    g->owns_csr = false;
+    g->rowptr = rowptr_dev;
+    g->col = col_dev;
+    g->val[0] = val_left_dev;
+    g->val[1] = val_sym_dev;
+    g->hub_threshold = hub_threshold ? hub_threshold : kDefaultHubThreshold;
+    g->hub_segment = hub_segment ? hub_segment : kDefaultHubSegment;
+    if ((rc = build_hub_schedule(g, rp.data())) != CLEORA_OK) {
+        free_graph(g);
+        return rc;
+    }
+    *out = g;
+    return CLEORA_OK;
+}
+
+int cleora_graph_destroy(cleora_graph *g) {
+    free_graph(g);
+    return CLEORA_OK;
+}
+
+int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info) {
+    CL_REQUIRE(g != nullptr && info != nullptr, "graph / info is NULL");
+    info->n_rows = g->n_rows;
+    info->n_cols = g->n_cols;
+    info->nnz = g->nnz;
+    info->n_hub_rows = g->n_hub_rows;
+    info->n_hub_segments = g->n_hub_segments;
+    info->device_bytes = g->device_bytes;
+    info->hub_threshold = g->hub_threshold;
+    info->hub_segment = g->hub_segment;
+    info->device = g->device;
+    info->has_symmetric = g->val[1] != nullptr;
+    return CLEORA_OK;
+}
+
+int cleora_propagate_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx,
+                         uint32_t d, float *y, uint64_t ldy, uint32_t flags,
+                         float residual_weight, const float *x_self, double *row_sqdiff,
+                         void *stream) {
+    return launch_propagate(g, markov_type, x, ldx, d, y, ldy, flags, residual_weight, x_self,
+                            row_sqdiff, S(stream));
+}
+
+int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
+                      uint32_t flags, float residual_weight, const float *x_self,
+                      double *row_sqdiff, void *stream) {
+    return launch_rowops(x, ldx, n, d, y, ldy, flags, residual_weight, x_self, row_sqdiff, S(stream));
+}
+
+int cleora_init_dev(const uint64_t *entity_hash_dev, uint64_t n, uint32_t d, int64_t seed,
+                    float *x, uint64_t ldx, void *stream) {
+    return launch_init(entity_hash_dev, n, d, seed, x, ldx, S(stream));
+}
+
+uint64_t cleora_reduce_workspace(uint64_t n) { return reduce_workspace(n); }
+
+int cleora_reduce_sum_f64_dev(const double *v, uint64_t n, double *workspace, double *out_dev,
+                              void *stream) {
+    return launch_reduce_sum(v, n, workspace, out_dev, S(stream));
+}
+
+uint64_t cleora_colsum_workspace(uint64_t n, uint32_t d) { return colsum_workspace(n, d); }
+
+int cleora_colsum_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *workspace,
+                      double *colsum_dev, void *stream) {
+    return launch_colsum(x, ldx, n, d, workspace, colsum_dev, S(stream));
+}
+
+uint64_t cleora_gram_workspace(uint64_t n, uint32_t d) { return gram_workspace(n, d); }
+
+int cleora_centered_gram_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                             const double *mean_dev, double *workspace, double *gram_dev,
+                             void *stream) {
+    return launch_gram(x, ldx, n, d, mean_dev, workspace, gram_dev, S(stream));
+}
+
+int cleora_project_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                       const float *mean_f32_dev, const float *transform_dev, uint32_t k,
+                       float *out, uint64_t ldo, void *stream) {
+    return launch_project(x, ldx, n, d, mean_f32_dev, transform_dev, k, out, ldo, S(stream));
+}
+
+// ---- host-pointer entry points ----------------------------------------------------------------
+
+int cleora_propagate(const cleora_graph *g, int markov_type, const float *x_host, uint32_t d,
+                     float *y_host) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    CL_REQUIRE(x_host != nullptr && y_host != nullptr, "x / y is NULL");
+    CL_REQUIRE(d > 0, "d must be positive");
+    CL_HIP(hipSetDevice(g->device));
+    DevBuf x, y;
+    int rc;
+    const uint64_t xb = g->n_cols * (uint64_t)d * sizeof(float), yb = g->n_rows * (uint64_t)d * sizeof(float);
+    if ((rc = x.alloc(xb)) != CLEORA_OK || (rc = y.alloc(yb)) != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(x.p, x_host, xb, hipMemcpyHostToDevice));
+    rc = launch_propagate(g, markov_type, x.as<float>(), d, d, y.as<float>(), d, 0, 0.f, nullptr,
+                          nullptr, nullptr);
+    if (rc != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(y_host, y.p, yb, hipMemcpyDeviceToHost));
+    return CLEORA_OK;
+}
+
+int cleora_l2_normalize(const float *x_host, uint64_t n, uint32_t d, float *y_host) {
+    CL_REQUIRE(x_host != nullptr && y_host != nullptr, "x / y is NULL");
+    CL_REQUIRE(d > 0, "d must be positive");
+    int rc = require_device();
+    if (rc != CLEORA_OK) return rc;
+    DevBuf x;
+    const uint64_t bytes = n * (uint64_t)d * sizeof(float);
+    if ((rc = x.alloc(bytes)) != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(x.p, x_host, bytes, hipMemcpyHostToDevice));
+    rc = launch_rowops(x.as<float>(), d, n, d, x.as<float>(), d, CLEORA_F_L2NORM, 0.f, nullptr,
+                       nullptr, nullptr);
+    if (rc != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(y_host, x.p, bytes, hipMemcpyDeviceToHost));
+    return CLEORA_OK;
+}
+
+int cleora_init(const uint64_t *entity_hash_host, uint64_t n, uint32_t d, int64_t seed,
+                float *x_host) {
+    CL_REQUIRE(entity_hash_host != nullptr && x_host != nullptr, "hash / x is NULL");
+    CL_REQUIRE(d > 0, "d must be positive");
+    int rc = require_device();
+    if (rc != CLEORA_OK) return rc;
+    DevBuf h, x;
+    const uint64_t bytes = n * (uint64_t)d * sizeof(float);
+    if ((rc = h.alloc(n * sizeof(uint64_t))) != CLEORA_OK || (rc = x.alloc(bytes)) != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(h.p, entity_hash_host, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    rc = launch_init(h.as<uint64_t>(), n, d, seed, x.as<float>(), d, nullptr);
+    if (rc != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(x_host, x.p, bytes, hipMemcpyDeviceToHost));
+    return CLEORA_OK;
+}
+
+int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
+                 int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
+                 float residual_weight, float convergence_threshold, uint32_t flags,
+                 float *out_host, uint64_t *iterations_run) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    CL_REQUIRE(g->n_rows == g->n_cols, "cleora_embed needs the whole (square) graph on one device");
+    CL_REQUIRE(out_host != nullptr, "out is NULL");
+    CL_REQUIRE(entity_hash_host != nullptr || x0_host != nullptr, "need entity hashes or x0");
+    CL_REQUIRE(d > 0, "d must be positive");
+    CL_HIP(hipSetDevice(g->device));
+    const uint64_t n = g->n_rows;
+    const uint64_t bytes = n * (uint64_t)d * sizeof(float);
+    const bool check = convergence_threshold > 0.0f;  // embedding.rs:150
+    DevBuf a, b, h, sq, ws, total;
+    int rc;
+    if ((rc = a.alloc(bytes)) != CLEORA_OK || (rc = b.alloc(bytes)) != CLEORA_OK) return rc;
+    if (x0_host) {
+        CL_HIP(hipMemcpy(a.p, x0_host, bytes, hipMemcpyHostToDevice));
+    } else {
+        if ((rc = h.alloc(n * sizeof(uint64_t))) != CLEORA_OK) return rc;
+        CL_HIP(hipMemcpy(h.p, entity_hash_host, n * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if ((rc = launch_init(h.as<uint64_t>(), n, d, seed, a.as<float>(), d, nullptr)) != CLEORA_OK) return rc;
+    }
+    if (check) {
+        if ((rc = sq.alloc(n * sizeof(double))) != CLEORA_OK ||
+            (rc = ws.alloc(reduce_workspace(n) * sizeof(double))) != CLEORA_OK ||
+            (rc = total.alloc(sizeof(double))) != CLEORA_OK)
+            return rc;
+    }
+    float *src = a.as<float>(), *dst = b.as<float>();
+    uint64_t actual = max_iterations;
+    const uint32_t base = CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | (flags & CLEORA_F_FASTNORM);
+    for (uint64_t it = 0; it < max_iterations; ++it) {
+        const bool test = check && it > 0;  // embedding.rs:169
+        rc = launch_propagate(g, markov_type, src, d, d, dst, d, base | (test ? CLEORA_F_SQDIFF : 0u),
+                              residual_weight, src, test ? sq.as<double>() : nullptr, nullptr);
+        if (rc != CLEORA_OK) return rc;
+        std::swap(src, dst);
+        if (test) {
+            if ((rc = launch_reduce_sum(sq.as<double>(), n, ws.as<double>(), total.as<double>(), nullptr)) != CLEORA_OK)
+                return rc;
+            double sum = 0.0;
+            CL_HIP(hipMemcpy(&sum, total.p, sizeof(double), hipMemcpyDeviceToHost));
+            // rmse = sqrt(diff / (n*d)) < threshold                       (embedding.rs:177-178)
+            const float rmse = sqrtf((float)(sum / (double)(n * (uint64_t)d)));
+            if (rmse < convergence_threshold) {
+                actual = it + 1;
+                break;
+            }
+        }
+    }
+    CL_HIP(hipMemcpy(out_host, src, bytes, hipMemcpyDeviceToHost));
+    if (iterations_run) *iterations_run = actual;
+    return CLEORA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Internal declarations shared by the translation units of libcleora_hip.so.
+// Public interface: include/cleora_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/cleora_hip.h"
+
+namespace cleora {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define CL_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t _e = (call);                                               \
+        if (_e != hipSuccess) return ::cleora::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define CL_REQUIRE(cond, msg)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            ::cleora::set_error(msg);              \
+            return CLEORA_E_INVALID;               \
+        }                                          \
+    } while (0)
+
+constexpr uint32_t kDefaultHubThreshold = 1024;  // edges; longer rows are split
+constexpr uint32_t kDefaultHubSegment = 256;     // edges per split segment
+
+}  // namespace cleora
+
+// Device CSR shard.  Mirrors struct SparseMatrix's `edges` + `slices`
+// (src/sparse_matrix.rs:56-78) as SoA streams.
+struct cleora_graph {
+    int device = 0;
+    uint64_t n_rows = 0, n_cols = 0, nnz = 0;
+    const uint64_t *rowptr = nullptr;  // [n_rows + 1]
+    const uint32_t *col = nullptr;     // [nnz]
+    const float *val[2] = {nullptr, nullptr};  // [nnz] per MarkovType
+    bool owns_csr = false;
+
+    // rows longer than hub_threshold: split into segments that run on separate waves
+    uint32_t hub_threshold = 0, hub_segment = 0;
+    uint64_t n_hub_rows = 0, n_hub_segments = 0;
+    uint32_t *hub_rows = nullptr;       // [n_hub_rows]       row ids
+    uint64_t *hub_seg_first = nullptr;  // [n_hub_rows + 1]   first segment of each hub row
+    uint32_t *seg_row = nullptr;        // [n_hub_segments]   row id of the segment
+    uint64_t *seg_begin = nullptr;      // [n_hub_segments]   first edge of the segment
+    uint64_t device_bytes = 0;
+
+    // scratch for the hub partial sums, sized for the largest d seen so far
+    mutable std::mutex mu;
+    mutable float *hub_partial = nullptr;
+    mutable uint64_t hub_partial_elems = 0;
+};
+
+namespace cleora {
+
+// spmm.hip
+int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
+                     float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
+                     double *row_sqdiff, hipStream_t stream);
+int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
+                  uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
+                  hipStream_t stream);
+// rowops.hip
+int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, float *x, uint64_t ldx,
+                hipStream_t stream);
+uint64_t reduce_workspace(uint64_t n);
+int launch_reduce_sum(const double *v, uint64_t n, double *ws, double *out, hipStream_t stream);
+uint64_t colsum_workspace(uint64_t n, uint32_t d);
+int launch_colsum(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *ws, double *out,
+                  hipStream_t stream);
+// whiten.hip
+uint64_t gram_workspace(uint64_t n, uint32_t d);
+int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
+                double *ws, double *gram, hipStream_t stream);
+int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
+                   const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
+
+}  // namespace cleora

@@ -1,0 +1,566 @@
+// spmm.hip — CSR x dense f32 SpMM with the fused row epilogue, for gfx950.
+//
+// Replaces NdArrayMatrix::spmm_kernel / multiply_into / l2_normalize_inplace and the
+// per-iteration body of embed_full (src/embedding.rs:41-136).
+//
+// Mapping to the hardware:
+//   * one GROUP of G lanes owns one output row; G = 64 (a whole wavefront) for d >= 256, so
+//     one gathered embedding row is ONE coalesced `global_load_dwordx4` per 1 KiB (lane l
+//     reads bytes [16 l, 16 l + 16) of the row); narrower d packs 64/G rows per wavefront.
+//   * the row's (col, val) slice is fetched 64 (G) entries at a time with one coalesced load
+//     into registers and broadcast edge by edge with v_readlane (G = 64: the column index
+//     lands in an SGPR, so the gather address is scalar-base + lane offset) or ds_bpermute.
+//   * U*V >= 8 independent 16-byte loads are in flight per lane before the first use; with 8
+//     waves per SIMD that is >= 256 KiB of gathers in flight per CU.
+//   * edges are consumed in stored order with separate f32 multiply and add
+//     (-ffp-contract=off + __fmul_rn/__fadd_rn), so every row that is not split is
+//     bit-identical to the reference's sequential accumulate (src/embedding.rs:80-82).
+//   * rows longer than hub_threshold are split into hub_segment-edge segments computed by
+//     separate wavefronts (hub_partial_kernel) and combined in segment order
+//     (hub_finish_kernel): deterministic, but not the reference's summation order.
+//   * the epilogue (residual blend, L2 normalise, squared difference) runs on the
+//     accumulator registers, so Y is written exactly once and never re-read.
+#include "common.h"
+
+#include <type_traits>
+
+namespace cleora {
+namespace {
+
+struct RowArgs {
+    float *y;
+    uint64_t ldy;
+    const float *x_self;
+    uint64_t ldxs;
+    double *row_sqdiff;
+    float rw, alpha;
+    uint32_t flags;  // CLEORA_F_* with RESIDUAL already gated on 0 < rw < 1
+    uint32_t d;
+};
+
+struct SpmmArgs {
+    const uint64_t *rowptr;
+    const uint32_t *col;
+    const float *val;
+    const float *x;
+    uint64_t ldx;
+    uint64_t n_items;
+    uint32_t hub_threshold;
+    // hub kernels
+    const uint32_t *seg_row;
+    const uint64_t *seg_begin;
+    uint32_t hub_segment;
+    const uint32_t *hub_rows;
+    const uint64_t *hub_seg_first;
+    float *partial;
+    RowArgs r;
+};
+
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+
+template <int G>
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, uint32_t src, int gbase) {
+    if constexpr (G == 64) {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src);
+    } else {
+        return (uint32_t)__shfl((int)v, gbase + (int)src, 64);
+    }
+}
+template <int G>
+__device__ __forceinline__ float bcast_f32(float v, uint32_t src, int gbase) {
+    return __uint_as_float(bcast_u32<G>(__float_as_uint(v), src, gbase));
+}
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// element index of chunk v of lane gl:  j = (v*G + gl) * W
+template <int G, int V, int W, bool FULL>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, int gl, uint32_t d,
+                                         float (&r)[V][W]) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const uint32_t j = (uint32_t)(v * G + gl) * W;
+        if constexpr (W == 4) {
+            if (FULL || j < d) {
+                const float4 t = *reinterpret_cast<const float4 *>(p + j);
+                r[v][0] = t.x; r[v][1] = t.y; r[v][2] = t.z; r[v][3] = t.w;
+            } else {
+                r[v][0] = r[v][1] = r[v][2] = r[v][3] = 0.f;
+            }
+        } else {
+            r[v][0] = (FULL || j < d) ? p[j] : 0.f;
+        }
+    }
+}
+
+template <int G, int V, int W, bool FULL>
+__device__ __forceinline__ void store_row(float *__restrict__ p, int gl, uint32_t d,
+                                          const float (&r)[V][W]) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const uint32_t j = (uint32_t)(v * G + gl) * W;
+        if constexpr (W == 4) {
+            if (FULL || j < d)
+                *reinterpret_cast<float4 *>(p + j) = make_float4(r[v][0], r[v][1], r[v][2], r[v][3]);
+        } else {
+            if (FULL || j < d) p[j] = r[v][0];
+        }
+    }
+}
+
+// acc += sum over edges [beg, end) in stored order.  For G == 64 beg/end are wave-uniform.
+template <int G, int V, int W, bool FULL>
+__device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint64_t end, int gl,
+                                           int gbase, float (&acc)[V][W]) {
+    constexpr int U = (8 / V) > 0 ? (8 / V) : 1;
+    const uint32_t d = a.r.d;
+    for (uint64_t e = beg; e < end; e += G) {
+        const uint32_t cnt = (end - e) < (uint64_t)G ? (uint32_t)(end - e) : (uint32_t)G;
+        uint32_t cv = 0;
+        float wv = 0.f;
+        if ((uint32_t)gl < cnt) {
+            cv = a.col[e + gl];
+            wv = a.val[e + gl];
+        }
+        uint32_t k = 0;
+        for (; k + U <= cnt; k += U) {
+            float r[U][V][W];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t c = bcast_u32<G>(cv, k + u, gbase);
+                load_row<G, V, W, FULL>(a.x + (uint64_t)c * a.ldx, gl, d, r[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = bcast_f32<G>(wv, k + u, gbase);
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+#pragma unroll
+                    for (int q = 0; q < W; ++q) acc[v][q] = fadd(acc[v][q], fmul(w, r[u][v][q]));
+            }
+        }
+        for (; k < cnt; ++k) {
+            float r[V][W];
+            const uint32_t c = bcast_u32<G>(cv, k, gbase);
+            const float w = bcast_f32<G>(wv, k, gbase);
+            load_row<G, V, W, FULL>(a.x + (uint64_t)c * a.ldx, gl, d, r);
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int q = 0; q < W; ++q) acc[v][q] = fadd(acc[v][q], fmul(w, r[v][q]));
+        }
+    }
+}
+
+// Residual blend, L2 normalise, squared difference, store — on the accumulator registers.
+template <int G, int V, int W, bool FULL>
+__device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int gl, int gbase,
+                                           float (&acc)[V][W]) {
+    const uint32_t d = ra.d;
+    float xs[V][W];
+    if (ra.flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF))
+        load_row<G, V, W, FULL>(ra.x_self + row * ra.ldxs, gl, d, xs);
+
+    if (ra.flags & CLEORA_F_RESIDUAL) {
+        // dst[j] = alpha * dst[j] + rw * src[j]                      (src/embedding.rs:121-129)
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int q = 0; q < W; ++q)
+                acc[v][q] = fadd(fmul(ra.alpha, acc[v][q]), fmul(ra.rw, xs[v][q]));
+    }
+
+    if (ra.flags & CLEORA_F_L2NORM) {
+        float s = 0.f;
+        if (ra.flags & CLEORA_F_FASTNORM) {
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int q = 0; q < W; ++q) s = fadd(s, fmul(acc[v][q], acc[v][q]));
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) s = fadd(s, __shfl_xor(s, o, 64));
+        } else {
+            // the reference's order: sum_sq += v*v for j = 0..d-1   (src/embedding.rs:94-97)
+            const uint32_t nchunks = (d + W - 1) / W;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float sq[W];
+#pragma unroll
+                for (int q = 0; q < W; ++q) sq[q] = fmul(acc[v][q], acc[v][q]);
+                const uint32_t base = (uint32_t)v * G;
+                const uint32_t lim = nchunks > base ? ((nchunks - base) < (uint32_t)G ? (nchunks - base) : (uint32_t)G) : 0u;
+                for (uint32_t g = 0; g < lim; ++g) {
+#pragma unroll
+                    for (int q = 0; q < W; ++q) s = fadd(s, bcast_f32<G>(sq[q], g, gbase));
+                }
+            }
+        }
+        // norm = sum_sq.sqrt().max(1e-10); inv = 1/norm; v *= inv    (src/embedding.rs:98-102)
+        const float norm = fmaxf(sqrtf(s), 1e-10f);
+        const float inv = (1.0f / norm);
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int q = 0; q < W; ++q) acc[v][q] = fmul(acc[v][q], inv);
+    }
+
+    if (ra.flags & CLEORA_F_SQDIFF) {
+        // delta = dst - src (f32, as the reference), accumulated in f64 instead of the
+        // reference's whole-matrix f32 accumulator                   (src/embedding.rs:169-176)
+        double ds = 0.0;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const uint32_t j = (uint32_t)(v * G + gl) * W + q;
+                if (FULL || j < d) {
+                    const double delta = (double)fsub(acc[v][q], xs[v][q]);
+                    ds += delta * delta;
+                }
+            }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        if (gl == 0) ra.row_sqdiff[row] = ds;
+    }
+
+    store_row<G, V, W, FULL>(ra.y + row * ra.ldy, gl, d, acc);
+}
+
+template <int G, int V, int W>
+__device__ __forceinline__ void zero(float (&acc)[V][W]) {
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int q = 0; q < W; ++q) acc[v][q] = 0.f;
+}
+
+// ---- main kernel: one group per row, rows <= hub_threshold edges ------------------------
+template <int G, int V, int W, bool FULL>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    uint64_t row = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    bool active = row < a.n_items;
+    uint64_t beg = 0, end = 0;
+    if (active) {
+        beg = a.rowptr[row];
+        end = a.rowptr[row + 1];
+    }
+    if constexpr (G == 64) {
+        row = uniform_u64(row);
+        beg = uniform_u64(beg);
+        end = uniform_u64(end);
+    }
+    if (end - beg > a.hub_threshold) active = false;  // hub row: hub_* kernels own it
+    if (!active) {
+        if constexpr (G == 64) return;
+        beg = end = 0;
+    }
+    float acc[V][W];
+    zero<G, V, W>(acc);
+    accumulate<G, V, W, FULL>(a, beg, end, gl, gbase, acc);
+    if (active) finish_row<G, V, W, FULL>(a.r, row, gl, gbase, acc);
+}
+
+// ---- hub rows: partial sums per segment, then an in-order combine + epilogue --------------
+template <int G, int V, int W>
+__global__ __launch_bounds__(256) void hub_partial_kernel(const SpmmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    uint64_t seg = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    const bool active = seg < a.n_items;
+    uint64_t beg = 0, end = 0;
+    if (active) {
+        const uint32_t row = a.seg_row[seg];
+        beg = a.seg_begin[seg];
+        const uint64_t rend = a.rowptr[row + 1];
+        end = beg + a.hub_segment < rend ? beg + a.hub_segment : rend;
+    }
+    if constexpr (G == 64) {
+        if (!active) return;
+        seg = uniform_u64(seg);
+        beg = uniform_u64(beg);
+        end = uniform_u64(end);
+    }
+    float acc[V][W];
+    zero<G, V, W>(acc);
+    accumulate<G, V, W, false>(a, beg, end, gl, gbase, acc);
+    if (active) store_row<G, V, W, false>(a.partial + seg * (uint64_t)a.r.d, gl, a.r.d, acc);
+}
+
+template <int G, int V, int W>
+__global__ __launch_bounds__(256) void hub_finish_kernel(const SpmmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    const uint64_t h = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    if (h >= a.n_items) return;  // no cross-lane traffic between groups below
+    const uint64_t row = a.hub_rows[h];
+    const uint64_t s0 = a.hub_seg_first[h], s1 = a.hub_seg_first[h + 1];
+    float acc[V][W];
+    zero<G, V, W>(acc);
+    for (uint64_t s = s0; s < s1; ++s) {
+        float p[V][W];
+        load_row<G, V, W, false>(a.partial + s * (uint64_t)a.r.d, gl, a.r.d, p);
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int q = 0; q < W; ++q) acc[v][q] = fadd(acc[v][q], p[v][q]);
+    }
+    finish_row<G, V, W, false>(a.r, row, gl, gbase, acc);
+}
+
+// ---- stand-alone row epilogue (l2_normalize_inplace & friends) --------------------------
+template <int G, int V, int W>
+__global__ __launch_bounds__(256) void rowops_kernel(const float *x, uint64_t ldx, uint64_t n,
+                                                     const RowArgs ra) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    const uint64_t row = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    if (row >= n) return;
+    float acc[V][W];
+    load_row<G, V, W, false>(x + row * ldx, gl, ra.d, acc);
+    finish_row<G, V, W, false>(ra, row, gl, gbase, acc);
+}
+
+// ---- rows wider than the register-resident shapes: wave per row, two passes -----------------
+__global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64_t ldx, uint64_t n,
+                                                          const RowArgs ra) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + row * ldx;
+    const float *xs = (ra.flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) ? ra.x_self + row * ra.ldxs : nullptr;
+    float *yr = ra.y + row * ra.ldy;
+    const uint32_t d = ra.d;
+    float s = 0.f;
+    for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        float v = j < d ? xr[j] : 0.f;
+        if ((ra.flags & CLEORA_F_RESIDUAL) && j < d) v = fadd(fmul(ra.alpha, v), fmul(ra.rw, xs[j]));
+        if (j < d) yr[j] = v;
+        if (ra.flags & CLEORA_F_L2NORM) {
+            const float sq = fmul(v, v);
+            if (ra.flags & CLEORA_F_FASTNORM) {
+                float t = sq;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) t = fadd(t, __shfl_xor(t, o, 64));
+                s = fadd(s, t);
+            } else {
+                const uint32_t lim = (d - j0) < 64u ? (d - j0) : 64u;
+                for (uint32_t g = 0; g < lim; ++g) s = fadd(s, bcast_f32<64>(sq, g, 0));
+            }
+        }
+    }
+    float inv = 1.0f;
+    if (ra.flags & CLEORA_F_L2NORM) inv = (1.0f / fmaxf(sqrtf(s), 1e-10f));
+    double ds = 0.0;
+    for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        if (j < d) {
+            float v = yr[j];
+            if (ra.flags & CLEORA_F_L2NORM) v = fmul(v, inv);
+            if (ra.flags & CLEORA_F_SQDIFF) {
+                const double delta = (double)fsub(v, xs[j]);
+                ds += delta * delta;
+            }
+            yr[j] = v;
+        }
+    }
+    if (ra.flags & CLEORA_F_SQDIFF) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+        if (lane == 0) ra.row_sqdiff[row] = ds;
+    }
+}
+
+// ---- shape dispatch -----------------------------------------------------------------------------
+template <int N> using I = std::integral_constant<int, N>;
+constexpr uint32_t kMaxD4 = 64 * 8 * 4;  // widest register-resident row, float4 path
+constexpr uint32_t kMaxD1 = 64 * 16;     // scalar path
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Calls f(G, V, W, FULL) with the compile-time shape for a row of d floats.
+template <class F>
+bool dispatch_shape(uint32_t d, bool w4, F &&f) {
+    if (w4) {
+        const uint32_t chunks = d / 4;
+        if (chunks <= 8) { chunks == 8 ? f(I<8>{}, I<1>{}, I<4>{}, I<1>{}) : f(I<8>{}, I<1>{}, I<4>{}, I<0>{}); return true; }
+        if (chunks <= 16) { chunks == 16 ? f(I<16>{}, I<1>{}, I<4>{}, I<1>{}) : f(I<16>{}, I<1>{}, I<4>{}, I<0>{}); return true; }
+        if (chunks <= 32) { chunks == 32 ? f(I<32>{}, I<1>{}, I<4>{}, I<1>{}) : f(I<32>{}, I<1>{}, I<4>{}, I<0>{}); return true; }
+        if (chunks <= 64) { chunks == 64 ? f(I<64>{}, I<1>{}, I<4>{}, I<1>{}) : f(I<64>{}, I<1>{}, I<4>{}, I<0>{}); return true; }
+        if (chunks <= 128) { chunks == 128 ? f(I<64>{}, I<2>{}, I<4>{}, I<1>{}) : f(I<64>{}, I<2>{}, I<4>{}, I<0>{}); return true; }
+        if (chunks <= 256) { chunks == 256 ? f(I<64>{}, I<4>{}, I<4>{}, I<1>{}) : f(I<64>{}, I<4>{}, I<4>{}, I<0>{}); return true; }
+        if (chunks <= 512) { chunks == 512 ? f(I<64>{}, I<8>{}, I<4>{}, I<1>{}) : f(I<64>{}, I<8>{}, I<4>{}, I<0>{}); return true; }
+        return false;
+    }
+    if (d <= 64) { f(I<64>{}, I<1>{}, I<1>{}, I<0>{}); return true; }
+    if (d <= 128) { f(I<64>{}, I<2>{}, I<1>{}, I<0>{}); return true; }
+    if (d <= 256) { f(I<64>{}, I<4>{}, I<1>{}, I<0>{}); return true; }
+    if (d <= 512) { f(I<64>{}, I<8>{}, I<1>{}, I<0>{}); return true; }
+    if (d <= 1024) { f(I<64>{}, I<16>{}, I<1>{}, I<0>{}); return true; }
+    return false;
+}
+
+inline unsigned grid_for(uint64_t items, int per_block) {
+    return (unsigned)((items + per_block - 1) / per_block);
+}
+
+int ensure_partial(const cleora_graph *g, uint32_t d) {
+    const uint64_t need = g->n_hub_segments * (uint64_t)d;
+    if (need <= g->hub_partial_elems) return CLEORA_OK;
+    if (g->hub_partial) CL_HIP(hipFree(g->hub_partial));
+    g->hub_partial = nullptr;
+    g->hub_partial_elems = 0;
+    CL_HIP(hipMalloc(&g->hub_partial, need * sizeof(float)));
+    g->hub_partial_elems = need;
+    return CLEORA_OK;
+}
+
+// One SpMM over a column panel [c0, c0 + dp) that fits the register-resident shapes.
+int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stream) {
+    const uint32_t d = a.r.d;
+    bool ok = true;
+    if (g->n_hub_segments) {
+        SpmmArgs h = a;
+        h.n_items = g->n_hub_segments;
+        ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
+            hipLaunchKernelGGL((hub_partial_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
+                               dim3(grid_for(h.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, h);
+        });
+    }
+    if (ok && g->n_rows) {
+        a.n_items = g->n_rows;
+        ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
+            hipLaunchKernelGGL((spmm_rows_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value, (decltype(FULL)::value != 0)>),
+                               dim3(grid_for(a.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, a);
+        });
+    }
+    if (ok && g->n_hub_rows) {
+        SpmmArgs h = a;
+        h.n_items = g->n_hub_rows;
+        ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
+            hipLaunchKernelGGL((hub_finish_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
+                               dim3(grid_for(h.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, h);
+        });
+    }
+    if (!ok) {
+        set_error("internal: no kernel shape for d");
+        return CLEORA_E_INVALID;
+    }
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+}  // namespace
+
+int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
+                     float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
+                     double *row_sqdiff, hipStream_t stream) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    CL_REQUIRE(kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC, "unknown markov_type");
+    CL_REQUIRE(g->val[kind] != nullptr, "graph has no values for this markov_type");
+    CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
+    CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
+    CL_REQUIRE(x != y, "x and y must not alias");
+    if ((flags & CLEORA_F_RESIDUAL) && !(rw > 0.0f && rw < 1.0f)) flags &= ~CLEORA_F_RESIDUAL;  // embedding.rs:116
+    if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) {
+        if (!x_self && g->n_rows == g->n_cols) x_self = x;
+        CL_REQUIRE(x_self != nullptr, "x_self is required for RESIDUAL / SQDIFF on a row shard");
+    }
+    if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
+    if (g->n_rows == 0) return CLEORA_OK;
+
+    std::lock_guard<std::mutex> lock(g->mu);
+    CL_HIP(hipSetDevice(g->device));
+    if (g->n_hub_segments) {
+        const int rc = ensure_partial(g, d);
+        if (rc != CLEORA_OK) return rc;
+    }
+
+    SpmmArgs a{};
+    a.rowptr = g->rowptr;
+    a.col = g->col;
+    a.val = g->val[kind];
+    a.x = x;
+    a.ldx = ldx;
+    a.hub_threshold = g->hub_threshold;
+    a.seg_row = g->seg_row;
+    a.seg_begin = g->seg_begin;
+    a.hub_segment = g->hub_segment;
+    a.hub_rows = g->hub_rows;
+    a.hub_seg_first = g->hub_seg_first;
+    a.partial = g->hub_partial;
+    a.r.y = y;
+    a.r.ldy = ldy;
+    a.r.x_self = x_self;
+    a.r.ldxs = ldx;
+    a.r.row_sqdiff = row_sqdiff;
+    a.r.rw = rw;
+    a.r.alpha = 1.0f - rw;
+    a.r.flags = flags;
+    a.r.d = d;
+
+    const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
+                    (!x_self || aligned16(x_self));
+    if (d <= (w4 ? kMaxD4 : kMaxD1)) return propagate_panel(g, a, w4, stream);
+
+    // Wider rows: SpMM column panel by column panel without the epilogue, then the wide row pass.
+    const uint32_t panel = w4 ? kMaxD4 : kMaxD1;
+    for (uint32_t c0 = 0; c0 < d; c0 += panel) {
+        SpmmArgs p = a;
+        p.x = x + c0;
+        p.r.y = y + c0;
+        p.r.d = (d - c0) < panel ? (d - c0) : panel;
+        p.r.flags = 0;
+        const int rc = propagate_panel(g, p, w4, stream);
+        if (rc != CLEORA_OK) return rc;
+    }
+    if (flags & (CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF))
+        return launch_rowops(y, ldy, g->n_rows, d, y, ldy, flags, rw, x_self, row_sqdiff, stream);
+    return CLEORA_OK;
+}
+
+int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
+                  uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
+                  hipStream_t stream) {
+    CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
+    CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
+    if ((flags & CLEORA_F_RESIDUAL) && !(rw > 0.0f && rw < 1.0f)) flags &= ~CLEORA_F_RESIDUAL;
+    if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) CL_REQUIRE(x_self != nullptr, "x_self is NULL");
+    if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
+    if (n == 0) return CLEORA_OK;
+    RowArgs ra{};
+    ra.y = y;
+    ra.ldy = ldy;
+    ra.x_self = x_self;
+    ra.ldxs = ldx;
+    ra.row_sqdiff = row_sqdiff;
+    ra.rw = rw;
+    ra.alpha = 1.0f - rw;
+    ra.flags = flags;
+    ra.d = d;
+    const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
+                    (!x_self || aligned16(x_self));
+    const bool ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
+        hipLaunchKernelGGL((rowops_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
+                           dim3(grid_for(n, 256 / decltype(G)::value)), dim3(256), 0, stream, x, ldx, n, ra);
+    });
+    if (!ok) {
+        hipLaunchKernelGGL(rowops_wide_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, x, ldx, n, ra);
+    }
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+}  // namespace cleora

@@ -1,0 +1,182 @@
+/*
+ * cleora_hip.h — C ABI of libcleora_hip.so: the MI355X (gfx950) implementation of
+ * pycleora 3.2.1's Markov-propagation hot path.
+ *
+ * The reference has no C ABI of its own: its boundary is the PyO3 class
+ * `pycleora.pycleora.SparseMatrix` (src/lib.rs:84-476) whose methods call
+ * `NdArrayMatrix::*` (src/embedding.rs).  BASELINE.json:north_star asks for the Rust
+ * host to reach the kernels "through a thin extern-C FFI"; the entry points below
+ * are exactly what that FFI binds.  Every function cites the reference interface it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the call sites in src/embedding.rs / src/lib.rs.
+ *
+ * Conventions
+ *   - plain C, opaque handles, plain pointers and sizes; no C++/torch types.
+ *   - every function returns CLEORA_OK (0) or a negative CLEORA_E_* code;
+ *     cleora_last_error() returns a thread-local message for the last failure.
+ *   - "*_dev" entry points take DEVICE pointers and a hipStream_t (as void*; NULL =
+ *     the default stream) and only enqueue work.  The others take HOST pointers,
+ *     borrow them for the duration of the call and return with results on the host.
+ *   - matrices are row-major f32 with a leading dimension in ELEMENTS (ld >= d).
+ *   - there is no CPU fallback: without a gfx950 device every compute entry point
+ *     fails with CLEORA_E_NODEVICE / CLEORA_E_HIP.
+ */
+#ifndef CLEORA_HIP_H
+#define CLEORA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLEORA_ABI_VERSION 1
+
+#define CLEORA_OK 0
+#define CLEORA_E_INVALID (-1)   /* bad argument (shape, null pointer, unknown enum) */
+#define CLEORA_E_OOM (-2)       /* device or host allocation failed */
+#define CLEORA_E_HIP (-3)       /* a HIP runtime call failed; see cleora_last_error() */
+#define CLEORA_E_NODEVICE (-4)  /* no usable GPU */
+
+/* MarkovType (src/embedding.rs:7-10) */
+#define CLEORA_LEFT 0
+#define CLEORA_SYMMETRIC 1
+
+/* flags of cleora_propagate_dev / cleora_rowops_dev */
+#define CLEORA_F_L2NORM 1u    /* fuse l2_normalize_inplace (src/embedding.rs:88-104) into the epilogue */
+#define CLEORA_F_FASTNORM 2u  /* sum of squares by wave butterfly instead of the reference's
+                                 sequential order (last-ulp differences; default is sequential) */
+#define CLEORA_F_RESIDUAL 4u  /* y = (1-rw)*y + rw*x_self before the norm (src/embedding.rs:121-129) */
+#define CLEORA_F_SQDIFF 8u    /* row_sqdiff[r] = sum_j (y[r][j]-x_self[r][j])^2 in f64 (src/embedding.rs:169-176) */
+
+typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct SparseMatrix, src/sparse_matrix.rs:56-78) */
+
+typedef struct cleora_graph_info {
+    uint64_t n_rows, n_cols, nnz;
+    uint64_t n_hub_rows;      /* rows longer than hub_threshold: split across waves */
+    uint64_t n_hub_segments;
+    uint64_t device_bytes;    /* HBM held by the handle */
+    uint32_t hub_threshold, hub_segment;
+    int32_t device;
+    int32_t has_symmetric;
+} cleora_graph_info;
+
+/* ---- library / device ------------------------------------------------------------ */
+int cleora_abi_version(void);
+const char *cleora_last_error(void);
+int cleora_device_count(int *count);
+int cleora_set_device(int device);
+
+/* ---- device memory + streams (plumbing for hosts that do not bring their own) ------ */
+int cleora_malloc(uint64_t bytes, void **dev_ptr);
+int cleora_free(void *dev_ptr);
+int cleora_memcpy_h2d(void *dst_dev, const void *src_host, uint64_t bytes, void *stream);
+int cleora_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t bytes, void *stream);
+int cleora_memcpy_d2d(void *dst_dev, const void *src_dev, uint64_t bytes, void *stream);
+int cleora_memset(void *dst_dev, int value, uint64_t bytes, void *stream);
+int cleora_stream_sync(void *stream);
+
+/* ---- graph: the CSR the kernels read ------------------------------------------------
+ * Replaces the in-memory `edges`/`slices` of struct SparseMatrix (src/sparse_matrix.rs:56-78):
+ * AoS {u32 col, f32 left, f32 sym} + (start,end) pairs become SoA rowptr u64[n_rows+1],
+ * col u32[nnz], one f32[nnz] stream per MarkovType (val_sym may be NULL).
+ * Rows are the OUTPUT rows of this shard (all rows on one GPU; a row block when the graph
+ * is row-partitioned); col indexes the n_cols rows of the full embedding matrix.
+ * hub_threshold: rows with more edges are split into hub_segment-edge segments that run
+ * on separate wavefronts (0 = defaults 1024 / 256).  Copies the arrays; the caller keeps
+ * ownership of its buffers. */
+int cleora_graph_create(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
+                        const uint64_t *rowptr, const uint32_t *col, const float *val_left,
+                        const float *val_sym, uint32_t hub_threshold, uint32_t hub_segment,
+                        cleora_graph **out);
+/* Same, but rowptr/col/val_* are DEVICE pointers on `device` and are ADOPTED without a copy:
+ * they must stay valid until cleora_graph_destroy (which does not free them). */
+int cleora_graph_create_dev(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
+                            const uint64_t *rowptr_dev, const uint32_t *col_dev,
+                            const float *val_left_dev, const float *val_sym_dev,
+                            uint32_t hub_threshold, uint32_t hub_segment, cleora_graph **out);
+int cleora_graph_destroy(cleora_graph *g);
+int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info);
+
+/* ---- device-pointer hot path ------------------------------------------------------- */
+
+/* NdArrayMatrix::spmm_kernel / multiply_into (src/embedding.rs:41-86) with the optional
+ * fused epilogue of embed_full (residual blend :121-129, l2_normalize_inplace :88-104,
+ * squared-difference for the RMSE test :169-176).
+ *   y[r,:] = sum_{e in row r, stored order} val_e * x[col_e,:]     separate f32 mul / add
+ * Rows without edges produce zeros (the reference zero-fills first, :21/:47).
+ * x: n_cols x d (ldx); y: n_rows x d (ldy); x_self: the n_rows rows of the previous iterate
+ * that correspond to this shard's rows (ld = ldx), needed by RESIDUAL / SQDIFF;
+ * row_sqdiff: f64[n_rows] or NULL.  x and y must not alias. */
+int cleora_propagate_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx,
+                         uint32_t d, float *y, uint64_t ldy, uint32_t flags,
+                         float residual_weight, const float *x_self, double *row_sqdiff,
+                         void *stream);
+
+/* Row-wise epilogue alone: NdArrayMatrix::l2_normalize_inplace (src/embedding.rs:88-104) when
+ * flags = CLEORA_F_L2NORM; same flags as above.  x may equal y (in place). */
+int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
+                      uint32_t flags, float residual_weight, const float *x_self,
+                      double *row_sqdiff, void *stream);
+
+/* initialize_deterministically_rust + init_value (src/lib.rs:69-81, 478-488) from the cached
+ * XXH64 entity hashes (hash_entity, src/entity.rs:109-114).  Bit-exact (integer arithmetic). */
+int cleora_init_dev(const uint64_t *entity_hash_dev, uint64_t n, uint32_t d, int64_t seed,
+                    float *x, uint64_t ldx, void *stream);
+
+/* Deterministic (fixed-order) sum of a f64 vector into *out_dev; used for the RMSE of
+ * embed_full_with_convergence (src/embedding.rs:169-183).  workspace: f64[cleora_reduce_workspace(n)]. */
+uint64_t cleora_reduce_workspace(uint64_t n);
+int cleora_reduce_sum_f64_dev(const double *v, uint64_t n, double *workspace, double *out_dev,
+                              void *stream);
+
+/* ---- whitening (pycleora/__init__.py:130-164) -------------------------------------- */
+
+/* colsum[c] = sum_r x[r,c] in f64 (the mean of :136 is colsum / n).
+ * workspace: f64[cleora_colsum_workspace(n, d)]. */
+uint64_t cleora_colsum_workspace(uint64_t n, uint32_t d);
+int cleora_colsum_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *workspace,
+                      double *colsum_dev, void *stream);
+
+/* gram[i,j] = sum_r (x[r,i]-mean[i]) * (x[r,j]-mean[j]) in f64 on the f64 matrix cores
+ * (:138-143 without the 1/(n-1) factor).  gram: d x d row-major, full symmetric matrix.
+ * workspace: f64[cleora_gram_workspace(n, d)]. */
+uint64_t cleora_gram_workspace(uint64_t n, uint32_t d);
+int cleora_centered_gram_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                             const double *mean_dev, double *workspace, double *gram_dev,
+                             void *stream);
+
+/* out[r,:] = (x[r,:] - mean_f32) @ transform   (f32 MFMA; :157-163).
+ * transform: d x k row-major f32; out: n x k (ldo). */
+int cleora_project_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                       const float *mean_f32_dev, const float *transform_dev, uint32_t k,
+                       float *out, uint64_t ldo, void *stream);
+
+/* ---- host-pointer entry points: what the PyO3 methods call ------------------------- */
+
+/* SparseMatrix::markov_propagate → NdArrayMatrix::multiply (src/lib.rs:29-47, src/embedding.rs:15-39).
+ * x: n_cols x d host; y: n_rows x d host (fresh output, like `to_pyarray`). */
+int cleora_propagate(const cleora_graph *g, int markov_type, const float *x_host, uint32_t d,
+                     float *y_host);
+
+/* SparseMatrix::l2_normalize (src/lib.rs:414-424). */
+int cleora_l2_normalize(const float *x_host, uint64_t n, uint32_t d, float *y_host);
+
+/* SparseMatrix::initialize_deterministically (src/lib.rs:242-252). */
+int cleora_init(const uint64_t *entity_hash_host, uint64_t n, uint32_t d, int64_t seed,
+                float *x_host);
+
+/* SparseMatrix::embed_fast / embed_fast_convergence (src/lib.rs:320-412) →
+ * NdArrayMatrix::embed_full / embed_full_with_convergence (src/embedding.rs:106-188).
+ * Device-resident loop: init (or x0_host if non-NULL), `max_iterations` x (SpMM, residual for
+ * 0 < rw < 1, L2), optional RMSE early stop (threshold > 0, from iteration 1).
+ * The graph must be square (n_rows == n_cols).  out_host: n x d.  iterations_run may be NULL. */
+int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
+                 int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
+                 float residual_weight, float convergence_threshold, uint32_t flags,
+                 float *out_host, uint64_t *iterations_run);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLEORA_HIP_H */

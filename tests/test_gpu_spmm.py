@@ -1,0 +1,188 @@
+"""GPU parity: SpMM + fused epilogue through the C ABI vs the CPU oracle.
+
+Bit-exact (assert_array_equal) wherever rows are not split: the kernel consumes each row's
+edges in stored order with separate f32 multiply/add exactly as src/embedding.rs:80-82.
+Hub rows (split across waves) are compared with a relative tolerance of 2e-6 * sum|terms|.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from cleora_amd import _hip
+from tests.graphs import random_csr
+
+pytestmark = pytest.mark.gpu
+
+L = None
+
+
+def setup_module(module):
+    global L
+    L = _hip.lib()
+    assert _hip.device_count() >= 1, "no GPU visible"
+
+
+def run_dev(g, kind, x, flags=0, rw=0.0, x_self=None, want_sqdiff=False):
+    n_rows = g.info().n_rows
+    d = x.shape[1]
+    dx = _hip.DevArray.from_host(x)
+    dy = _hip.DevArray((n_rows, d), np.float32)
+    L.cleora_memset(dy.ptr, 0xFF, dy.nbytes, None)  # poison: every row must be written
+    dxs = _hip.DevArray.from_host(x_self) if x_self is not None else None
+    dsq = _hip.DevArray((n_rows,), np.float64) if want_sqdiff else None
+    _hip.check(L.cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, flags, rw,
+                                      dxs.ptr if dxs else None, dsq.ptr if dsq else None, None))
+    _hip.check(L.cleora_stream_sync(None))
+    y = dy.to_host()
+    return (y, dsq.to_host()) if want_sqdiff else y
+
+
+@pytest.mark.parametrize("d", [256, 128, 32, 8, 64, 512, 1024, 2048, 100, 4, 20, 260])
+def test_spmm_bit_exact_vs_oracle(d):
+    n = 3000 if d <= 512 else 600
+    rowptr, col, vl, vs = random_csr(n, 12, seed=d, empty_frac=0.05)
+    x = np.random.default_rng(d + 1).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl, vs)
+    for kind, val in ((_hip.LEFT, vl), (_hip.SYMMETRIC, vs)):
+        want = oracle.spmm(rowptr, col, val, x)
+        got = run_dev(g, kind, x)
+        np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("d", [3, 7, 33, 65, 129, 250, 1000])
+def test_spmm_scalar_path_bit_exact(d):
+    n = 1200
+    rowptr, col, vl, _ = random_csr(n, 9, seed=100 + d, empty_frac=0.1)
+    x = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x), oracle.spmm(rowptr, col, vl, x))
+
+
+@pytest.mark.parametrize("d", [256, 64, 1024, 48])
+def test_fused_l2_bit_exact(d):
+    n = 2500
+    rowptr, col, vl, _ = random_csr(n, 15, seed=7 * d, empty_frac=0.02)
+    x = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    want = oracle.l2_normalize(oracle.spmm(rowptr, col, vl, x))
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
+    np.testing.assert_array_equal(got, want)
+    fast = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM | _hip.F_FASTNORM)
+    np.testing.assert_allclose(fast, want, rtol=0, atol=3e-7)
+
+
+def test_residual_and_sqdiff():
+    n, d = 2000, 256
+    rowptr, col, vl, _ = random_csr(n, 10, seed=5)
+    x = np.random.default_rng(6).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    rw = np.float32(0.3)
+    y = oracle.spmm(rowptr, col, vl, x)
+    blended = (np.float32(1.0) - rw) * y + rw * x      # f32: alpha*dst + rw*src
+    want = oracle.l2_normalize(blended)
+    got, sq = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM | _hip.F_RESIDUAL | _hip.F_SQDIFF,
+                      rw=float(rw), want_sqdiff=True)
+    np.testing.assert_array_equal(got, want)
+    delta = (want - x).astype(np.float64)
+    np.testing.assert_allclose(sq, (delta * delta).sum(axis=1), rtol=1e-12)
+    # rw outside (0,1) disables the blend (src/embedding.rs:116)
+    for bad in (0.0, 1.0, 1.5):
+        got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM | _hip.F_RESIDUAL, rw=bad)
+        np.testing.assert_array_equal(got, oracle.l2_normalize(y))
+
+
+@pytest.mark.parametrize("d", [256, 64, 1024])
+def test_hub_rows_split(d):
+    n = 4000
+    hubs = [(17, 5000), (1234, 1025), (3999, 20000), (2000, 1024)]  # 1024 = threshold: not split
+    rowptr, col, vl, _ = random_csr(n, 8, seed=11, hubs=hubs)
+    x = np.random.default_rng(12).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    info = g.info()
+    assert info.n_hub_rows == 3 and info.hub_threshold == 1024
+    want = oracle.spmm(rowptr, col, vl, x)
+    got = run_dev(g, _hip.LEFT, x)
+    hub_rows = np.array([17, 1234, 3999])
+    mask = np.ones(n, bool)
+    mask[hub_rows] = False
+    np.testing.assert_array_equal(got[mask], want[mask])          # unsplit rows: bit exact
+    # split rows: different summation order, same terms
+    absx = np.abs(x)
+    bound = oracle.spmm(rowptr, col, np.abs(vl), absx)[hub_rows]
+    assert np.all(np.abs(got[hub_rows] - want[hub_rows]) <= 2e-6 * bound + 1e-30)
+    # with the epilogue
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
+    np.testing.assert_allclose(got, oracle.l2_normalize(want), rtol=0, atol=2e-6)
+    # custom thresholds: everything split at 16 edges/segment still agrees
+    g2 = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=4, hub_segment=16)
+    np.testing.assert_allclose(run_dev(g2, _hip.LEFT, x), want, rtol=0, atol=1e-4 * np.abs(want).max())
+
+
+def test_row_shard_rectangular():
+    # a row block of a bigger graph: n_rows < n_cols, x_self offset
+    n, d = 3000, 128
+    rowptr, col, vl, _ = random_csr(n, 10, seed=21)
+    x = np.random.default_rng(22).standard_normal((n, d)).astype(np.float32)
+    r0, r1 = 1000, 1800
+    rp = (rowptr[r0:r1 + 1] - rowptr[r0]).astype(np.uint64)
+    e0, e1 = int(rowptr[r0]), int(rowptr[r1])
+    g = _hip.Graph.from_host(rp, col[e0:e1], vl[e0:e1], n_cols=n)
+    want = oracle.l2_normalize(oracle.spmm(rowptr, col, vl, x))[r0:r1]
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_host_entry_points_and_errors():
+    n, d = 500, 32
+    rowptr, col, vl, vs = random_csr(n, 6, seed=31)
+    x = np.random.default_rng(32).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl, vs)
+    y = np.empty((n, d), np.float32)
+    _hip.check(L.cleora_propagate(g.handle, _hip.SYMMETRIC, _hip.ptr(x), d, _hip.ptr(y)))
+    np.testing.assert_array_equal(y, oracle.spmm(rowptr, col, vs, x))
+    _hip.check(L.cleora_l2_normalize(_hip.ptr(x), n, d, _hip.ptr(y)))
+    np.testing.assert_array_equal(y, oracle.l2_normalize(x))
+    with pytest.raises(ValueError):
+        _hip.check(L.cleora_propagate(g.handle, 7, _hip.ptr(x), d, _hip.ptr(y)))
+    g1 = _hip.Graph.from_host(rowptr, col, vl)  # no symmetric values
+    with pytest.raises(ValueError):
+        _hip.check(L.cleora_propagate(g1.handle, _hip.SYMMETRIC, _hip.ptr(x), d, _hip.ptr(y)))
+    bad = col.copy()
+    bad[3] = n + 5
+    with pytest.raises(ValueError):
+        _hip.Graph.from_host(rowptr, bad, vl)
+
+
+def test_init_bit_exact():
+    rng = np.random.default_rng(41)
+    hashes = rng.integers(0, 1 << 63, 3000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 3000, dtype=np.uint64)
+    for d, seed in ((256, 0), (128, 42), (33, -7), (1, 1 << 40)):
+        out = np.empty((hashes.shape[0], d), np.float32)
+        _hip.check(L.cleora_init(_hip.ptr(hashes), hashes.shape[0], d, seed, _hip.ptr(out)))
+        np.testing.assert_array_equal(out, oracle.init(hashes, d, seed))
+
+
+def test_embed_loop_bit_exact():
+    n, d = 2000, 64
+    rowptr, col, vl, vs = random_csr(n, 10, seed=51)
+    hashes = np.random.default_rng(52).integers(0, 1 << 62, n, dtype=np.uint64)
+    g = _hip.Graph.from_host(rowptr, col, vl, vs)
+    x0 = oracle.init(hashes, d, 3)
+    for kind, val, rw in ((_hip.LEFT, vl, 0.0), (_hip.SYMMETRIC, vs, 0.25)):
+        want, _ = oracle.embed(rowptr, col, val, x0, 7, residual_weight=rw)
+        out = np.empty((n, d), np.float32)
+        it = ctypes.c_uint64(0)
+        _hip.check(L.cleora_embed(g.handle, _hip.ptr(hashes), None, kind, d, 7, 3, rw, 0.0, 0,
+                                  _hip.ptr(out), ctypes.byref(it)))
+        assert it.value == 7
+        np.testing.assert_array_equal(out, want)
+    # convergence: same stopping iteration as the oracle for a threshold away from the boundary
+    want, it_want = oracle.embed(rowptr, col, vl, x0, 50, convergence_threshold=1e-3)
+    out = np.empty((n, d), np.float32)
+    it = ctypes.c_uint64(0)
+    _hip.check(L.cleora_embed(g.handle, _hip.ptr(hashes), None, _hip.LEFT, d, 50, 3, 0.0, 1e-3, 0,
+                              _hip.ptr(out), ctypes.byref(it)))
+    assert it.value == it_want and it_want < 50
+    np.testing.assert_array_equal(out, want)

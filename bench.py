@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — the Markov-propagation hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 40 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one propagate iteration of BASELINE.json's metric workload: CSR x dense SpMM with
+the L2 normalisation fused into its epilogue (src/embedding.rs:106-136, one loop body of
+embed_full) on the synthetic power-law graph |V| = 10M, |E| = nnz ~ 200M, d = 256, plus, for
+N > 1, the all-gather of the row-partitioned next iterate (cleora_amd/sharded.py).  The graph,
+X and the CSR are resident in HBM before the timed region.  Total work is fixed as N grows
+("strong" scaling, as BASELINE.json quotes the same graph at 1/2/4/8 GPUs).
+
+Prints ONE JSON line on rank 0.  `value` = nnz * d * steps / seconds (edge*dim/s, whole job);
+`roofline` is for the dominant kernel (spmm_rows_kernel) from HIP events recorded inside the
+timed region on the launch stream; `cpu_baseline` is the oracle's reference-order CPU port timed
+on this box's host cores (N = 1, rank 0 only) — a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from cleora_amd import _hip, sharded, synth  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming ceiling)
+
+
+def algorithmic_bytes(nnz, n_rows_written, n_rowptr, d):
+    """SURVEY.md §8(d) gather model: col + one value stream, rowptr, one gathered X row per
+    edge, Y written once (the L2 norm is fused)."""
+    return nnz * 8 + (n_rowptr + 1) * 8 + nnz * d * 4 + n_rows_written * d * 4
+
+
+def cpu_baseline(g, x_dev, n, d, budget_s=12.0):
+    """Reference-order CPU port (oracle AoS SpMM + separate L2 pass, all host cores) on whole
+    iterations of the same graph and X; bounded to about `budget_s` seconds."""
+    import oracle
+    rowptr = g["rowptr"].cpu().numpy().astype(np.uint64)
+    edges = np.empty(g["nnz"], dtype=oracle.EDGE_DTYPE)
+    edges["col"] = g["col"].cpu().numpy().view(np.uint32)
+    edges["left"] = g["val_left"].cpu().numpy()
+    edges["sym"] = g["val_sym"].cpu().numpy()
+    x = x_dev[:n].cpu().numpy()
+    y = np.empty_like(x)
+    threads = oracle.max_threads()
+    oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)  # page-touch + pool spin-up
+    count, t0 = 0, time.perf_counter()
+    while True:
+        oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)
+        x, y = y, x
+        count += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or count >= 5:
+            break
+    return {"value": g["nnz"] * d * count / el, "unit": "edge*dim/s", "cores": threads,
+            "kind": "port", "iterations_per_sec": count / el,
+            "sample": f"{count} full iteration(s) of the same graph and X (SpMM, reference AoS edge "
+                      f"layout, dynamic row schedule + separate L2 pass), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=10_000_000)
+    ap.add_argument("--pairs", type=int, default=95_000_000)
+    ap.add_argument("--dim", type=int, default=256)
+    ap.add_argument("--overlap-steps", type=int, default=0,
+                    help="row blocks per rank per iteration (gather of block k overlaps SpMM of k+1); "
+                         "0 = 1 on one GPU, 4 otherwise")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; cleora_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+
+    d = args.dim
+    steps_per_iter = args.overlap_steps or (1 if world == 1 else 4)
+    g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)  # same seed on every rank
+    n, nnz = g["n"], g["nnz"]
+    sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world,
+                              steps_per_iter, sharded.HipBackend(dev))
+    # algorithmic bytes of this rank's dominant-kernel launches (rows the rows-kernel owns)
+    deg = torch.diff(g["rowptr"])
+    launch_bytes = []
+    for k in range(steps_per_iter):
+        r0 = min((k * world + rank) * sg.block, n)
+        r1 = min(r0 + sg.block, n)
+        dk = deg[r0:r1]
+        main_rows = dk <= sg.blocks[k].info().hub_threshold
+        launch_bytes.append(algorithmic_bytes(int(dk[main_rows].sum()), sg.block, sg.block, d))
+    hashes = synth.entity_hashes(n, 0, dev)
+    x = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
+    x_next = torch.zeros_like(x)
+    L = _hip.lib()
+    _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d,
+                                 torch.cuda.current_stream().cuda_stream))
+    keep_full = g if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+    del g, deg, hashes
+    torch.cuda.empty_cache()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sg.propagate(_hip.LEFT, x, x_next)
+        x, x_next = x_next, x
+    for blk in sg.blocks:
+        blk.set_timing(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sg.propagate(_hip.LEFT, x, x_next)
+        x, x_next = x_next, x
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    # dominant kernel: average launch duration from the HIP events recorded in the timed region
+    rows_ms, calls, other_ms = 0.0, 0, 0.0
+    for blk in sg.blocks:
+        ms, c = blk.get_timing()
+        blk.set_timing(False)
+        rows_ms += ms[1]
+        other_ms += ms[0] + ms[2]
+        calls += c
+    avg_ms = rows_ms / max(calls, 1)
+    avg_bytes = sum(launch_bytes) / len(launch_bytes)
+    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    finite = bool(torch.isfinite(x[:n]).all())
+    norm_err = float((x[:n].double().pow(2).sum(1).sqrt() - 1).abs().max())
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath))
+                if rec.get("n") == n and rec.get("nnz") == nnz and rec.get("d") == d and world == 1:
+                    traffic = rec.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "propagate edges*dim/sec (SpMM + fused L2 norm"
+                      + (" + all-gather" if world > 1 else "") + "), |V|=10M |E|=200M d=256",
+            "value": nnz * d * args.steps / elapsed,
+            "unit": "edge*dim/s",
+            "iterations_per_sec": args.steps / elapsed,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic power-law graph, reflexive column semantics "
+                                   f"(BASELINE config 3): n={n}, nnz={nnz}, d={d}, left Markov",
+                       "n": n, "nnz": nnz, "d": d,
+                       "parallelism": f"row-block-cyclic x{world}, {steps_per_iter} block(s)/rank/iter"
+                                      + (", in-place RCCL all-gather overlapped with the next block" if world > 1 else ""),
+                       "seed": 2},
+            "roofline": {"bound": "hbm", "kernel": "spmm_rows_kernel<64,1,4,true>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
+                         "launches": calls, "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
+                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+            "checks": {"finite": finite, "max_abs_row_norm_minus_1": norm_err},
+        }
+        if keep_full is not None:
+            out["cpu_baseline"] = cpu_baseline(keep_full, x, n, d)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

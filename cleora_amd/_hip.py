@@ -46,6 +46,8 @@ SIGNATURES = {
                                         ctypes.POINTER(vp)]),
     "cleora_graph_destroy": (c_int, [vp]),
     "cleora_graph_get_info": (c_int, [vp, ctypes.POINTER(GraphInfo)]),
+    "cleora_graph_set_timing": (c_int, [vp, c_int]),
+    "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
     "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
     "cleora_rowops_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
     "cleora_init_dev": (c_int, [vp, c_u64, c_u32, c_i64, vp, c_u64, vp]),
@@ -157,6 +159,16 @@ class Graph:
         gi = GraphInfo()
         check(lib().cleora_graph_get_info(self.handle, ctypes.byref(gi)))
         return gi
+
+    def set_timing(self, enable):
+        check(lib().cleora_graph_set_timing(self.handle, 1 if enable else 0))
+
+    def get_timing(self):
+        """(ms[hub_partial, spmm_rows, hub_finish] summed, calls) since the last query."""
+        ms = (ctypes.c_double * 3)()
+        calls = c_u64(0)
+        check(lib().cleora_graph_get_timing(self.handle, ctypes.byref(ms), ctypes.byref(calls)))
+        return [ms[0], ms[1], ms[2]], calls.value
 
     def close(self):
         if self.handle:

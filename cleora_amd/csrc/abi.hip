@@ -108,6 +108,8 @@ void free_graph(cleora_graph *g) {
     (void)hipFree(g->seg_row);
     (void)hipFree(g->seg_begin);
     (void)hipFree(g->hub_partial);
+    for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_used) (void)hipEventDestroy(e);
     delete g;
 }
 
@@ -283,6 +285,31 @@ int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info) {
     info->hub_segment = g->hub_segment;
     info->device = g->device;
     info->has_symmetric = g->val[1] != nullptr;
+    return CLEORA_OK;
+}
+
+int cleora_graph_set_timing(cleora_graph *g, int enable) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    std::lock_guard<std::mutex> lock(g->mu);
+    g->timing = enable != 0;
+    return CLEORA_OK;
+}
+
+int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls) {
+    CL_REQUIRE(g != nullptr && ms != nullptr && calls != nullptr, "graph / ms / calls is NULL");
+    std::lock_guard<std::mutex> lock(g->mu);
+    ms[0] = ms[1] = ms[2] = 0.0;
+    *calls = g->ev_used.size() / 4;
+    if (!g->ev_used.empty()) CL_HIP(hipEventSynchronize(g->ev_used.back()));
+    for (size_t i = 0; i + 3 < g->ev_used.size(); i += 4) {
+        for (int k = 0; k < 3; ++k) {
+            float t = 0.f;
+            CL_HIP(hipEventElapsedTime(&t, g->ev_used[i + k], g->ev_used[i + k + 1]));
+            ms[k] += (double)t;
+        }
+    }
+    g->ev_pool.insert(g->ev_pool.end(), g->ev_used.begin(), g->ev_used.end());
+    g->ev_used.clear();
     return CLEORA_OK;
 }
 

@@ -7,6 +7,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/cleora_hip.h"
 
@@ -57,6 +58,12 @@ struct cleora_graph {
     mutable std::mutex mu;
     mutable float *hub_partial = nullptr;
     mutable uint64_t hub_partial_elems = 0;
+
+    // optional per-kernel timing (cleora_graph_set_timing): 4 events per propagate call,
+    // recorded on the launch stream: [hub_partial | rows | hub_finish]
+    mutable bool timing = false;
+    mutable std::vector<hipEvent_t> ev_pool;   // recycled events
+    mutable std::vector<hipEvent_t> ev_used;   // 4 per recorded call, in order
 };
 
 namespace cleora {

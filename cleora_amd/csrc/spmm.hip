@@ -427,10 +427,28 @@ int ensure_partial(const cleora_graph *g, uint32_t d) {
     return CLEORA_OK;
 }
 
+hipEvent_t take_event(const cleora_graph *g) {
+    hipEvent_t e = nullptr;
+    if (!g->ev_pool.empty()) {
+        e = g->ev_pool.back();
+        g->ev_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        return nullptr;
+    }
+    g->ev_used.push_back(e);
+    return e;
+}
+
+inline void mark(const cleora_graph *g, hipStream_t stream) {
+    if (!g->timing) return;
+    if (hipEvent_t e = take_event(g)) (void)hipEventRecord(e, stream);
+}
+
 // One SpMM over a column panel [c0, c0 + dp) that fits the register-resident shapes.
 int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stream) {
     const uint32_t d = a.r.d;
     bool ok = true;
+    mark(g, stream);
     if (g->n_hub_segments) {
         SpmmArgs h = a;
         h.n_items = g->n_hub_segments;
@@ -439,6 +457,7 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
                                dim3(grid_for(h.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, h);
         });
     }
+    mark(g, stream);
     if (ok && g->n_rows) {
         a.n_items = g->n_rows;
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
@@ -446,6 +465,7 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
                                dim3(grid_for(a.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, a);
         });
     }
+    mark(g, stream);
     if (ok && g->n_hub_rows) {
         SpmmArgs h = a;
         h.n_items = g->n_hub_rows;
@@ -454,6 +474,7 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
                                dim3(grid_for(h.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, h);
         });
     }
+    mark(g, stream);
     if (!ok) {
         set_error("internal: no kernel shape for d");
         return CLEORA_E_INVALID;

@@ -1,0 +1,134 @@
+"""Row-partitioned Markov propagation: one process per GPU, RCCL all-gather over xGMI.
+
+The reference is single-process (rayon over rows, src/embedding.rs:59-63); this is the
+multi-GPU design BASELINE.json:north_star asks for, not a port of anything:
+
+  * output rows are independent, each needs arbitrary rows of the PREVIOUS iterate, so every
+    rank keeps a full replica of X (n x d f32: 10 GB at |V| = 10M, d = 256 — small next to
+    288 GB of HBM) and owns a set of row blocks of the CSR and of the next iterate;
+  * rows are dealt out BLOCK-CYCLICALLY: with P ranks and K steps per iteration the padded row
+    space is cut into P*K blocks of B rows and rank r owns blocks {k*P + r}.  Step k of an
+    iteration computes block (k, r) on every rank and then all-gathers exactly the contiguous
+    row range [k*P*B, (k+1)*P*B) of the next replica, IN PLACE (`all_gather_into_tensor` with
+    the input being the rank's own slot of the output) — no staging copies, natural row order;
+  * the collective of step k runs on the process group's stream while the SpMM of step k+1
+    runs on the compute stream, so only the last step's gather is exposed (the all-gather, not
+    the SpMM, is the critical path at 8 GPUs: SURVEY.md §8e);
+  * the L2 normalisation is row-local and fused into the SpMM epilogue, so what travels over
+    xGMI is the finished next iterate.
+
+`backend` does the per-block arithmetic.  HipBackend is the product path (libcleora_hip.so);
+tests inject a CPU backend so the partition / collective logic runs under gloo without a GPU.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+
+class HipBackend:
+    """Per-block SpMM through the C ABI on the current torch stream."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.lib = _hip.lib()
+
+    def make_block(self, rowptr, col, val_left, val_sym, n_cols, hub_threshold=0, hub_segment=0):
+        keep = (rowptr, col, val_left, val_sym)
+        return _hip.Graph.from_device(
+            rowptr.numel() - 1, n_cols, col.numel(), rowptr.data_ptr(), col.data_ptr(),
+            val_left.data_ptr(), val_sym.data_ptr() if val_sym is not None else None,
+            self.device.index or 0, hub_threshold, hub_segment, keepalive=keep)
+
+    def propagate(self, block, kind, x, y, flags, rw=0.0, x_self=None, row_sqdiff=None):
+        d = x.shape[1]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _hip.check(self.lib.cleora_propagate_dev(
+            block.handle, kind, x.data_ptr(), x.stride(0), d, y.data_ptr(), y.stride(0), flags, rw,
+            x_self.data_ptr() if x_self is not None else None,
+            row_sqdiff.data_ptr() if row_sqdiff is not None else None, stream))
+
+
+def block_size(n, world, steps):
+    """Rows per block: the padded row count is block * world * steps (block a multiple of 4 so
+    every block of a 16-byte-aligned matrix stays 16-byte aligned for any d)."""
+    b = -(-n // (world * steps))
+    return max(4, -(-b // 4) * 4)
+
+
+class ShardedGraph:
+    """This rank's row blocks of a CSR graph plus the replica bookkeeping."""
+
+    def __init__(self, n, rowptr, col, val_left, val_sym, rank, world, steps, backend,
+                 hub_threshold=0, hub_segment=0, group=None):
+        self.n, self.rank, self.world, self.steps = n, rank, world, steps
+        self.backend, self.group = backend, group
+        self.block = block_size(n, world, steps)
+        self.n_pad = self.block * world * steps
+        self.blocks = []
+        self.local_nnz = 0
+        rp = rowptr.to(torch.int64)
+        for k in range(steps):
+            r0 = min((k * world + rank) * self.block, n)
+            r1 = min(r0 + self.block, n)
+            e0, e1 = int(rp[r0]), int(rp[r1])
+            brp = torch.full((self.block + 1,), e1 - e0, dtype=torch.int64, device=rp.device)
+            brp[: r1 - r0 + 1] = rp[r0:r1 + 1] - e0     # padded rows are empty
+            blk = backend.make_block(brp, col[e0:e1].clone(), val_left[e0:e1].clone(),
+                                     val_sym[e0:e1].clone() if val_sym is not None else None,
+                                     self.n_pad, hub_threshold, hub_segment)
+            self.blocks.append(blk)
+            self.local_nnz += e1 - e0
+
+    def rows_of_step(self, k):
+        """(first row of this rank's block, first row of the step's gathered range)."""
+        g0 = k * self.world * self.block
+        return g0 + self.rank * self.block, g0
+
+    def propagate(self, kind, x, x_next, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None):
+        """One iteration: x_next <- rowops(A @ x), replicated on every rank.
+        x, x_next: (n_pad, d) f32 replicas.  Returns after the collectives are enqueued and
+        waited on the current stream (no host sync)."""
+        works = []
+        for k in range(self.steps):
+            mine, g0 = self.rows_of_step(k)
+            y = x_next[mine:mine + self.block]
+            xs = x[mine:mine + self.block]
+            sq = row_sqdiff[k * self.block:(k + 1) * self.block] if row_sqdiff is not None else None
+            self.backend.propagate(self.blocks[k], kind, x, y, flags, rw, xs, sq)
+            if self.world > 1:
+                out = x_next[g0:g0 + self.world * self.block]
+                works.append(dist.all_gather_into_tensor(out, y, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+
+    def sqdiff_total(self, row_sqdiff):
+        """Sum of the per-row squared differences over all ranks (f64)."""
+        t = row_sqdiff.sum(dtype=torch.float64).reshape(1)
+        if self.world > 1:
+            dist.all_reduce(t, group=self.group)
+        return float(t)
+
+
+def embed_sharded(sg, kind, x0, iterations, residual_weight=0.0, convergence_threshold=0.0,
+                  flags=_hip.F_L2NORM):
+    """embed_full / embed_full_with_convergence (src/embedding.rs:106-188) over a ShardedGraph.
+    x0: (n_pad, d) replica (rows >= n zero).  Returns (x, iterations_run)."""
+    x = x0
+    x_next = torch.zeros_like(x0)
+    check = convergence_threshold > 0
+    flags = flags | _hip.F_RESIDUAL
+    sq = torch.zeros(sg.steps * sg.block, dtype=torch.float64, device=x0.device) if check else None
+    ran = iterations
+    total = float(sg.n) * x0.shape[1]
+    for it in range(iterations):
+        test = check and it > 0
+        sg.propagate(kind, x, x_next, flags | (_hip.F_SQDIFF if test else 0), residual_weight,
+                     sq if test else None)
+        x, x_next = x_next, x
+        if test:
+            rmse = (sg.sqdiff_total(sq) / total) ** 0.5
+            if rmse < convergence_threshold:
+                ran = it + 1
+                break
+    return x, ran

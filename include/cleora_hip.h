@@ -98,6 +98,14 @@ int cleora_graph_create_dev(int device, uint64_t n_rows, uint64_t n_cols, uint64
 int cleora_graph_destroy(cleora_graph *g);
 int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info);
 
+/* Per-kernel timing for roofline reporting (no reference counterpart).  While enabled, every
+ * cleora_propagate_dev call on this graph brackets its three kernels with HIP events on the
+ * launch stream.  cleora_graph_get_timing waits for the recorded events, returns the summed
+ * durations in milliseconds — ms[0] hub_partial, ms[1] spmm_rows (the dominant kernel),
+ * ms[2] hub_finish — and the number of calls they cover, then resets the record. */
+int cleora_graph_set_timing(cleora_graph *g, int enable);
+int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
+
 /* ---- device-pointer hot path ------------------------------------------------------- */
 
 /* NdArrayMatrix::spmm_kernel / multiply_into (src/embedding.rs:41-86) with the optional

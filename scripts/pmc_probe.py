@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Workload for rocprofv3 passes: on the bench graph run init -> L2 rowops -> 3 x propagate.
+init / rowops move a KNOWN number of bytes with the same 16-byte-per-lane row accesses as the
+SpMM, which calibrates FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md §HBM) before they are
+read for the SpMM kernel."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cleora_amd import _hip, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nodes", type=int, default=10_000_000)
+ap.add_argument("--pairs", type=int, default=95_000_000)
+ap.add_argument("--dim", type=int, default=256)
+ap.add_argument("--iters", type=int, default=3)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+L = _hip.lib()
+g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)
+n, nnz, d = g["n"], g["nnz"], args.dim
+graph = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(),
+                               g["val_left"].data_ptr(), None, 0, 0, 0, keepalive=g)
+hashes = synth.entity_hashes(n, 0, dev)
+x = torch.empty((n, d), dtype=torch.float32, device=dev)
+y = torch.empty_like(x)
+s = torch.cuda.current_stream().cuda_stream
+_hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, s))
+_hip.check(L.cleora_rowops_dev(x.data_ptr(), d, n, d, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, s))
+x, y = y, x
+for _ in range(args.iters):
+    _hip.check(L.cleora_propagate_dev(graph.handle, 0, x.data_ptr(), d, d, y.data_ptr(), d,
+                                      _hip.F_L2NORM, 0.0, None, None, s))
+    x, y = y, x
+torch.cuda.synchronize()
+info = graph.info()
+print(f"PMC_PROBE n={n} nnz={nnz} d={d} hub_rows={info.n_hub_rows} hub_segments={info.n_hub_segments}")

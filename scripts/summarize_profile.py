@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ rocprofv3 capture into the tracked files under profiles/.
+
+  profiles/<tag>_kernel_stats.csv   `rocprofv3 --kernel-trace --stats` summary of `python bench.py`
+                                    (our kernels + the top torch kernels of the graph generator)
+  profiles/<tag>_pmc.json           FETCH_SIZE / WRITE_SIZE per kernel from the two --pmc passes over
+                                    scripts/pmc_probe.py, with the calibration used
+  profiles/hbm_traffic.json         bytes per launch of the dominant kernel (read by bench.py)
+
+Counter handling follows MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in
+separate passes (TCC slots), both are in KiB, and on gfx950 FETCH_SIZE reports half of the
+bytes of a 16-byte-per-lane coalesced read.  The factor is not assumed: the probe runs
+rowops_kernel (reads exactly n*d*4 B with the same dwordx4 row accesses as the SpMM gathers) and
+init_kernel (writes exactly n*d*4 B), and the corrections are the ratios measured on those.
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+# 1. kernel stats
+rows = list(csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.csv"))))
+with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for r in rows[:12]:
+        name = r["Name"] if "cleora" in r["Name"] else r["Name"][:90]
+        w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                    r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+# 2. PMC
+probe = open(os.path.join(src, "fetch.log")).read()
+m = re.search(r"PMC_PROBE n=(\d+) nnz=(\d+) d=(\d+)", probe)
+n, nnz, d = (int(v) for v in m.groups())
+counters = collections.defaultdict(lambda: collections.defaultdict(list))
+for kind in ("fetch", "write"):
+    for r in csv.DictReader(open(os.path.join(src, kind, "pmc_counter_collection.csv"))):
+        if "cleora" in r["Kernel_Name"]:
+            counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+known = n * d * 4
+fetch_corr = known / (counters["rowops_kernel<64, 1, 4>"]["FETCH_SIZE"][0] * 1024)
+write_corr = known / (counters["init_kernel"]["WRITE_SIZE"][0] * 1024)
+out = {"tag": tag, "n": n, "nnz": nnz, "d": d,
+       "calibration": {"known_bytes": known,
+                       "rowops_FETCH_SIZE_KiB": counters["rowops_kernel<64, 1, 4>"]["FETCH_SIZE"][0],
+                       "init_WRITE_SIZE_KiB": counters["init_kernel"]["WRITE_SIZE"][0],
+                       "fetch_correction": fetch_corr, "write_correction": write_corr},
+       "kernels": {}}
+for k, c in counters.items():
+    f = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)
+    w_ = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+    out["kernels"][k] = {"launches": len(c["FETCH_SIZE"]), "FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w_,
+                         "hbm_bytes_per_launch": f * 1024 * fetch_corr + w_ * 1024 * write_corr}
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+dom = [k for k in out["kernels"] if k.startswith("spmm_rows_kernel")][0]
+json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"profiles/{tag}_pmc.json",
+           "bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"]},
+          open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -1,0 +1,62 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/cleora_hip.h declares;
+no compute call is made (there is no GPU here and no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cleora_amd import _hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "cleora_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cleora_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    L = _hip.lib()
+    names = declared_functions()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(L, name), f"libcleora_hip.so does not export {name}"
+    # the ctypes table covers the header one to one
+    assert sorted(_hip.SIGNATURES) == names
+
+
+def test_abi_version_and_error_channel():
+    L = _hip.lib()
+    assert L.cleora_abi_version() == 1
+    # argument validation happens before any device work
+    n = ctypes.c_int(-1)
+    assert L.cleora_device_count(ctypes.byref(n)) == _hip.OK and n.value >= 0
+    assert L.cleora_graph_get_info(None, None) == _hip.E_INVALID
+    assert "NULL" in _hip.last_error()
+
+
+@pytest.mark.skipif(_hip.device_count() > 0, reason="only meaningful without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    """The product path fails loudly when there is no device."""
+    rowptr = np.array([0, 1, 2], np.uint64)
+    col = np.array([1, 0], np.uint32)
+    val = np.array([1.0, 1.0], np.float32)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        _hip.Graph.from_host(rowptr, col, val)
+    x = np.ones((2, 4), np.float32)
+    with pytest.raises(RuntimeError):
+        _hip.check(_hip.lib().cleora_l2_normalize(_hip.ptr(x), 2, 4, _hip.ptr(x.copy())))
+
+
+def test_product_never_imports_oracle():
+    """Nothing under cleora_amd/ may import, load or execute the oracle."""
+    pkg = os.path.join(ROOT, "cleora_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "libcleora_oracle" not in text, f

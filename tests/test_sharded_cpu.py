@@ -1,0 +1,95 @@
+"""CPU-only, world_size 2 over gloo: the row-block-cyclic partition + in-place all-gather of
+cleora_amd/sharded.py reproduce the single-process result bit for bit.  The per-block
+arithmetic is injected (the C oracle) so the distributed logic is what is under test; the HIP
+backend is exercised by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from cleora_amd import _hip, sharded
+from tests.graphs import random_csr
+
+
+class OracleBackend:
+    """Test double for sharded.HipBackend: same interface, oracle arithmetic on CPU tensors."""
+
+    def make_block(self, rowptr, col, val_left, val_sym, n_cols, hub_threshold=0, hub_segment=0):
+        return {"rowptr": rowptr.numpy().astype(np.uint64), "col": col.numpy().view(np.uint32),
+                "val": [val_left.numpy(), val_sym.numpy() if val_sym is not None else None]}
+
+    def propagate(self, block, kind, x, y, flags, rw=0.0, x_self=None, row_sqdiff=None):
+        out = oracle.spmm(block["rowptr"], block["col"], block["val"][kind], x.numpy())
+        if (flags & _hip.F_RESIDUAL) and 0.0 < rw < 1.0:
+            out = (np.float32(1.0) - np.float32(rw)) * out + np.float32(rw) * x_self.numpy()
+        if flags & _hip.F_L2NORM:
+            out = oracle.l2_normalize(out)
+        if flags & _hip.F_SQDIFF:
+            delta = (out - x_self.numpy()).astype(np.float64)
+            row_sqdiff.copy_(torch.from_numpy((delta * delta).sum(axis=1)))
+        y.copy_(torch.from_numpy(out))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, d = 1001, 24  # n deliberately not a multiple of world*steps*4
+        rowptr, col, vl, vs = random_csr(n, 7, seed=3, empty_frac=0.05, hubs=[(5, 300)])
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.kind == "u" else a)
+        sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
+                                  torch.from_numpy(vs), rank, world, steps, OracleBackend())
+        x0 = np.zeros((sg.n_pad, d), np.float32)
+        x0[:n] = np.random.default_rng(9).standard_normal((n, d)).astype(np.float32)
+        res = {}
+        for kind, rw, thr in ((0, 0.0, 0.0), (1, 0.4, 0.0), (0, 0.0, 2e-3)):
+            x, ran = sharded.embed_sharded(sg, kind, torch.from_numpy(x0.copy()), 12, rw, thr)
+            res[(kind, rw, thr)] = (x[:n].numpy().copy(), ran, float(x[n:].abs().max()) if sg.n_pad > n else 0.0)
+        q.put((rank, sg.block, sg.n_pad, sg.local_nnz, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps", [1, 3])
+def test_world2_matches_single_process(steps):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, d = 1001, 24
+    rowptr, col, vl, vs = random_csr(n, 7, seed=3, empty_frac=0.05, hubs=[(5, 300)])
+    x0 = np.random.default_rng(9).standard_normal((n, d)).astype(np.float32)
+    assert sum(g[3] for g in got) == int(rowptr[-1])            # every edge owned exactly once
+    assert got[0][2] == got[1][2] and got[0][2] >= n and got[0][2] % (world * steps * 4) == 0
+    for (kind, rw, thr), val in ((k, (vl, vs)[k[0]]) for k in got[0][4]):
+        want, it = oracle.embed(rowptr, col, val, x0, 12, residual_weight=rw, convergence_threshold=thr)
+        for rank, _, _, _, res in got:
+            x, ran, pad_max = res[(kind, rw, thr)]
+            assert ran == it
+            assert pad_max == 0.0                                   # padded rows stay zero
+            np.testing.assert_array_equal(x, want)                   # replicas identical + exact
+
+
+def test_block_size_alignment():
+    for n, w, s in ((10, 1, 1), (1001, 2, 3), (9_999_997, 8, 4), (5, 8, 4)):
+        b = sharded.block_size(n, w, s)
+        assert b % 4 == 0 and b * w * s >= n and (b - 4) * w * s < n or b == 4

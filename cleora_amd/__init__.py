@@ -6,3 +6,19 @@
   cleora_amd._hip                    ctypes binding of libcleora_hip.so (include/cleora_hip.h)
 """
 __version__ = "0.1.0"
+
+
+def install():
+    """Make this package's SparseMatrix the reference's compiled module: after this call
+    `import pycleora` (the reference's unmodified Python package) binds
+    `from .pycleora import SparseMatrix` (pycleora/__init__.py:4) to cleora_amd.pycleora."""
+    import importlib.util
+    import sys
+
+    from . import pycleora as _mod
+    sys.modules["pycleora.pycleora"] = _mod
+    # pickles name the class by module path; use the reference's (src/sparse_matrix.rs:56) when its
+    # Python package is importable so pickles interchange with real pycleora, else keep ours
+    if "pycleora" in sys.modules or importlib.util.find_spec("pycleora") is not None:
+        _mod.SparseMatrix.__module__ = "pycleora.pycleora"
+    return _mod

@@ -1,0 +1,505 @@
+// cleora_host.cpp — host-side graph construction for the drop-in (include/cleora_host.h).
+// Written from the behaviour of the reference's Rust builder (citations: paths under the
+// reference checkout); data structures and control flow are this project's own: entities are
+// interned to dense indices as lines are scanned, edges accumulate in one open-addressing table
+// keyed by (row << 32 | col), and the CSR comes out of a radix sort of those keys.
+#include "../../include/cleora_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <string_view>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+// ---- XXH64 (public specification; twox-hash is not under the reference tree) -------------------
+constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
+                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+inline uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint64_t rnd(uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; }
+inline uint64_t mrg(uint64_t h, uint64_t v) { return (h ^ rnd(0, v)) * P1 + P4; }
+
+uint64_t xxh64(const uint8_t *p, uint64_t len, uint64_t seed) {
+    const uint8_t *end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const uint8_t *lim = end - 32;
+        do {
+            v1 = rnd(v1, rd64(p)); v2 = rnd(v2, rd64(p + 8)); v3 = rnd(v3, rd64(p + 16)); v4 = rnd(v4, rd64(p + 24));
+            p += 32;
+        } while (p <= lim);
+        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+        h = mrg(mrg(mrg(mrg(h, v1), v2), v3), v4);
+    } else {
+        h = seed + P5;
+    }
+    h += len;
+    for (; p + 8 <= end; p += 8) h = rotl(h ^ rnd(0, rd64(p)), 27) * P1 + P4;
+    if (p + 4 <= end) { h = rotl(h ^ (rd32(p) * P1), 23) * P2 + P3; p += 4; }
+    for (; p < end; ++p) h = rotl(h ^ (*p * P5), 11) * P1;
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// ---- column spec (src/configuration.rs:19-70) and relation (src/sparse_matrix.rs:5-46) -----------
+struct Column { std::string name; bool complex = false, reflexive = false; };
+
+bool ieq(std::string_view a, const char *b) {
+    size_t n = strlen(b);
+    if (a.size() != n) return false;
+    for (size_t i = 0; i < n; ++i) if (tolower((unsigned char)a[i]) != b[i]) return false;
+    return true;
+}
+
+std::vector<std::string_view> split(std::string_view s, std::string_view sep) {
+    std::vector<std::string_view> out;
+    size_t pos = 0;
+    for (;;) {
+        size_t q = s.find(sep, pos);
+        if (q == std::string_view::npos) { out.push_back(s.substr(pos)); break; }
+        out.push_back(s.substr(pos, q - pos));
+        pos = q + sep.size();
+    }
+    return out;
+}
+
+bool parse_fields(const char *spec, std::vector<Column> &cols) {
+    for (auto col : split(spec, " ")) {
+        auto parts = split(col, "::");
+        Column c;
+        if (parts.size() > 1) {
+            c.name = std::string(parts.back());
+            for (size_t i = 0; i + 1 < parts.size(); ++i) {
+                if (ieq(parts[i], "complex")) c.complex = true;
+                else if (ieq(parts[i], "reflexive")) c.reflexive = true;
+                else { g_err = "Unrecognized column field modifier: " + std::string(parts[i]); return false; }
+            }
+        } else {
+            c.name = std::string(col);
+        }
+        cols.push_back(c);
+    }
+    for (auto &c : cols)
+        if (c.reflexive && !c.complex) {
+            g_err = "A field cannot be REFLEXIVE but NOT COMPLEX. It does not make sense: " + c.name;
+            return false;
+        }
+    return true;
+}
+
+struct Descriptor { uint8_t a_id = 0, b_id = 0; std::string a_name, b_name; };
+
+bool relation(const std::vector<Column> &cols, Descriptor &d) {
+    std::vector<Descriptor> all;
+    const size_t nf = cols.size();
+    size_t refl = 0;
+    for (size_t i = 0; i < nf; ++i)
+        for (size_t j = i; j < nf; ++j) {
+            if (i < j) all.push_back({(uint8_t)i, (uint8_t)j, cols[i].name, cols[j].name});
+            else if (cols[i].reflexive) { all.push_back({(uint8_t)i, (uint8_t)(nf + refl), cols[i].name, cols[j].name}); ++refl; }
+        }
+    if (all.size() != 1) {
+        g_err = "More than one relation! Adjust your columns so there is only one relation.";
+        return false;
+    }
+    d = all[0];
+    return true;
+}
+
+// ---- Rust str::trim (Unicode White_Space) on UTF-8 ------------------------------------------------
+bool ws_at(std::string_view s, size_t i, size_t &len) {
+    unsigned char c = s[i];
+    if (c == ' ' || (c >= 9 && c <= 13)) { len = 1; return true; }
+    if (c == 0xC2 && i + 1 < s.size() && ((unsigned char)s[i + 1] == 0x85 || (unsigned char)s[i + 1] == 0xA0)) { len = 2; return true; }
+    if (i + 2 < s.size()) {
+        unsigned char c1 = s[i + 1], c2 = s[i + 2];
+        if (c == 0xE1 && c1 == 0x9A && c2 == 0x80) { len = 3; return true; }                  // U+1680
+        if (c == 0xE2 && c1 == 0x80 && ((c2 >= 0x80 && c2 <= 0x8A) || c2 == 0xA8 || c2 == 0xA9 || c2 == 0xAF)) { len = 3; return true; }
+        if (c == 0xE2 && c1 == 0x81 && c2 == 0x9F) { len = 3; return true; }                  // U+205F
+        if (c == 0xE3 && c1 == 0x80 && c2 == 0x80) { len = 3; return true; }                  // U+3000
+    }
+    return false;
+}
+
+std::string_view trim(std::string_view s) {
+    size_t b = 0, len;
+    while (b < s.size() && ws_at(s, b, len)) b += len;
+    size_t e = s.size();
+    for (;;) {
+        if (e <= b) break;
+        // step back one code point
+        size_t k = e - 1;
+        while (k > b && ((unsigned char)s[k] & 0xC0) == 0x80) --k;
+        if (ws_at(s, k, len) && k + len == e) e = k; else break;
+    }
+    return s.substr(b, e - b);
+}
+
+// ---- open-addressing tables ---------------------------------------------------------------------------
+inline uint64_t mix(uint64_t x) { x ^= x >> 32; x *= 0xD6E8FEB86659FD93ULL; x ^= x >> 32; return x; }
+
+struct Interner {  // entity hash -> dense index, first-seen order (SyncNodeIndexerBuilder, :58-70)
+    std::vector<uint64_t> keys; std::vector<uint32_t> vals; size_t mask = 0, count = 0;
+    Interner() { resize(1 << 12); }
+    void resize(size_t cap) {
+        std::vector<uint64_t> ok = std::move(keys); std::vector<uint32_t> ov = std::move(vals);
+        keys.assign(cap, 0); vals.assign(cap, UINT32_MAX); mask = cap - 1;
+        for (size_t i = 0; i < ok.size(); ++i) if (ov[i] != UINT32_MAX) put(ok[i], ov[i]);
+    }
+    void put(uint64_t k, uint32_t v) { size_t i = mix(k) & mask; while (vals[i] != UINT32_MAX) i = (i + 1) & mask; keys[i] = k; vals[i] = v; }
+    uint32_t find_or_add(uint64_t k, bool &added) {
+        size_t i = mix(k) & mask;
+        while (vals[i] != UINT32_MAX) { if (keys[i] == k) { added = false; return vals[i]; } i = (i + 1) & mask; }
+        added = true;
+        uint32_t v = (uint32_t)count++;
+        keys[i] = k; vals[i] = v;
+        if (count * 2 > mask) resize((mask + 1) * 2);
+        return v;
+    }
+};
+
+struct EdgeTable {  // (row << 32 | col) -> f32 running sum (SparseMatrixBuffer::hashes_2_edge)
+    static constexpr uint64_t EMPTY = ~0ULL;
+    std::vector<uint64_t> keys; std::vector<float> vals; size_t mask = 0, count = 0;
+    EdgeTable() { keys.assign(1 << 14, EMPTY); vals.assign(1 << 14, 0.f); mask = (1 << 14) - 1; }
+    void grow() {
+        std::vector<uint64_t> ok = std::move(keys); std::vector<float> ov = std::move(vals);
+        size_t cap = (mask + 1) * 2;
+        keys.assign(cap, EMPTY); vals.assign(cap, 0.f); mask = cap - 1;
+        for (size_t i = 0; i < ok.size(); ++i) if (ok[i] != EMPTY) { size_t j = mix(ok[i]) & mask; while (keys[j] != EMPTY) j = (j + 1) & mask; keys[j] = ok[i]; vals[j] = ov[i]; }
+    }
+    void add(uint32_t r, uint32_t c, float v) {
+        const uint64_t k = ((uint64_t)r << 32) | c;
+        size_t i = mix(k) & mask;
+        while (keys[i] != EMPTY) { if (keys[i] == k) { vals[i] += v; return; } i = (i + 1) & mask; }
+        keys[i] = k; vals[i] = v;
+        if (++count * 2 > mask) grow();
+    }
+};
+
+}  // namespace
+
+struct cleora_hostgraph {
+    Descriptor desc;
+    std::vector<std::string> ids;
+    std::vector<uint64_t> hashes;
+    std::vector<uint8_t> column_ids;
+    std::vector<float> row_sum;
+    std::vector<uint64_t> rowptr{0};
+    std::vector<uint32_t> col;
+    std::vector<float> val_left, val_sym;
+};
+
+namespace {
+
+struct Builder {
+    std::vector<Column> cols;
+    Descriptor desc;
+    uint32_t trim_n;
+    Interner interner;
+    std::vector<std::string> ids;
+    std::vector<uint64_t> hashes;
+    std::vector<uint8_t> column_ids;
+    std::vector<uint32_t> occurrence;  // Row::occurrence
+    std::vector<float> row_sum;        // Row::row_sum
+    EdgeTable edges;
+    std::vector<uint32_t> nodes, a, b;  // scratch
+
+    uint32_t intern(std::string_view tok, uint8_t column) {
+        const uint64_t h = xxh64(reinterpret_cast<const uint8_t *>(tok.data()), tok.size(), 0);
+        bool added;
+        const uint32_t ix = interner.find_or_add(h, added);
+        if (added) {
+            ids.emplace_back(tok); hashes.push_back(h); column_ids.push_back(column);
+            occurrence.push_back(0); row_sum.push_back(0.f);
+        }
+        return ix;
+    }
+
+    // get_high_low_nodes (sparse_matrix_builder.rs:195-208): keep the trim_n nodes with the highest
+    // occurrence first.  The reference's select_nth_unstable leaves the order of ties to pdqselect;
+    // here ties keep their position in the line (documented divergence).
+    size_t high_first(std::vector<uint32_t> &v) {
+        if (v.size() <= trim_n) return v.size();
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return occurrence[x] > occurrence[y]; });
+        return trim_n;
+    }
+
+    void line(std::string_view raw) {
+        // parse_line (src/pipeline.rs:223-240)
+        std::string_view t = trim(raw);
+        std::vector<std::string_view> columns;
+        bool comma = false;
+        if (t.find('\t') != std::string_view::npos) columns = split(t, "\t");
+        else if (t.find(',') != std::string_view::npos) { columns = split(t, ","); comma = true; }
+        else columns.push_back(t);
+        if (columns.size() != cols.size()) return;  // wrong width: skipped (pipeline.rs:60-79)
+        // process_row_and_get_edges (src/entity.rs:67-106)
+        nodes.clear();
+        uint32_t slice[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        uint32_t offset = 0, refl = 0;
+        for (size_t i = 0; i < columns.size(); ++i) {
+            std::string_view c = comma ? trim(columns[i]) : columns[i];
+            auto toks = split(c, " ");
+            if (cols[i].complex) {
+                for (auto tk : toks) nodes.push_back(intern(tk, (uint8_t)i));
+                const uint32_t len = (uint32_t)toks.size();
+                if (i < 2) { slice[i][0] = offset; slice[i][1] = offset + len; }
+                if (cols[i].reflexive) {
+                    const size_t rid = cols.size() + refl++;
+                    if (rid < 4) { slice[rid][0] = offset; slice[rid][1] = offset + len; }
+                }
+                offset += len;
+            } else {
+                nodes.push_back(intern(toks[0], (uint8_t)i));
+                if (i < 2) { slice[i][0] = offset; slice[i][1] = offset + 1; }
+                offset += 1;
+            }
+        }
+        // handle_hyperedge (src/sparse_matrix_builder.rs:170-193)
+        a.assign(nodes.begin() + slice[desc.a_id][0], nodes.begin() + slice[desc.a_id][1]);
+        b.assign(nodes.begin() + slice[desc.b_id][0], nodes.begin() + slice[desc.b_id][1]);
+        const uint32_t na = (uint32_t)a.size(), nb = (uint32_t)b.size();
+        for (uint32_t x : a) { occurrence[x] += nb; row_sum[x] += 1.0f / (float)nb; }
+        for (uint32_t x : b) { occurrence[x] += na; row_sum[x] += 1.0f / (float)na; }
+        const float value = 1.0f / (float)(na * nb);
+        const size_t ah = high_first(a), bh = high_first(b);
+        auto combos = [&](size_t a0, size_t a1, size_t b0, size_t b1) {
+            for (size_t i = a0; i < a1; ++i)
+                for (size_t j = b0; j < b1; ++j) { edges.add(a[i], b[j], value); edges.add(b[j], a[i], value); }
+        };
+        combos(0, ah, 0, bh);            // high x high
+        combos(0, ah, bh, b.size());     // high x low
+        combos(ah, a.size(), 0, bh);     // low  x high      (low x low is dropped)
+    }
+
+    cleora_hostgraph *finish() {
+        auto *g = new cleora_hostgraph();
+        g->desc = desc;
+        g->ids = std::move(ids);
+        g->hashes = std::move(hashes);
+        g->column_ids = std::move(column_ids);
+        g->row_sum = row_sum;
+        const size_t n = g->ids.size();
+        // reduce (src/sparse_matrix_builder.rs:275-343): sort by (row, col), slices, normalise
+        std::vector<std::pair<uint64_t, float>> ent;
+        ent.reserve(edges.count);
+        for (size_t i = 0; i < edges.keys.size(); ++i)
+            if (edges.keys[i] != EdgeTable::EMPTY) ent.emplace_back(edges.keys[i], edges.vals[i]);
+        std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
+        g->rowptr.assign(n + 1, 0);
+        g->col.resize(ent.size()); g->val_left.resize(ent.size()); g->val_sym.resize(ent.size());
+        for (size_t k = 0; k < ent.size(); ++k) {
+            const uint32_t r = (uint32_t)(ent[k].first >> 32), c = (uint32_t)ent[k].first;
+            g->rowptr[r + 1]++;
+            g->col[k] = c;
+            const float v = ent[k].second, rs = row_sum[r], cs = row_sum[c];
+            g->val_left[k] = v / rs;
+            g->val_sym[k] = v / std::sqrt(rs * cs);
+        }
+        for (size_t r = 0; r < n; ++r) g->rowptr[r + 1] += g->rowptr[r];
+        return g;
+    }
+};
+
+bool make_builder(Builder &b, const char *columns, uint32_t trim_n) {
+    if (!columns) { g_err = "columns is NULL"; return false; }
+    if (!parse_fields(columns, b.cols)) return false;
+    if (!relation(b.cols, b.desc)) return false;
+    b.trim_n = trim_n;
+    return true;
+}
+
+// ---- bincode helpers -------------------------------------------------------------------------------------
+struct Writer {
+    std::vector<uint8_t> buf;
+    template <class T> void put(T v) { const auto *p = reinterpret_cast<const uint8_t *>(&v); buf.insert(buf.end(), p, p + sizeof(T)); }
+    void str(const std::string &s) { put<uint64_t>(s.size()); buf.insert(buf.end(), s.begin(), s.end()); }
+};
+struct Reader {
+    const uint8_t *p, *end; bool ok = true;
+    template <class T> T get() { T v{}; if ((size_t)(end - p) < sizeof(T)) { ok = false; return v; } memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+    std::string str() { uint64_t n = get<uint64_t>(); if (!ok || (uint64_t)(end - p) < n) { ok = false; return {}; } std::string s(reinterpret_cast<const char *>(p), n); p += n; return s; }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char *cleora_host_last_error(void) { return g_err.c_str(); }
+
+uint64_t cleora_xxh64(const void *data, uint64_t len, uint64_t seed) {
+    return xxh64(static_cast<const uint8_t *>(data), len, seed);
+}
+
+int cleora_host_build_from_lines(const char *data, const uint64_t *offsets, uint64_t n_lines,
+                                 const char *columns, uint32_t trim_n, cleora_hostgraph **out) {
+    if (!out || (n_lines && (!data || !offsets))) { g_err = "NULL argument"; return -1; }
+    Builder b;
+    if (!make_builder(b, columns, trim_n)) return -1;
+    for (uint64_t i = 0; i < n_lines; ++i)
+        b.line(std::string_view(data + offsets[i], offsets[i + 1] - offsets[i]));
+    *out = b.finish();
+    return 0;
+}
+
+int cleora_host_build_from_files(const char *const *paths, uint64_t n_paths, const char *columns,
+                                 uint32_t trim_n, cleora_hostgraph **out) {
+    if (!out || !paths) { g_err = "NULL argument"; return -1; }
+    Builder b;
+    if (!make_builder(b, columns, trim_n)) return -1;
+    std::string ln;
+    for (uint64_t i = 0; i < n_paths; ++i) {
+        std::ifstream f(paths[i], std::ios::binary);
+        if (!f) continue;  // read_file logs and skips (src/pipeline.rs:193-199)
+        while (std::getline(f, ln)) {
+            if (!ln.empty() && ln.back() == '\r') ln.pop_back();  // BufRead::lines strips "\r\n"
+            if (!ln.empty()) b.line(ln);
+        }
+    }
+    *out = b.finish();
+    return 0;
+}
+
+void cleora_host_free(cleora_hostgraph *g) { delete g; }
+
+int cleora_host_empty(cleora_hostgraph **out) {
+    if (!out) { g_err = "NULL argument"; return -1; }
+    *out = new cleora_hostgraph();
+    return 0;
+}
+
+int cleora_host_sizes(const cleora_hostgraph *g, uint64_t *n, uint64_t *nnz, uint64_t *ids_bytes) {
+    if (!g) { g_err = "NULL graph"; return -1; }
+    if (n) *n = g->ids.size();
+    if (nnz) *nnz = g->col.size();
+    if (ids_bytes) { uint64_t t = 0; for (auto &s : g->ids) t += s.size(); *ids_bytes = t; }
+    return 0;
+}
+
+int cleora_host_copy(const cleora_hostgraph *g, uint64_t *rowptr, uint32_t *col, float *val_left,
+                     float *val_sym, float *row_sum, uint64_t *hashes, uint8_t *column_ids) {
+    if (!g) { g_err = "NULL graph"; return -1; }
+    auto cp = [](auto *dst, const auto &v) { if (dst && !v.empty()) memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+    cp(rowptr, g->rowptr); cp(col, g->col); cp(val_left, g->val_left); cp(val_sym, g->val_sym);
+    cp(row_sum, g->row_sum); cp(hashes, g->hashes); cp(column_ids, g->column_ids);
+    return 0;
+}
+
+int cleora_host_copy_ids(const cleora_hostgraph *g, char *buf, uint64_t *offsets) {
+    if (!g || !offsets) { g_err = "NULL argument"; return -1; }
+    uint64_t pos = 0;
+    for (size_t i = 0; i < g->ids.size(); ++i) {
+        offsets[i] = pos;
+        if (buf && !g->ids[i].empty()) memcpy(buf + pos, g->ids[i].data(), g->ids[i].size());
+        pos += g->ids[i].size();
+    }
+    offsets[g->ids.size()] = pos;
+    return 0;
+}
+
+int cleora_host_descriptor(const cleora_hostgraph *g, uint8_t *a_id, const char **a_name,
+                           uint8_t *b_id, const char **b_name) {
+    if (!g) { g_err = "NULL graph"; return -1; }
+    if (a_id) *a_id = g->desc.a_id;
+    if (b_id) *b_id = g->desc.b_id;
+    if (a_name) *a_name = g->desc.a_name.c_str();
+    if (b_name) *b_name = g->desc.b_name.c_str();
+    return 0;
+}
+
+int cleora_host_set_ids(cleora_hostgraph *g, const char *buf, const uint64_t *offsets, uint64_t n) {
+    if (!g || (n && !offsets)) { g_err = "NULL argument"; return -1; }
+    g->ids.resize(n);
+    g->hashes.resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        g->ids[i].assign(buf + offsets[i], offsets[i + 1] - offsets[i]);
+        // initialize_deterministically hashes the CURRENT id strings (src/lib.rs:75)
+        g->hashes[i] = xxh64(reinterpret_cast<const uint8_t *>(g->ids[i].data()), g->ids[i].size(), 0);
+    }
+    return 0;
+}
+
+int cleora_host_serialize(const cleora_hostgraph *g, uint8_t **bytes, uint64_t *len) {
+    if (!g || !bytes || !len) { g_err = "NULL argument"; return -1; }
+    Writer w;
+    w.put<uint8_t>(g->desc.a_id); w.str(g->desc.a_name); w.put<uint8_t>(g->desc.b_id); w.str(g->desc.b_name);
+    w.put<uint64_t>(g->ids.size());
+    for (auto &s : g->ids) w.str(s);
+    w.put<uint64_t>(g->row_sum.size());
+    for (float v : g->row_sum) w.put<float>(v);
+    w.put<uint64_t>(g->col.size());
+    for (size_t k = 0; k < g->col.size(); ++k) { w.put<uint32_t>(g->col[k]); w.put<float>(g->val_left[k]); w.put<float>(g->val_sym[k]); }
+    // slices: one (start, end) per row that has edges (src/sparse_matrix_builder.rs:294-304)
+    uint64_t nslices = 0;
+    for (size_t r = 0; r + 1 < g->rowptr.size(); ++r) nslices += g->rowptr[r + 1] > g->rowptr[r];
+    w.put<uint64_t>(nslices);
+    for (size_t r = 0; r + 1 < g->rowptr.size(); ++r)
+        if (g->rowptr[r + 1] > g->rowptr[r]) { w.put<uint64_t>(g->rowptr[r]); w.put<uint64_t>(g->rowptr[r + 1]); }
+    w.put<uint64_t>(g->column_ids.size());
+    for (uint8_t c : g->column_ids) w.put<uint8_t>(c);
+    *len = w.buf.size();
+    *bytes = static_cast<uint8_t *>(malloc(w.buf.size() ? w.buf.size() : 1));
+    if (!*bytes) { g_err = "Serialization failed: out of memory"; return -1; }
+    memcpy(*bytes, w.buf.data(), w.buf.size());
+    return 0;
+}
+
+int cleora_host_deserialize(const uint8_t *bytes, uint64_t len, cleora_hostgraph **out) {
+    if (!bytes || !out) { g_err = "NULL argument"; return -1; }
+    Reader r{bytes, bytes + len};
+    auto g = new cleora_hostgraph();
+    auto fail = [&](const char *what) { delete g; g_err = std::string("Deserialization failed: ") + what; return -1; };
+    g->desc.a_id = r.get<uint8_t>(); g->desc.a_name = r.str(); g->desc.b_id = r.get<uint8_t>(); g->desc.b_name = r.str();
+    uint64_t n = r.get<uint64_t>();
+    if (!r.ok || n > len) return fail("entity_ids");
+    g->ids.resize(n); g->hashes.resize(n);
+    for (uint64_t i = 0; i < n && r.ok; ++i) {
+        g->ids[i] = r.str();
+        g->hashes[i] = xxh64(reinterpret_cast<const uint8_t *>(g->ids[i].data()), g->ids[i].size(), 0);
+    }
+    uint64_t ne = r.get<uint64_t>();
+    if (!r.ok || ne > len) return fail("entities");
+    g->row_sum.resize(ne);
+    for (uint64_t i = 0; i < ne; ++i) g->row_sum[i] = r.get<float>();
+    uint64_t nnz = r.get<uint64_t>();
+    if (!r.ok || nnz > len) return fail("edges");
+    g->col.resize(nnz); g->val_left.resize(nnz); g->val_sym.resize(nnz);
+    for (uint64_t k = 0; k < nnz; ++k) { g->col[k] = r.get<uint32_t>(); g->val_left[k] = r.get<float>(); g->val_sym[k] = r.get<float>(); }
+    uint64_t ns = r.get<uint64_t>();
+    if (!r.ok || ns > len) return fail("slices");
+    // The reference zips slices positionally with rows (src/embedding.rs:59-63): slice i is row i.
+    g->rowptr.assign(n + 1, 0);
+    uint64_t prev_end = 0;
+    for (uint64_t i = 0; i < ns; ++i) {
+        uint64_t s = r.get<uint64_t>(), e = r.get<uint64_t>();
+        if (!r.ok || s != prev_end || e < s || e > nnz || i >= n) return fail("slices are not a partition of the edges");
+        g->rowptr[i + 1] = e;
+        prev_end = e;
+    }
+    for (uint64_t i = ns; i < n; ++i) g->rowptr[i + 1] = prev_end;
+    if (prev_end != nnz) return fail("slices do not cover the edges");
+    uint64_t nc = r.get<uint64_t>();
+    if (!r.ok || nc > len) return fail("column_ids");
+    g->column_ids.resize(nc);
+    for (uint64_t i = 0; i < nc; ++i) g->column_ids[i] = r.get<uint8_t>();
+    if (!r.ok) return fail("truncated input");
+    if (r.p != r.end) return fail("trailing bytes");
+    for (uint32_t c : g->col) if (c >= n) return fail("edge column out of range");
+    *out = g;
+    return 0;
+}
+
+void cleora_host_free_bytes(uint8_t *bytes) { free(bytes); }
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Device-resident version of the reference's `embed()` loop and `whiten_embeddings`
+(pycleora/__init__.py:51-164, 942-976): the iterate stays in HBM for all iterations; only the
+d-vector of column sums and the d x d Gram matrix cross PCIe per whitening (for the host
+LAPACK `eigh`, exactly the routine the reference itself calls, :145), plus the final result.
+
+Per iteration (reference order, :109-125):
+    propagate (SpMM)  -> residual blend -> L2 normalise      one fused kernel   (cleora_propagate_dev)
+    whiten: column sums (f64) -> centred Gram (f64 MFMA) -> eigh (host) -> project (f32 MFMA)
+    callback(i, X) if given (forces a device->host copy) ; RMSE early stop (f64 on device)
+
+The reference's own `pycleora.embed()` also runs unmodified over cleora_amd.pycleora.SparseMatrix
+(cleora_amd.install()); it then crosses PCIe twice per iteration and whitens in numpy.  This
+module is the fast path for the same arithmetic.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+from .pycleora import SparseMatrix
+
+DEFAULT_FEATURE_DIM = 256       # pycleora/__init__.py:12
+DEFAULT_NUM_ITERATIONS = 40     # pycleora/__init__.py:13
+
+
+class DeviceWhitener:
+    """whiten_embeddings on device buffers.  Workspaces are sized once per (n, d)."""
+
+    def __init__(self, n, d):
+        L = _hip.lib()
+        self.n, self.d, self.L = n, d, L
+        self.colsum_ws = _hip.DevArray((L.cleora_colsum_workspace(n, d),), np.float64)
+        self.colsum = _hip.DevArray((d,), np.float64)
+        self.mean64 = _hip.DevArray((d,), np.float64)
+        self.mean32 = _hip.DevArray((d,), np.float32)
+        self.gram_ws = _hip.DevArray((L.cleora_gram_workspace(n, d),), np.float64)
+        self.gram = _hip.DevArray((d, d), np.float64)
+        self.transform = None
+        self.last_eigenvalues = None
+
+    def stats(self, x_ptr, ldx, stream=None):
+        """(mean f64[d], cov f64[d,d]) as pycleora/__init__.py:136-143."""
+        L, n, d = self.L, self.n, self.d
+        _hip.check(L.cleora_colsum_dev(x_ptr, ldx, n, d, self.colsum_ws.ptr, self.colsum.ptr, stream))
+        _hip.check(L.cleora_stream_sync(stream))
+        mean = self.colsum.to_host() / float(n)
+        _hip.check(L.cleora_memcpy_h2d(self.mean64.ptr, _hip.ptr(mean), mean.nbytes, stream))
+        _hip.check(L.cleora_centered_gram_dev(x_ptr, ldx, n, d, self.mean64.ptr, self.gram_ws.ptr,
+                                              self.gram.ptr, stream))
+        _hip.check(L.cleora_stream_sync(stream))
+        cov = self.gram.to_host()
+        cov *= 1.0 / (n - 1)
+        return mean, cov
+
+    def whiten(self, x_ptr, ldx, out_ptr, ldo, n_components=None, stream=None):
+        """out = whiten_embeddings(x).  Returns k (columns written)."""
+        L, n, d = self.L, self.n, self.d
+        mean, cov = self.stats(x_ptr, ldx, stream)
+        w, v = np.linalg.eigh(cov)                       # :145 — same LAPACK routine as the reference
+        idx = np.argsort(w)[::-1]                        # :147-149
+        w, v = w[idx], v[:, idx]
+        if n_components is not None:                     # :151-153
+            w, v = w[:n_components], v[:, :n_components]
+        scale = 1.0 / np.sqrt(np.maximum(w, 1e-10))      # :155
+        transform = np.ascontiguousarray((v * scale).astype(np.float32))
+        mean32 = mean.astype(np.float32)
+        k = transform.shape[1]
+        if self.transform is None or self.transform.shape != transform.shape:
+            self.transform = _hip.DevArray(transform.shape, np.float32)
+        _hip.check(L.cleora_memcpy_h2d(self.transform.ptr, _hip.ptr(transform), transform.nbytes, stream))
+        _hip.check(L.cleora_memcpy_h2d(self.mean32.ptr, _hip.ptr(mean32), mean32.nbytes, stream))
+        _hip.check(L.cleora_project_dev(x_ptr, ldx, n, d, self.mean32.ptr, self.transform.ptr, k,
+                                        out_ptr, ldo, stream))
+        self.last_eigenvalues = w
+        return k
+
+
+def whiten_embeddings(embeddings, n_components=None):
+    """Drop-in for pycleora.whiten_embeddings on host arrays (one upload, one download)."""
+    x = np.ascontiguousarray(embeddings, dtype=np.float32)
+    n, d = x.shape
+    if n <= 1:
+        return x.copy()                                   # :132-133
+    dx = _hip.DevArray.from_host(x)
+    k = d if n_components is None else min(int(n_components), d)
+    out = _hip.DevArray((n, k), np.float32)
+    DeviceWhitener(n, d).whiten(dx.ptr, d, out.ptr, k, n_components)
+    _hip.check(_hip.lib().cleora_stream_sync(None))
+    return out.to_host()
+
+
+def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITERATIONS,
+          propagation="left", normalization="l2", seed=0, initial_embeddings=None, num_workers=None,
+          callback=None, residual_weight=0.0, convergence_threshold=0.0, whiten=True):
+    """Same signature and semantics as pycleora.embed (pycleora/__init__.py:51-127)."""
+    if isinstance(num_iterations, str):
+        if num_iterations == "auto":
+            num_iterations = DEFAULT_NUM_ITERATIONS
+        else:
+            raise ValueError(f"num_iterations must be an int or 'auto', got '{num_iterations}'")
+    if propagation not in ("left", "symmetric"):
+        raise ValueError(f"Unknown propagation type: '{propagation}'. Use 'left' or 'symmetric'.")
+    if normalization not in ("l2", "none"):
+        raise ValueError(f"cleora_amd.embed runs normalization 'l2' or 'none' on the device; got "
+                         f"'{normalization}' (use the reference's pycleora.embed for 'l1'/'spectral')")
+    if not isinstance(graph, SparseMatrix):
+        raise TypeError("graph must be a cleora_amd.pycleora.SparseMatrix")
+    kind = _hip.LEFT if propagation == "left" else _hip.SYMMETRIC
+    L = _hip.lib()
+    n = graph.num_entities
+
+    fast = initial_embeddings is None and callback is None and normalization == "l2" and not whiten
+    if fast:                                              # :70-96 — the all-native loop
+        if convergence_threshold > 0:
+            return graph.embed_fast_convergence(feature_dim, num_iterations, propagation=propagation,
+                                                seed=seed, residual_weight=residual_weight,
+                                                convergence_threshold=convergence_threshold)[0]
+        return graph.embed_fast(feature_dim, num_iterations, propagation=propagation, seed=seed,
+                                residual_weight=residual_weight)
+
+    if initial_embeddings is not None:                    # :100-105
+        x0 = np.ascontiguousarray(np.asarray(initial_embeddings).astype(np.float32))
+        if x0.shape[0] != n:
+            raise ValueError(f"initial_embeddings has {x0.shape[0]} rows but graph has {n} entities")
+    else:
+        x0 = graph.initialize_deterministically(feature_dim, seed)
+    d = x0.shape[1]
+    if n == 0 or d == 0 or num_iterations <= 0:
+        return x0
+
+    with graph._lock:
+        g = graph._graph()
+        cur = _hip.DevArray.from_host(x0)
+        nxt = _hip.DevArray((n, d), np.float32)
+        wht = _hip.DevArray((n, d), np.float32) if whiten else None
+        whitener = DeviceWhitener(n, d) if (whiten and n > 1) else None
+        check = convergence_threshold > 0
+        sq = _hip.DevArray((n,), np.float64) if check else None
+        ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None
+        tot = _hip.DevArray((1,), np.float64) if check else None
+        flags = (_hip.F_L2NORM if normalization == "l2" else 0)
+        # the reference's slow path blends for any rw > 0 (:114); the kernel gates on 0 < rw < 1
+        # like the Rust loop (src/embedding.rs:116).  rw >= 1 is rejected rather than guessed.
+        if residual_weight >= 1.0:
+            raise ValueError("residual_weight must be < 1 on the device path")
+        if residual_weight > 0:
+            flags |= _hip.F_RESIDUAL
+        for i in range(int(num_iterations)):
+            _hip.check(L.cleora_propagate_dev(g.handle, kind, cur.ptr, d, d, nxt.ptr, d, flags,
+                                              float(residual_weight), cur.ptr, None, None))
+            result = nxt
+            if whitener is not None:
+                whitener.whiten(nxt.ptr, d, wht.ptr, d)
+                result = wht
+            if callback is not None:
+                _hip.check(L.cleora_stream_sync(None))
+                callback(i, result.to_host())
+            stop = False
+            if check and i > 0:                           # :122-125, f64 RMSE vs the previous iterate
+                _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF, 0.0,
+                                               cur.ptr, sq.ptr, None))
+                _hip.check(L.cleora_reduce_sum_f64_dev(sq.ptr, n, ws.ptr, tot.ptr, None))
+                _hip.check(L.cleora_stream_sync(None))
+                rmse = float(np.sqrt(tot.to_host()[0] / (float(n) * d)))
+                stop = rmse < convergence_threshold
+            # rotate buffers: `result` becomes the current iterate
+            if result is wht:
+                cur, wht = wht, cur
+            else:
+                cur, nxt = nxt, cur
+            if stop:
+                break
+        _hip.check(L.cleora_stream_sync(None))
+        return cur.to_host()

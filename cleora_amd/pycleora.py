@@ -1,0 +1,270 @@
+"""Drop-in for the reference's compiled module `pycleora.pycleora` (PyO3 class SparseMatrix,
+src/lib.rs:84-476 + src/sparse_matrix.rs:56-66): same class name, methods, signatures, defaults,
+return types and exceptions.  Graph construction runs in libcleora_host.so (C++), every
+propagate / normalise / init / embed call runs on the MI355X through libcleora_hip.so.
+
+    import cleora_amd; cleora_amd.install()      # sys.modules["pycleora.pycleora"] = this module
+    import pycleora                               # the reference's Python package, unmodified
+
+Differences from the reference, all deliberate:
+  * from_iterator / from_files always produce the single-consumer result; `num_workers` is
+    accepted and ignored (the reference's multi-worker f32 sums are order-nondeterministic).
+  * non-contiguous / non-C-ordered float32 inputs are copied instead of panicking
+    (src/embedding.rs:78 `as_slice().unwrap()`).
+  * rows split across wavefronts (more than 1024 edges) are summed in a different order than
+    the reference's sequential loop; every other row is bit-identical.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from . import _hip, _host
+
+_PROPAGATIONS = {"left": _hip.LEFT, "symmetric": _hip.SYMMETRIC}
+
+
+def _device_index():
+    return int(os.environ.get("CLEORA_DEVICE", "0"))
+
+
+def _as_f32_matrix(x, name="x"):
+    if not isinstance(x, np.ndarray):
+        raise TypeError(f"argument '{name}': expected a 2-D numpy.ndarray of float32")
+    if x.dtype != np.float32 or x.ndim != 2:
+        raise TypeError(f"argument '{name}': expected a 2-D numpy.ndarray of float32, "
+                        f"got dtype={x.dtype}, ndim={x.ndim}")
+    return np.ascontiguousarray(x)
+
+
+class SparseMatrix:
+    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_lock", "_bufs", "__weakref__")
+
+    # ---- construction -------------------------------------------------------------------------
+    def __new__(cls, *args):
+        if len(args) != 0:
+            raise ValueError("SparseMatrix cannot be constructed directly. Use "
+                             "SparseMatrix.from_files() or SparseMatrix.from_iterator().")
+        self = object.__new__(cls)
+        self._adopt(_host.HostGraph.empty())
+        return self
+
+    def _adopt(self, host):
+        self._host = host
+        self._arr = host.arrays()
+        self._ids = None
+        self._dev_graph = None
+        self._lock = threading.Lock()
+        self._bufs = {}
+
+    @classmethod
+    def _wrap(cls, host):
+        self = object.__new__(cls)
+        self._adopt(host)
+        return self
+
+    @staticmethod
+    def from_iterator(hyperedges, columns, hyperedge_trim_n=16, num_workers=None):
+        lines = []
+        it = iter(hyperedges)
+        while True:
+            try:
+                line = next(it)
+            except StopIteration:
+                break
+            except Exception as e:  # src/lib.rs:113-115
+                raise ValueError(f"Error reading iterator element: {e}")
+            if not isinstance(line, str):
+                raise ValueError("Iterator elements must be strings")
+            try:
+                line.encode("utf-8")
+            except UnicodeEncodeError:
+                raise ValueError("Iterator elements must be valid UTF-8")
+            lines.append(line)
+        return SparseMatrix._wrap(_host.HostGraph.from_lines(lines, columns, int(hyperedge_trim_n)))
+
+    @staticmethod
+    def from_files(filepaths, columns, hyperedge_trim_n=16, num_workers=None):
+        filepaths = list(filepaths)
+        if not filepaths:
+            raise ValueError("At least one file path is required")
+        for fp in filepaths:
+            if not (fp.endswith(".tsv") or fp.endswith(".csv") or fp.endswith(".txt")):
+                raise ValueError(f"Unsupported file format: {fp}. Supported: .tsv, .csv, .txt")
+        return SparseMatrix._wrap(_host.HostGraph.from_files(filepaths, columns, int(hyperedge_trim_n)))
+
+    # ---- device plumbing ----------------------------------------------------------------------
+    def _graph(self):
+        if self._dev_graph is None:
+            a = self._arr
+            self._dev_graph = _hip.Graph.from_host(a["rowptr"], a["col"], a["val_left"], a["val_sym"],
+                                                   device=_device_index())
+        return self._dev_graph
+
+    def _buf(self, key, shape, dtype=np.float32):
+        b = self._bufs.get(key)
+        if b is None or b.shape != tuple(shape) or b.dtype != np.dtype(dtype):
+            if b is not None:
+                b.free()
+            b = _hip.DevArray(shape, dtype)
+            self._bufs[key] = b
+        return b
+
+    def _upload(self, key, a):
+        b = self._buf(key, a.shape, a.dtype)
+        if b.nbytes:
+            _hip.check(_hip.lib().cleora_memcpy_h2d(b.ptr, _hip.ptr(a), b.nbytes, None))
+        return b
+
+    # ---- propagation (src/lib.rs:29-47, 86-102) --------------------------------------------------
+    def _markov_propagate(self, x, kind):
+        x = _as_f32_matrix(x)
+        n = self.num_entities
+        if x.shape[0] != n:
+            raise ValueError(f"Embedding matrix has {x.shape[0]} rows but graph has {n} entities")
+        d = x.shape[1]
+        if n == 0 or d == 0:
+            return np.zeros((n, d), np.float32)
+        with self._lock:
+            g = self._graph()
+            dx = self._upload("x", x)
+            dy = self._buf("y", (n, d))
+            _hip.check(_hip.lib().cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, 0, 0.0,
+                                                       None, None, None))
+            return dy.to_host()
+
+    def left_markov_propagate(self, x, num_workers=None):
+        return self._markov_propagate(x, _hip.LEFT)
+
+    def symmetric_markov_propagate(self, x, num_workers=None):
+        return self._markov_propagate(x, _hip.SYMMETRIC)
+
+    # ---- fused loops (src/lib.rs:320-412) ------------------------------------------------------------
+    def _embed(self, feature_dim, iterations, propagation, seed, residual_weight, threshold):
+        if propagation not in _PROPAGATIONS:
+            raise ValueError(f"Unknown propagation '{propagation}'. Use 'left' or 'symmetric'.")
+        n, d = self.num_entities, int(feature_dim)
+        out = np.zeros((n, d), np.float32)
+        if n == 0 or d == 0:
+            return out, int(iterations)
+        ran = ctypes.c_uint64(0)
+        with self._lock:
+            g = self._graph()
+            _hip.check(_hip.lib().cleora_embed(
+                g.handle, _hip.ptr(self._arr["hashes"]), None, _PROPAGATIONS[propagation], d,
+                int(iterations), int(seed), float(residual_weight), float(threshold), 0,
+                _hip.ptr(out), ctypes.byref(ran)))
+        return out, int(ran.value)
+
+    def embed_fast(self, feature_dim, num_iterations, propagation="left", seed=0,
+                   residual_weight=0.0, num_workers=None):
+        return self._embed(feature_dim, num_iterations, propagation, seed, residual_weight, 0.0)[0]
+
+    def embed_fast_convergence(self, feature_dim, max_iterations, propagation="left", seed=0,
+                               residual_weight=0.0, convergence_threshold=0.0, num_workers=None):
+        return self._embed(feature_dim, max_iterations, propagation, seed, residual_weight,
+                           convergence_threshold)
+
+    def l2_normalize(self, x, num_workers=None):
+        x = _as_f32_matrix(x)
+        out = np.empty_like(x)
+        if x.size:
+            _hip.check(_hip.lib().cleora_l2_normalize(_hip.ptr(x), x.shape[0], x.shape[1], _hip.ptr(out)))
+        return out
+
+    def initialize_deterministically(self, feature_dim, seed=0):
+        n, d = self.num_entities, int(feature_dim)
+        out = np.zeros((n, d), np.float32)
+        if n and d:
+            _hip.check(_hip.lib().cleora_init(_hip.ptr(self._arr["hashes"]), n, d, int(seed), _hip.ptr(out)))
+        return out
+
+    # ---- structure queries: host data, no kernel (src/lib.rs:175-318) -----------------------------------
+    def to_sparse_csr(self, markov_type=None):
+        mt = "left" if markov_type is None else markov_type
+        if mt not in ("left", "symmetric"):
+            raise ValueError(f"Unknown markov_type '{mt}'. Use 'left' or 'symmetric'.")
+        a = self._arr
+        n = self.num_entities
+        rows = np.repeat(np.arange(n, dtype=np.uint32), np.diff(a["rowptr"].astype(np.int64)))
+        vals = a["val_sym"] if mt == "symmetric" else a["val_left"]
+        return rows, a["col"].copy(), vals.copy(), n, n
+
+    def get_entity_column_mask(self, column_name):
+        a_id, a_name, b_id, b_name = self._host.descriptor()
+        by_name = {a_name: a_id, b_name: b_id}  # HashMap::from: the later pair wins on equal names
+        if column_name not in by_name:
+            raise ValueError(f"Column name '{column_name}' not found. Available: '{a_name}', '{b_name}'")
+        return self._arr["column_ids"] == by_name[column_name]
+
+    @property
+    def entity_ids(self):
+        if self._ids is None:
+            self._ids = self._host.entity_ids()
+        return list(self._ids)
+
+    @entity_ids.setter
+    def entity_ids(self, ids):
+        ids = [str(s) for s in ids]
+        self._host.set_entity_ids(ids)
+        self._ids = ids
+        self._arr["hashes"] = self._host.arrays()["hashes"]
+
+    @property
+    def entity_degrees(self):
+        return self._arr["row_sum"].copy()
+
+    @property
+    def num_entities(self):
+        return len(self._ids) if self._ids is not None else self._host.sizes()[0]
+
+    @property
+    def num_edges(self):
+        return int(self._arr["col"].shape[0])
+
+    def get_entity_index(self, entity_id):
+        try:
+            return self.entity_ids.index(entity_id)
+        except ValueError:
+            raise ValueError(f"Entity '{entity_id}' not found")
+
+    def get_entity_indices(self, entity_ids):
+        index = {e: i for i, e in enumerate(self.entity_ids)}
+        out = []
+        for e in entity_ids:
+            if e not in index:
+                raise ValueError(f"Entity '{e}' not found")
+            out.append(index[e])
+        return out
+
+    def get_neighbors(self, entity_id):
+        i = self.get_entity_index(entity_id)
+        a = self._arr
+        b, e = int(a["rowptr"][i]), int(a["rowptr"][i + 1])
+        ids = self.entity_ids
+        return [(ids[int(c)], float(v)) for c, v in zip(a["col"][b:e], a["val_left"][b:e])]
+
+    # ---- dunder (src/lib.rs:426-475) --------------------------------------------------------------------
+    def __repr__(self):
+        _, a_name, _, b_name = self._host.descriptor()
+        return (f"SparseMatrix(entities={self.num_entities}, edges={self.num_edges}, "
+                f"columns=('{a_name}', '{b_name}'))")
+
+    def __len__(self):
+        return self.num_entities
+
+    def __getstate__(self):
+        return self._host.serialize()
+
+    def __setstate__(self, state):
+        if not isinstance(state, (bytes, bytearray)):
+            raise TypeError("state must be bytes")
+        self._adopt(_host.HostGraph.deserialize(bytes(state)))
+
+    def __reduce__(self):
+        return (_reconstruct, (type(self),), self.__getstate__())
+
+
+def _reconstruct(cls):
+    return cls.__new__(cls)

@@ -1,0 +1,102 @@
+"""GPU: the drop-in SparseMatrix and the device-resident embed() against the reference's outputs
+for BASELINE config 1 (karate club; tests/golden/karate_ref.npz was produced by the reference's
+own `pycleora.embed()` running over an oracle-backed stub, see tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from cleora_amd import embed as dev_embed
+from cleora_amd.pycleora import SparseMatrix
+from oracle import whiten as ow
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def karate(golden_dir):
+    k = np.load(os.path.join(golden_dir, "karate_ref.npz"))
+    g = SparseMatrix.from_iterator(iter(str(s) for s in k["edges"]), str(k["columns"]))
+    return k, g
+
+
+def cosine_matrix(e):
+    e = e.astype(np.float64)
+    e = e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-300)
+    return e @ e.T
+
+
+def test_propagate_init_normalize(karate):
+    k, g = karate
+    for d in (16, 128, 5):
+        x0 = g.initialize_deterministically(d, 7)
+        np.testing.assert_array_equal(x0, oracle.init(k["entity_hashes"], d, 7))
+        y = g.left_markov_propagate(x0)
+        np.testing.assert_array_equal(y, oracle.spmm(k["rowptr"], k["col"], k["val_left"], x0))
+        ys = g.symmetric_markov_propagate(np.asfortranarray(x0))          # non-C-order input is copied
+        np.testing.assert_array_equal(ys, oracle.spmm(k["rowptr"], k["col"], k["val_sym"], x0))
+        np.testing.assert_array_equal(g.l2_normalize(y), oracle.l2_normalize(y))
+    with pytest.raises(TypeError):
+        g.left_markov_propagate(np.zeros((34, 4), np.float64))
+
+
+@pytest.mark.parametrize("d", [16, 128])
+def test_embed_fast_matches_reference_fast_path(karate, d):
+    k, g = karate
+    # bit-exact: no karate row is long enough to be split
+    np.testing.assert_array_equal(g.embed_fast(d, 40), k[f"embed_fast_d{d}"])
+    np.testing.assert_array_equal(dev_embed.embed(g, d, 40, whiten=False), k[f"embed_fast_d{d}"])
+    emb, it = g.embed_fast_convergence(d, 40, convergence_threshold=0.0)
+    assert it == 40
+    np.testing.assert_array_equal(emb, k[f"embed_fast_d{d}"])
+    with pytest.raises(ValueError, match="Unknown propagation 'up'"):
+        g.embed_fast(d, 2, propagation="up")
+
+
+def test_embed_slow_path_no_whiten(karate):
+    k, g = karate
+    seen = []
+    got = dev_embed.embed(g, 16, 8, propagation="symmetric", whiten=False, callback=lambda i, e: seen.append(i))
+    assert seen == list(range(8))
+    # the reference's slow path normalises with numpy (divide, pairwise sum), ours with the Rust
+    # order (reciprocal multiply, sequential sum): last-ulp differences, not bit equality
+    np.testing.assert_allclose(got, k["embed_sym_d16"], rtol=0, atol=3e-6)
+
+
+def test_embed_default_whiten_d16(karate):
+    """CLI default path (whiten=True), d = 16 < rank 33: element-wise stable up to column sign."""
+    k, g = karate
+    got = dev_embed.embed(g, 16, 40)
+    want = k["embed_whiten_d16"]
+    s = np.sign((got * want).sum(axis=0))
+    assert np.abs(got * s - want).max() <= 5e-3 * np.abs(want).max()
+    assert np.abs(cosine_matrix(got) - cosine_matrix(want)).max() < 1e-4
+    res = dev_embed.embed(g, 16, 10, residual_weight=0.3)
+    want = k["embed_resid_d16"]
+    assert np.abs(cosine_matrix(res) - cosine_matrix(want)).max() < 1e-4
+
+
+def test_embed_default_whiten_d128_rank_deficient(karate):
+    """d = 128 > rank: ~95 eigenvalues are clamped to 1e-10, so coordinates are meaningless but
+    the pairwise-cosine matrix (what every downstream consumer uses) is stable."""
+    k, g = karate
+    got = dev_embed.embed(g, 128, 40)
+    want = k["embed_whiten_d128"]
+    assert np.isfinite(got).all()
+    assert np.abs(cosine_matrix(got) - cosine_matrix(want)).max() < 5e-3
+
+
+def test_embed_with_initial_embeddings_and_convergence(karate):
+    k, g = karate
+    x0 = oracle.init(k["entity_hashes"], 12, 1)
+    prop = lambda x: oracle.spmm(k["rowptr"], k["col"], k["val_left"], x)
+    want, ran = ow.embed_slow(prop, x0, 40, convergence_threshold=5e-3, whiten=False)
+    assert ran < 40
+    calls = []
+    got = dev_embed.embed(g, 12, 40, initial_embeddings=x0, whiten=False, convergence_threshold=5e-3,
+                          callback=lambda i, e: calls.append(i))
+    assert len(calls) == ran
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+    with pytest.raises(ValueError, match="initial_embeddings has 3 rows"):
+        dev_embed.embed(g, 12, 2, initial_embeddings=np.zeros((3, 12), np.float32))

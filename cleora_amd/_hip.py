@@ -68,6 +68,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the GPU ("no ROCm-capable device is detected" in
+    whichever initialises second), so when torch is installed its copy is loaded first and
+    libcleora_hip.so's NEEDED libamdhip64.so.7 then resolves to that already-loaded object —
+    whatever the import order.  Without torch the system runtime under /opt/rocm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads libcleora_hip.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -76,6 +97,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(cleora_amd/csrc/build.sh).  cleora_amd has no CPU fallback.")
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

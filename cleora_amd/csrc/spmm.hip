@@ -15,9 +15,10 @@
 //   * edges are consumed in stored order with separate f32 multiply and add
 //     (-ffp-contract=off + __fmul_rn/__fadd_rn), so every row that is not split is
 //     bit-identical to the reference's sequential accumulate (src/embedding.rs:80-82).
-//   * rows longer than hub_threshold are split into hub_segment-edge segments computed by
-//     separate wavefronts (hub_partial_kernel) and combined in segment order
-//     (hub_finish_kernel): deterministic, but not the reference's summation order.
+//   * rows longer than hub_threshold are split into hub_segment-edge segments that are the
+//     FIRST work items of the same launch (longest work first), each on its own wavefront,
+//     and are combined in a fixed order by hub_finish_kernel: deterministic, but not the
+//     reference's summation order.
 //   * the epilogue (residual blend, L2 normalise, squared difference) runs on the
 //     accumulator registers, so Y is written exactly once and never re-read.
 #include "common.h"
@@ -44,7 +45,8 @@ struct SpmmArgs {
     const float *val;
     const float *x;
     uint64_t ldx;
-    uint64_t n_items;
+    uint64_t n_items;      // hub segments + rows
+    uint64_t n_segments;
     uint32_t hub_threshold;
     // hub kernels
     const uint32_t *seg_row;
@@ -240,81 +242,105 @@ __device__ __forceinline__ void zero(float (&acc)[V][W]) {
         for (int q = 0; q < W; ++q) acc[v][q] = 0.f;
 }
 
-// ---- main kernel: one group per row, rows <= hub_threshold edges ------------------------
+// ---- main kernel ---------------------------------------------------------------------------
+// Work items: first the hub SEGMENTS (so the longest work starts first), then one item per row.
+// A segment item writes its partial sum to scratch; a row item runs the epilogue and writes Y.
 template <int G, int V, int W, bool FULL>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
     const int gbase = lane & ~(G - 1);
-    uint64_t row = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
-    bool active = row < a.n_items;
-    uint64_t beg = 0, end = 0;
+    uint64_t item = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    bool active = item < a.n_items;
+    if constexpr (G == 64) {
+        if (!active) return;
+        item = uniform_u64(item);
+    }
+    const bool is_seg = item < a.n_segments;
+    uint64_t row = 0, beg = 0, end = 0;
     if (active) {
-        beg = a.rowptr[row];
-        end = a.rowptr[row + 1];
+        if (is_seg) {
+            row = a.seg_row[item];
+            beg = a.seg_begin[item];
+            const uint64_t rend = a.rowptr[row + 1];
+            end = beg + a.hub_segment < rend ? beg + a.hub_segment : rend;
+        } else {
+            row = item - a.n_segments;
+            beg = a.rowptr[row];
+            end = a.rowptr[row + 1];
+            if (end - beg > a.hub_threshold) active = false;  // hub row: its segments own it
+        }
     }
     if constexpr (G == 64) {
+        if (!active) return;
         row = uniform_u64(row);
         beg = uniform_u64(beg);
         end = uniform_u64(end);
-    }
-    if (end - beg > a.hub_threshold) active = false;  // hub row: hub_* kernels own it
-    if (!active) {
-        if constexpr (G == 64) return;
+    } else if (!active) {
         beg = end = 0;
     }
     float acc[V][W];
     zero<G, V, W>(acc);
     accumulate<G, V, W, FULL>(a, beg, end, gl, gbase, acc);
-    if (active) finish_row<G, V, W, FULL>(a.r, row, gl, gbase, acc);
-}
-
-// ---- hub rows: partial sums per segment, then an in-order combine + epilogue --------------
-template <int G, int V, int W>
-__global__ __launch_bounds__(256) void hub_partial_kernel(const SpmmArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int gl = lane & (G - 1);
-    const int gbase = lane & ~(G - 1);
-    uint64_t seg = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
-    const bool active = seg < a.n_items;
-    uint64_t beg = 0, end = 0;
     if (active) {
-        const uint32_t row = a.seg_row[seg];
-        beg = a.seg_begin[seg];
-        const uint64_t rend = a.rowptr[row + 1];
-        end = beg + a.hub_segment < rend ? beg + a.hub_segment : rend;
+        if (is_seg) store_row<G, V, W, FULL>(a.partial + item * (uint64_t)a.r.d, gl, a.r.d, acc);
+        else finish_row<G, V, W, FULL>(a.r, row, gl, gbase, acc);
     }
-    if constexpr (G == 64) {
-        if (!active) return;
-        seg = uniform_u64(seg);
-        beg = uniform_u64(beg);
-        end = uniform_u64(end);
-    }
-    float acc[V][W];
-    zero<G, V, W>(acc);
-    accumulate<G, V, W, false>(a, beg, end, gl, gbase, acc);
-    if (active) store_row<G, V, W, false>(a.partial + seg * (uint64_t)a.r.d, gl, a.r.d, acc);
 }
 
+// ---- hub rows: in-order combine of the segment partials + epilogue -----------------------------
+// One 256-thread block per hub row.  The row's segments are cut into 256/G contiguous runs, one
+// per lane group; each group adds its run in order with 8 loads in flight, the groups' sums are
+// then added in group order through LDS.  Fixed order => deterministic.
 template <int G, int V, int W>
 __global__ __launch_bounds__(256) void hub_finish_kernel(const SpmmArgs a) {
+    constexpr int NG = 256 / G;
+    __shared__ float sm[NG][G * V * W];
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
     const int gbase = lane & ~(G - 1);
-    const uint64_t h = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
-    if (h >= a.n_items) return;  // no cross-lane traffic between groups below
+    const int grp = threadIdx.x / G;
+    const uint64_t h = blockIdx.x;
     const uint64_t row = a.hub_rows[h];
     const uint64_t s0 = a.hub_seg_first[h], s1 = a.hub_seg_first[h + 1];
+    const uint64_t per = (s1 - s0 + NG - 1) / NG;
+    const uint64_t b = s0 + grp * per < s1 ? s0 + grp * per : s1;
+    const uint64_t e = b + per < s1 ? b + per : s1;
+    const uint32_t d = a.r.d;
     float acc[V][W];
     zero<G, V, W>(acc);
-    for (uint64_t s = s0; s < s1; ++s) {
+    constexpr int U = (8 / V) > 0 ? (8 / V) : 1;
+    uint64_t s = b;
+    for (; s + U <= e; s += U) {
+        float p[U][V][W];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_row<G, V, W, false>(a.partial + (s + u) * (uint64_t)d, gl, d, p[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int q = 0; q < W; ++q) acc[v][q] = fadd(acc[v][q], p[u][v][q]);
+    }
+    for (; s < e; ++s) {
         float p[V][W];
-        load_row<G, V, W, false>(a.partial + s * (uint64_t)a.r.d, gl, a.r.d, p);
+        load_row<G, V, W, false>(a.partial + s * (uint64_t)d, gl, d, p);
 #pragma unroll
         for (int v = 0; v < V; ++v)
 #pragma unroll
             for (int q = 0; q < W; ++q) acc[v][q] = fadd(acc[v][q], p[v][q]);
     }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+        for (int q = 0; q < W; ++q) sm[grp][(v * G + gl) * W + q] = acc[v][q];
+    __syncthreads();
+    if (grp != 0) return;
+    for (int g2 = 1; g2 < NG; ++g2)
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int q = 0; q < W; ++q) acc[v][q] = fadd(acc[v][q], sm[g2][(v * G + gl) * W + q]);
     finish_row<G, V, W, false>(a.r, row, gl, gbase, acc);
 }
 
@@ -444,22 +470,15 @@ inline void mark(const cleora_graph *g, hipStream_t stream) {
     if (hipEvent_t e = take_event(g)) (void)hipEventRecord(e, stream);
 }
 
-// One SpMM over a column panel [c0, c0 + dp) that fits the register-resident shapes.
+// One SpMM over a column panel that fits the register-resident shapes.
 int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stream) {
     const uint32_t d = a.r.d;
     bool ok = true;
     mark(g, stream);
-    if (g->n_hub_segments) {
-        SpmmArgs h = a;
-        h.n_items = g->n_hub_segments;
-        ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
-            hipLaunchKernelGGL((hub_partial_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
-                               dim3(grid_for(h.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, h);
-        });
-    }
-    mark(g, stream);
-    if (ok && g->n_rows) {
-        a.n_items = g->n_rows;
+    mark(g, stream);  // (slot kept: hub partials used to be a launch of their own)
+    a.n_segments = g->n_hub_segments;
+    a.n_items = g->n_hub_segments + g->n_rows;
+    if (a.n_items) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
             hipLaunchKernelGGL((spmm_rows_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value, (decltype(FULL)::value != 0)>),
                                dim3(grid_for(a.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, a);
@@ -467,11 +486,9 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
     }
     mark(g, stream);
     if (ok && g->n_hub_rows) {
-        SpmmArgs h = a;
-        h.n_items = g->n_hub_rows;
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
             hipLaunchKernelGGL((hub_finish_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
-                               dim3(grid_for(h.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, h);
+                               dim3((unsigned)g->n_hub_rows), dim3(256), 0, stream, a);
         });
     }
     mark(g, stream);

@@ -1,0 +1,149 @@
+"""GPU: degenerate inputs the reference handles (empty / ragged / all-empty rows / zero norms) and
+size-independent properties at BASELINE sizes, where the CPU oracle would not finish in seconds."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from cleora_amd import _hip
+from cleora_amd.pycleora import SparseMatrix
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_propagate(g, x, flags=0, kind=0):
+    L = _hip.lib()
+    n_rows, d = g.info().n_rows, x.shape[1]
+    dx, dy = _hip.DevArray.from_host(x), _hip.DevArray((n_rows, d), np.float32)
+    L.cleora_memset(dy.ptr, 0xFF, dy.nbytes, None)
+    _hip.check(L.cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, flags, 0.0, None, None, None))
+    _hip.check(L.cleora_stream_sync(None))
+    return dy.to_host()
+
+
+def test_all_rows_empty_and_zero_norm_rows():
+    n, d = 300, 64
+    rowptr = np.zeros(n + 1, np.uint64)
+    g = _hip.Graph.from_host(rowptr, np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    x = np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)
+    # no edges: zeros (the reference zero-fills), and normalising a zero row keeps zeros (norm clamp 1e-10)
+    np.testing.assert_array_equal(dev_propagate(g, x), np.zeros((n, d), np.float32))
+    np.testing.assert_array_equal(dev_propagate(g, x, _hip.F_L2NORM), np.zeros((n, d), np.float32))
+
+
+def test_single_entity_and_d1():
+    rowptr = np.array([0, 1], np.uint64)
+    g = _hip.Graph.from_host(rowptr, np.array([0], np.uint32), np.array([1.0], np.float32))
+    for d in (1, 2, 256):
+        x = np.full((1, d), -3.0, np.float32)
+        np.testing.assert_array_equal(dev_propagate(g, x), x)
+        np.testing.assert_array_equal(dev_propagate(g, x, _hip.F_L2NORM), oracle.l2_normalize(x))
+
+
+def test_ragged_rows_every_length_up_to_200():
+    # row r has exactly r edges: covers every remainder of the 8-wide unroll and the 64-wide chunking
+    n, d = 201, 256
+    deg = np.arange(n, dtype=np.int64)
+    rowptr = np.zeros(n + 1, np.uint64)
+    rowptr[1:] = np.cumsum(deg).astype(np.uint64)
+    rng = np.random.default_rng(1)
+    col = rng.integers(0, n, int(rowptr[-1])).astype(np.uint32)
+    val = rng.standard_normal(int(rowptr[-1])).astype(np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, val)
+    np.testing.assert_array_equal(dev_propagate(g, x), oracle.spmm(rowptr, col, val, x))
+    for dd in (64, 8, 20):   # sub-wave groups with ragged neighbours in one wavefront
+        xx = np.ascontiguousarray(x[:, :dd])
+        np.testing.assert_array_equal(dev_propagate(g, xx, _hip.F_L2NORM),
+                                      oracle.l2_normalize(oracle.spmm(rowptr, col, val, xx)))
+
+
+def test_special_values_propagate_like_ieee():
+    rowptr = np.array([0, 2, 3, 3], np.uint64)
+    col = np.array([1, 2, 0], np.uint32)
+    val = np.array([0.5, -2.0, 1e30], np.float32)
+    x = np.array([[1e30, 1.0, -0.0, 5.0], [np.inf, 1e-45, 0.0, -1.0], [1.0, np.nan, 0.0, 2.0]], np.float32)
+    g = _hip.Graph.from_host(rowptr, col, val)
+    got = dev_propagate(g, x)
+    want = oracle.spmm(rowptr, col, val, x)
+    np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32))   # inf, nan, denormals, signed zeros
+
+
+def test_empty_graph_object():
+    g = SparseMatrix()
+    assert g.left_markov_propagate(np.zeros((0, 8), np.float32)).shape == (0, 8)
+    assert g.initialize_deterministically(4).shape == (0, 4)
+    assert g.embed_fast(4, 3).shape == (0, 4)
+
+
+def test_wide_rows_panel_path():
+    n, d = 300, 2304   # > 2048: column panels + wide row epilogue
+    rng = np.random.default_rng(3)
+    deg = rng.poisson(6, n).astype(np.int64)
+    rowptr = np.zeros(n + 1, np.uint64)
+    rowptr[1:] = np.cumsum(deg).astype(np.uint64)
+    col = rng.integers(0, n, int(rowptr[-1])).astype(np.uint32)
+    val = rng.random(int(rowptr[-1]), dtype=np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, val)
+    want = oracle.spmm(rowptr, col, val, x)
+    np.testing.assert_array_equal(dev_propagate(g, x), want)
+    np.testing.assert_array_equal(dev_propagate(g, x, _hip.F_L2NORM), oracle.l2_normalize(want))
+
+
+@pytest.mark.parametrize("config", ["C2_bipartite_1M_20M", "C3_powerlaw_10M_200M"])
+def test_properties_at_baseline_sizes(config):
+    """BASELINE configs 2 and 3 at full size: row-stochasticity, linearity, determinism, unit norms,
+    independence from the hub split, and a sampled-row check against the oracle."""
+    import torch
+    from cleora_amd import synth
+    dev = torch.device("cuda:0")
+    if config.startswith("C2"):
+        g = synth.bipartite_graph(500_000, 500_000, 10_000_000, 1, dev)
+    else:
+        g = synth.power_law_graph(10_000_000, 95_000_000, 2, dev)
+    n, nnz, d = g["n"], g["nnz"], 256
+    L = _hip.lib()
+    mk = lambda thr, seg: _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(),
+                                                 g["val_left"].data_ptr(), g["val_sym"].data_ptr(), 0, thr, seg, keepalive=g)
+    graph, graph2 = mk(0, 0), mk(300, 64)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def prop(gr, x, flags=0, kind=0):
+        y = torch.empty_like(x)
+        _hip.check(L.cleora_propagate_dev(gr.handle, kind, x.data_ptr(), d, d, y.data_ptr(), d, flags, 0.0, None, None, s))
+        return y
+
+    # 1. left Markov matrix is row-stochastic: A @ c = c (each row sums to 1 within f32 rounding)
+    c = torch.full((n, d), 0.375, dtype=torch.float32, device=dev)
+    assert float((prop(graph, c) - 0.375).abs().max()) < 2e-5
+    # 2. determinism: two launches are bit-identical
+    x = torch.randn((n, d), dtype=torch.float32, device=dev)
+    y1, y2 = prop(graph, x), prop(graph, x)
+    assert torch.equal(y1, y2)
+    # 3. linearity: A(2x) = 2 A x exactly (power-of-two scaling commutes with every rounding)
+    assert torch.equal(prop(graph, x * 2.0), y1 * 2.0)
+    # 4. hub split changes only the split rows, and only within summation-order tolerance
+    y3 = prop(graph2, x)
+    deg = torch.diff(g["rowptr"])
+    unsplit = deg <= 300
+    assert torch.equal(y3[unsplit], y1[unsplit])
+    assert float((y3 - y1).abs().max()) < 1e-4
+    # 5. fused L2: unit rows
+    yn = prop(graph, x, _hip.F_L2NORM)
+    assert float((yn.double().pow(2).sum(1).sqrt() - 1).abs().max()) < 1e-6
+    # 6. symmetric propagation: sampled rows recomputed on the host in the reference's order, bit-exact
+    rows = torch.randint(0, n, (2000,), device=dev).cpu().numpy()
+    rp = g["rowptr"].cpu().numpy()
+    colh, vsh = g["col"].cpu().numpy().view(np.uint32), g["val_sym"].cpu().numpy()
+    xh = x.cpu().numpy()
+    ys = prop(graph, x, 0, 1).cpu().numpy()
+    for r in rows[:400]:
+        b, e = int(rp[r]), int(rp[r + 1])
+        if e - b > 1024:
+            continue
+        acc = np.zeros(d, np.float32)   # reference order: acc += v * x, separate f32 mul/add
+        for k in range(b, e):
+            acc += vsh[k] * xh[colh[k]]
+        np.testing.assert_array_equal(ys[r], acc)

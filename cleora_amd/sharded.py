@@ -40,13 +40,38 @@ class HipBackend:
             val_left.data_ptr(), val_sym.data_ptr() if val_sym is not None else None,
             self.device.index or 0, hub_threshold, hub_segment, keepalive=keep)
 
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
     def propagate(self, block, kind, x, y, flags, rw=0.0, x_self=None, row_sqdiff=None):
         d = x.shape[1]
-        stream = torch.cuda.current_stream(self.device).cuda_stream
         _hip.check(self.lib.cleora_propagate_dev(
             block.handle, kind, x.data_ptr(), x.stride(0), d, y.data_ptr(), y.stride(0), flags, rw,
             x_self.data_ptr() if x_self is not None else None,
-            row_sqdiff.data_ptr() if row_sqdiff is not None else None, stream))
+            row_sqdiff.data_ptr() if row_sqdiff is not None else None, self._stream()))
+
+    # whitening pieces on a contiguous row range (pycleora/__init__.py:136-163)
+    def colsum(self, x):
+        n, d = x.shape
+        ws = torch.empty(self.lib.cleora_colsum_workspace(n, d), dtype=torch.float64, device=x.device)
+        out = torch.empty(d, dtype=torch.float64, device=x.device)
+        _hip.check(self.lib.cleora_colsum_dev(x.data_ptr(), x.stride(0), n, d, ws.data_ptr(),
+                                              out.data_ptr(), self._stream()))
+        return out
+
+    def gram(self, x, mean):
+        n, d = x.shape
+        ws = torch.empty(self.lib.cleora_gram_workspace(n, d), dtype=torch.float64, device=x.device)
+        out = torch.empty((d, d), dtype=torch.float64, device=x.device)
+        _hip.check(self.lib.cleora_centered_gram_dev(x.data_ptr(), x.stride(0), n, d, mean.data_ptr(),
+                                                     ws.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def project(self, x, mean32, transform, out):
+        n, d = x.shape
+        _hip.check(self.lib.cleora_project_dev(x.data_ptr(), x.stride(0), n, d, mean32.data_ptr(),
+                                               transform.data_ptr(), transform.shape[1], out.data_ptr(),
+                                               out.stride(0), self._stream()))
 
 
 def block_size(n, world, steps):
@@ -85,22 +110,75 @@ class ShardedGraph:
         g0 = k * self.world * self.block
         return g0 + self.rank * self.block, g0
 
-    def propagate(self, kind, x, x_next, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None):
-        """One iteration: x_next <- rowops(A @ x), replicated on every rank.
+    def _gather_step(self, buf, k):
+        """Enqueue the in-place all-gather of step k's row range of `buf` (async)."""
+        mine, g0 = self.rows_of_step(k)
+        return dist.all_gather_into_tensor(buf[g0:g0 + self.world * self.block],
+                                           buf[mine:mine + self.block], group=self.group, async_op=True)
+
+    def propagate(self, kind, x, x_next, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, gather=True):
+        """One iteration: x_next <- rowops(A @ x), replicated on every rank (gather=True) or only
+        this rank's row blocks of x_next written (gather=False: whitening follows).
         x, x_next: (n_pad, d) f32 replicas.  Returns after the collectives are enqueued and
         waited on the current stream (no host sync)."""
         works = []
         for k in range(self.steps):
-            mine, g0 = self.rows_of_step(k)
+            mine, _ = self.rows_of_step(k)
             y = x_next[mine:mine + self.block]
             xs = x[mine:mine + self.block]
             sq = row_sqdiff[k * self.block:(k + 1) * self.block] if row_sqdiff is not None else None
             self.backend.propagate(self.blocks[k], kind, x, y, flags, rw, xs, sq)
-            if self.world > 1:
-                out = x_next[g0:g0 + self.world * self.block]
-                works.append(dist.all_gather_into_tensor(out, y, group=self.group, async_op=True))
+            if self.world > 1 and gather:
+                works.append(self._gather_step(x_next, k))
         for w in works:
             w.wait()
+
+    def _valid_rows(self, k):
+        mine, _ = self.rows_of_step(k)
+        return mine, max(0, min(self.block, self.n - mine))
+
+    def whiten(self, y, out, n_components=None):
+        """whiten_embeddings (pycleora/__init__.py:130-164) over the row partition: `y` holds this
+        rank's blocks of the matrix to whiten; `out` receives the whitened matrix, replicated.
+        Local f64 column sums and centred Gram -> all-reduce (d and d*d doubles) -> eigh on rank 0,
+        transform broadcast -> row-local projection -> in-place all-gather per block."""
+        import numpy as np
+        d = y.shape[1]
+        cs = torch.zeros(d, dtype=torch.float64, device=y.device)
+        for k in range(self.steps):
+            r0, nv = self._valid_rows(k)
+            if nv:
+                cs += self.backend.colsum(y[r0:r0 + nv])
+        if self.world > 1:
+            dist.all_reduce(cs, group=self.group)
+        mean = cs / float(self.n)
+        gram = torch.zeros((d, d), dtype=torch.float64, device=y.device)
+        for k in range(self.steps):
+            r0, nv = self._valid_rows(k)
+            if nv:
+                gram += self.backend.gram(y[r0:r0 + nv], mean)
+        if self.world > 1:
+            dist.all_reduce(gram, group=self.group)
+        kdim = d if n_components is None else min(int(n_components), d)
+        transform = torch.empty((d, kdim), dtype=torch.float32, device=y.device)
+        if self.rank == 0:
+            cov = gram.cpu().numpy() * (1.0 / (self.n - 1))
+            w, v = np.linalg.eigh(cov)
+            idx = np.argsort(w)[::-1][:kdim]
+            scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))
+            transform.copy_(torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32))))
+        if self.world > 1:
+            dist.broadcast(transform, src=0, group=self.group)
+        mean32 = mean.to(torch.float32)
+        works = []
+        for k in range(self.steps):
+            r0, nv = self._valid_rows(k)
+            if nv:
+                self.backend.project(y[r0:r0 + nv], mean32, transform, out[r0:r0 + nv])
+            if self.world > 1:
+                works.append(self._gather_step(out, k))
+        for w_ in works:
+            w_.wait()
 
     def sqdiff_total(self, row_sqdiff):
         """Sum of the per-row squared differences over all ranks (f64)."""
@@ -111,11 +189,20 @@ class ShardedGraph:
 
 
 def embed_sharded(sg, kind, x0, iterations, residual_weight=0.0, convergence_threshold=0.0,
-                  flags=_hip.F_L2NORM):
-    """embed_full / embed_full_with_convergence (src/embedding.rs:106-188) over a ShardedGraph.
+                  flags=_hip.F_L2NORM, whiten=False):
+    """embed_full / embed_full_with_convergence (src/embedding.rs:106-188) over a ShardedGraph;
+    with whiten=True the default embed() loop of pycleora/__init__.py:109-125 (normalise, then
+    whiten, every iteration; no convergence test in that mode here).
     x0: (n_pad, d) replica (rows >= n zero).  Returns (x, iterations_run)."""
     x = x0
     x_next = torch.zeros_like(x0)
+    if whiten:
+        y = torch.zeros_like(x0)
+        for _ in range(iterations):
+            sg.propagate(kind, x, y, flags | _hip.F_RESIDUAL, residual_weight, gather=False)
+            sg.whiten(y, x_next)
+            x, x_next = x_next, x
+        return x, iterations
     check = convergence_threshold > 0
     flags = flags | _hip.F_RESIDUAL
     sq = torch.zeros(sg.steps * sg.block, dtype=torch.float64, device=x0.device) if check else None

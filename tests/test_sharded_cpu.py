@@ -34,6 +34,16 @@ class OracleBackend:
             row_sqdiff.copy_(torch.from_numpy((delta * delta).sum(axis=1)))
         y.copy_(torch.from_numpy(out))
 
+    def colsum(self, x):
+        return torch.from_numpy(x.numpy().sum(axis=0, dtype=np.float64))
+
+    def gram(self, x, mean):
+        blk = x.numpy().astype(np.float64) - mean.numpy()
+        return torch.from_numpy(blk.T @ blk)
+
+    def project(self, x, mean32, transform, out):
+        out.copy_(torch.from_numpy((x.numpy() - mean32.numpy()) @ transform.numpy()))
+
 
 def _free_port():
     s = socket.socket()
@@ -58,6 +68,8 @@ def _worker(rank, world, port, steps, q):
         for kind, rw, thr in ((0, 0.0, 0.0), (1, 0.4, 0.0), (0, 0.0, 2e-3)):
             x, ran = sharded.embed_sharded(sg, kind, torch.from_numpy(x0.copy()), 12, rw, thr)
             res[(kind, rw, thr)] = (x[:n].numpy().copy(), ran, float(x[n:].abs().max()) if sg.n_pad > n else 0.0)
+        xw, _ = sharded.embed_sharded(sg, 0, torch.from_numpy(x0.copy()), 3, whiten=True)
+        res["whiten"] = xw[:n].numpy().copy()
         q.put((rank, sg.block, sg.n_pad, sg.local_nnz, res))
     finally:
         dist.destroy_process_group()
@@ -80,6 +92,14 @@ def test_world2_matches_single_process(steps):
     x0 = np.random.default_rng(9).standard_normal((n, d)).astype(np.float32)
     assert sum(g[3] for g in got) == int(rowptr[-1])            # every edge owned exactly once
     assert got[0][2] == got[1][2] and got[0][2] >= n and got[0][2] % (world * steps * 4) == 0
+    from oracle import whiten as ow
+    want_w, _ = ow.embed_slow(lambda x: oracle.spmm(rowptr, col, vl, x), x0, 3, whiten=True)
+    for rank, _, _, _, res in got:
+        w = res.pop("whiten")
+        # the partitioned Gram sums row blocks in a different order than the reference's 50k chunks:
+        # f64-rounding-level differences in cov, amplified through 3 whitenings
+        assert np.abs(w - want_w).max() <= 2e-3 * np.abs(want_w).max()
+    np.testing.assert_array_equal(got[0][4].get("whiten", 0), got[1][4].get("whiten", 0))
     for (kind, rw, thr), val in ((k, (vl, vs)[k[0]]) for k in got[0][4]):
         want, it = oracle.embed(rowptr, col, val, x0, 12, residual_weight=rw, convergence_threshold=thr)
         for rank, _, _, _, res in got:

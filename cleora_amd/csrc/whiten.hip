@@ -4,8 +4,9 @@
 //   centered Gram   G = sum_r (x_r - mu)(x_r - mu)^T  in f64     (:138-143, without the 1/(n-1))
 //     v_mfma_f64_16x16x4_f64; operands are centred and widened to f64 when the X tile is staged
 //     into LDS, so the accumulation is f64 end to end like the reference's `block.T @ block`
-//     on an f64 block.  Only block tiles on or above the diagonal are computed; the row range is
-//     cut into slices that are combined in a fixed order (deterministic).
+//     on an f64 block.  Only block tiles on or above the diagonal are computed, and of a diagonal
+//     block tile only its 36 upper 16x16 MFMA tiles (9 per wave); the row range is cut into slices
+//     that are combined in a fixed order (deterministic).
 //   projection      out = (X - mu_f32) @ T  in f32                 (:157-163)
 //     v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate — the same arithmetic class
 //     as the reference's sgemm; summation order differs, tolerance documented in the tests).
@@ -64,14 +65,19 @@ __device__ __forceinline__ float4 load4(const float *rp, uint32_t c, uint32_t d,
     return v;
 }
 
-__global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
-    __shared__ __attribute__((aligned(16))) double lds[2][GKC][GLD];
+// Tiles of a DIAGONAL block tile: only the 36 MFMA tiles (ti <= tj) of its 8 x 8 grid are needed
+// (the rest is the mirror image).  They are dealt 9 per wave; (ti, tj) = kDiagTiles[wave][t].
+__constant__ unsigned char kDiagTiles[4][9][2] = {
+    {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {0, 7}, {1, 1}},
+    {{1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}, {2, 2}, {2, 3}, {2, 4}},
+    {{2, 5}, {2, 6}, {2, 7}, {3, 3}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {4, 4}},
+    {{4, 5}, {4, 6}, {4, 7}, {5, 5}, {5, 6}, {5, 7}, {6, 6}, {6, 7}, {7, 7}}};
+
+template <bool DIAG>
+__device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DIAG ? 1 : 2][GKC][GLD],
+                                          uint32_t bi, uint32_t bj, uint32_t pair) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
-    uint32_t bi, bj;
-    pair_to_tiles(blockIdx.x, a.tiles, bi, bj);
-    const bool diag = bi == bj;
-    const bool compute = !(diag && wr > wc);
     const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
 
@@ -85,11 +91,25 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
         mB[q] = (colB + q < a.d) ? a.mean[colB + q] : 0.0;
     }
 
-    d4 acc[4][4];
+    constexpr int NACC = DIAG ? 9 : 16;
+    d4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    // LDS column of the A / B fragment of accumulator i (lane & 15 added at the read)
+    int fa_col[DIAG ? 9 : 4], fb_col[DIAG ? 9 : 4];
+    if constexpr (DIAG) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < 9; ++i) {
+            fa_col[i] = kDiagTiles[w][i][0] * 16;
+            fb_col[i] = kDiagTiles[w][i][1] * 16;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa_col[i] = wr * 64 + i * 16;
+            fb_col[i] = wc * 64 + i * 16;
+        }
+    }
 
     float4 pa[2], pb[2];
     bool ok[2];
@@ -101,70 +121,104 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
             ok[h] = r < r_end;
             const float *rp = a.x + r * a.ldx;
             pa[h] = load4(rp, colA, a.d, ok[h], a.w4);
-            if (!diag) pb[h] = load4(rp, colB, a.d, ok[h], a.w4);
+            if (!DIAG) pb[h] = load4(rp, colB, a.d, ok[h], a.w4);
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float va[4] = {pa[h].x, pa[h].y, pa[h].z, pa[h].w};
             const float vb[4] = {pb[h].x, pb[h].y, pb[h].z, pb[h].w};
-            double *da = &lds[0][lr + 8 * h][c4 * 4];
-            double *db = &lds[1][lr + 8 * h][c4 * 4];
+            double *da = &lds[buf][0][lr + 8 * h][c4 * 4];
+            double *db = &lds[buf][DIAG ? 0 : 1][lr + 8 * h][c4 * 4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // centre in f64: block.astype(float64) - mean          (pycleora/__init__.py:141)
                 da[q] = (ok[h] && colA + q < a.d) ? (double)va[q] - mA[q] : 0.0;
-                if (!diag) db[q] = (ok[h] && colB + q < a.d) ? (double)vb[q] - mB[q] : 0.0;
+                if constexpr (!DIAG) db[q] = (ok[h] && colB + q < a.d) ? (double)vb[q] - mB[q] : 0.0;
             }
         }
     };
 
-    if (r_begin < r_end) prefetch(r_begin);
-    for (uint64_t row0 = r_begin; row0 < r_end; row0 += GKC) {
-        stage();
-        __syncthreads();
-        if (row0 + GKC < r_end) prefetch(row0 + GKC);
-        if (compute) {
-            const int pb_sel = diag ? 0 : 1;
+    // Double-buffered LDS, one barrier per chunk: while the MFMAs of chunk c run from buffer c&1,
+    // chunk c+1 (already in registers) is staged into the other buffer and chunk c+2 is fetched.
+    if (r_begin < r_end) {
+        prefetch(r_begin);
+        stage(0);
+        if (r_begin + GKC < r_end) prefetch(r_begin + GKC);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += GKC, buf ^= 1) {
+        if (row0 + GKC < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * GKC < r_end) prefetch(row0 + 2 * GKC);
+        }
+        constexpr int PB = DIAG ? 0 : 1;
 #pragma unroll
-            for (int kk = 0; kk < GKC / 4; ++kk) {
-                const int krow = kk * 4 + (lane >> 4);
+        for (int kk = 0; kk < GKC / 4; ++kk) {
+            const int krow = kk * 4 + (lane >> 4);
+            if constexpr (DIAG) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const double fa = lds[buf][0][krow][fa_col[i] + (lane & 15)];
+                    const double fb = lds[buf][0][krow][fb_col[i] + (lane & 15)];
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[i], 0, 0, 0);
+                }
+            } else {
                 double fa[4], fb[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = lds[0][krow][wr * 64 + i * 16 + (lane & 15)];
+                for (int i = 0; i < 4; ++i) fa[i] = lds[buf][0][krow][fa_col[i] + (lane & 15)];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = lds[pb_sel][krow][wc * 64 + j * 16 + (lane & 15)];
+                for (int j = 0; j < 4; ++j) fb[j] = lds[buf][PB][krow][fb_col[j] + (lane & 15)];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i * 4 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i * 4 + j], 0, 0, 0);
             }
         }
         __syncthreads();
     }
 
-    if (compute) {
-        double *out = a.partial + ((uint64_t)blockIdx.y * a.pairs + blockIdx.x) * (uint64_t)(GT * GT);
+    double *out = a.partial + ((uint64_t)blockIdx.y * a.pairs + pair) * (uint64_t)(GT * GT);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC; ++i) {
+        const int trow = DIAG ? fa_col[i] : fa_col[i / 4];
+        const int tcol = DIAG ? fb_col[i] : fb_col[i % 4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    // f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
-                    const int row = wr * 64 + i * 16 + (lane >> 4) + 4 * reg;
-                    const int col = wc * 64 + j * 16 + (lane & 15);
-                    out[row * GT + col] = acc[i][j][reg];
-                }
+        for (int reg = 0; reg < 4; ++reg) {
+            // f64 16x16x4 C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg
+            out[(trow + (lane >> 4) + 4 * reg) * GT + tcol + (lane & 15)] = acc[i][reg];
+        }
     }
+}
+
+__device__ __forceinline__ uint32_t pair_index(uint32_t bi, uint32_t bj, uint32_t tiles) {
+    return bi * tiles - bi * (bi - 1) / 2 + (bj - bi);
+}
+
+// Two launches so each body gets its own register budget (2 waves/SIMD each):
+// DIAG: blockIdx.x = diagonal tile; off-diagonal: blockIdx.x enumerates the pairs bi < bj.
+template <bool DIAG>
+__global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
+    __shared__ __attribute__((aligned(16))) double lds[2][DIAG ? 1 : 2][GKC][GLD];
+    uint32_t bi, bj;
+    if constexpr (DIAG) {
+        bi = bj = blockIdx.x;
+    } else {
+        uint32_t q = blockIdx.x, rowlen = a.tiles - 1;
+        bi = 0;
+        while (q >= rowlen) { q -= rowlen; ++bi; --rowlen; }
+        bj = bi + 1 + q;
+    }
+    gram_body<DIAG>(a, lds, bi, bj, pair_index(bi, bj, a.tiles));
 }
 
 // gram[gi][gj] = sum over slices (fixed order) of the partial tiles; mirrors the upper triangle.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ partial,
-                                                          uint32_t slices, uint32_t pairs,
-                                                          uint32_t tiles, uint32_t d,
+                                                          uint32_t s_diag, uint32_t s_off,
+                                                          uint32_t pairs, uint32_t tiles, uint32_t d,
                                                           double *__restrict__ gram) {
     const uint32_t p = blockIdx.y;
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;  // element of the GT x GT tile
@@ -172,21 +226,43 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
     uint32_t bi, bj;
     pair_to_tiles(p, tiles, bi, bj);
     const bool diag = bi == bj;
-    if (diag && (r / 64) > (c / 64)) return;  // not computed: mirrored from the (0,1) quadrant
+    const uint32_t slices = diag ? s_diag : s_off;
+    if (diag && (r / 16) > (c / 16)) return;  // not computed: mirror image of an upper MFMA tile
     const uint32_t gi = bi * GT + r, gj = bj * GT + c;
     if (gi >= d || gj >= d) return;
     double s = 0.0;
     for (uint32_t sl = 0; sl < slices; ++sl)
         s += partial[((uint64_t)sl * pairs + p) * (uint64_t)(GT * GT) + e];
     gram[(uint64_t)gi * d + gj] = s;
-    if (!diag || (r / 64) < (c / 64)) gram[(uint64_t)gj * d + gi] = s;
+    if (!diag || (r / 16) < (c / 16)) gram[(uint64_t)gj * d + gi] = s;
 }
 
-inline uint32_t gram_slices(uint64_t n, uint32_t pairs) {
-    uint64_t s = (2048 + pairs - 1) / pairs;
-    const uint64_t cap = (n + 255) / 256;
+// Row slices per launch: the grid is sized to ONE resident round (2 blocks per CU) so there is no
+// partial last round — with 1-3 block tiles per launch at d = 256 a generic "many blocks" grid left
+// a third of the chip idle in its tail.  `group` = block tiles in the launch.
+inline uint32_t gram_slices(uint64_t n, uint32_t group) {
+    static int resident = 0;
+    if (!resident) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        resident = 2 * (cus > 0 ? cus : 256);
+    }
+    uint64_t s = group ? (uint64_t)resident / group : 1;
+    const uint64_t cap = (n + GKC - 1) / GKC;   // at least one chunk of rows per slice
     if (s > cap) s = cap;
     return (uint32_t)(s < 1 ? 1 : s);
+}
+
+struct GramPlan { uint32_t tiles, pairs, s_diag, s_off, s_max; };
+
+inline GramPlan gram_plan(uint64_t n, uint32_t d) {
+    GramPlan p;
+    p.tiles = (d + GT - 1) / GT;
+    p.pairs = p.tiles * (p.tiles + 1) / 2;
+    p.s_diag = gram_slices(n, p.tiles);
+    p.s_off = p.tiles > 1 ? gram_slices(n, p.pairs - p.tiles) : 0;
+    p.s_max = p.s_diag > p.s_off ? p.s_diag : p.s_off;
+    return p;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,9 +375,8 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
 }  // namespace
 
 uint64_t gram_workspace(uint64_t n, uint32_t d) {
-    const uint32_t tiles = (d + GT - 1) / GT;
-    const uint32_t pairs = tiles * (tiles + 1) / 2;
-    return (uint64_t)gram_slices(n, pairs) * pairs * GT * GT;
+    const GramPlan p = gram_plan(n, d);
+    return (uint64_t)p.s_max * p.pairs * GT * GT;
 }
 
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
@@ -309,6 +384,7 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && mean != nullptr && ws != nullptr && gram != nullptr,
                "x / mean / workspace / gram is NULL");
+    const GramPlan p = gram_plan(n, d);
     GramArgs a{};
     a.x = x;
     a.ldx = ldx;
@@ -316,18 +392,24 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
     a.d = d;
     a.mean = mean;
     a.partial = ws;
-    a.tiles = (d + GT - 1) / GT;
-    a.pairs = a.tiles * (a.tiles + 1) / 2;
-    const uint32_t slices = gram_slices(n, a.pairs);
-    uint64_t rps = (n + slices - 1) / slices;
-    rps = (rps + GKC - 1) / GKC * GKC;
-    a.rows_per_slice = rps ? rps : GKC;
+    a.tiles = p.tiles;
+    a.pairs = p.pairs;
     a.w4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
-    CL_REQUIRE(slices <= 65535, "internal: too many Gram slices");
+    auto rows_per_slice = [&](uint32_t slices) {
+        uint64_t rps = (n + slices - 1) / slices;
+        rps = (rps + GKC - 1) / GKC * GKC;
+        return rps ? rps : (uint64_t)GKC;
+    };
+    CL_REQUIRE(p.s_max <= 65535, "internal: too many Gram slices");
     // quadrants that are never computed are skipped by the reducer, so no memset is needed
-    hipLaunchKernelGGL(gram_kernel, dim3(a.pairs, slices), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, a.pairs), dim3(256), 0, stream, ws,
-                       slices, a.pairs, a.tiles, d, gram);
+    a.rows_per_slice = rows_per_slice(p.s_diag);
+    hipLaunchKernelGGL(gram_kernel<true>, dim3(p.tiles, p.s_diag), dim3(256), 0, stream, a);
+    if (p.tiles > 1) {
+        a.rows_per_slice = rows_per_slice(p.s_off);
+        hipLaunchKernelGGL(gram_kernel<false>, dim3(p.pairs - p.tiles, p.s_off), dim3(256), 0, stream, a);
+    }
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, p.pairs), dim3(256), 0, stream, ws,
+                       p.s_diag, p.s_off, p.pairs, p.tiles, d, gram);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

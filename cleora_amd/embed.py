@@ -23,12 +23,36 @@ DEFAULT_FEATURE_DIM = 256       # pycleora/__init__.py:12
 DEFAULT_NUM_ITERATIONS = 40     # pycleora/__init__.py:13
 
 
+def eigh_descending(cov, backend="auto"):
+    """Eigen-decomposition of the covariance, eigenvalues descending (pycleora/__init__.py:145-149).
+    backend "host": numpy/LAPACK, the routine the reference itself calls (default below d = 512:
+    5 ms at d = 256).  "device": torch.linalg.eigh on the GPU (rocSOLVER) — 23 ms instead of 322 ms
+    at d = 1024 on the MI355X box; eigenvector signs may differ from LAPACK's, which whitening
+    tolerates.  "auto": host below d = 512, device above when torch+GPU exist."""
+    d = cov.shape[0]
+    use_device = backend == "device"
+    if backend == "auto" and d >= 512:
+        try:
+            import torch
+            use_device = torch.cuda.is_available()
+        except ImportError:
+            use_device = False
+    if use_device:
+        import torch
+        w, v = torch.linalg.eigh(torch.from_numpy(cov).cuda())
+        w, v = w.cpu().numpy(), v.cpu().numpy()
+    else:
+        w, v = np.linalg.eigh(cov)
+    idx = np.argsort(w)[::-1]
+    return w[idx], v[:, idx]
+
+
 class DeviceWhitener:
     """whiten_embeddings on device buffers.  Workspaces are sized once per (n, d)."""
 
-    def __init__(self, n, d):
+    def __init__(self, n, d, eigh="auto"):
         L = _hip.lib()
-        self.n, self.d, self.L = n, d, L
+        self.n, self.d, self.L, self.eigh = n, d, L, eigh
         self.colsum_ws = _hip.DevArray((L.cleora_colsum_workspace(n, d),), np.float64)
         self.colsum = _hip.DevArray((d,), np.float64)
         self.mean64 = _hip.DevArray((d,), np.float64)
@@ -56,9 +80,7 @@ class DeviceWhitener:
         """out = whiten_embeddings(x).  Returns k (columns written)."""
         L, n, d = self.L, self.n, self.d
         mean, cov = self.stats(x_ptr, ldx, stream)
-        w, v = np.linalg.eigh(cov)                       # :145 — same LAPACK routine as the reference
-        idx = np.argsort(w)[::-1]                        # :147-149
-        w, v = w[idx], v[:, idx]
+        w, v = eigh_descending(cov, self.eigh)           # :145-149
         if n_components is not None:                     # :151-153
             w, v = w[:n_components], v[:, :n_components]
         scale = 1.0 / np.sqrt(np.maximum(w, 1e-10))      # :155

@@ -163,10 +163,11 @@ class ShardedGraph:
         transform = torch.empty((d, kdim), dtype=torch.float32, device=y.device)
         if self.rank == 0:
             cov = gram.cpu().numpy() * (1.0 / (self.n - 1))
-            w, v = np.linalg.eigh(cov)
-            idx = np.argsort(w)[::-1][:kdim]
-            scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))
-            transform.copy_(torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32))))
+            from .embed import eigh_descending
+            w, v = eigh_descending(cov, "auto" if y.is_cuda else "host")
+            w, v = w[:kdim], v[:, :kdim]
+            scale = 1.0 / np.sqrt(np.maximum(w, 1e-10))
+            transform.copy_(torch.from_numpy(np.ascontiguousarray((v * scale).astype(np.float32))))
         if self.world > 1:
             dist.broadcast(transform, src=0, group=self.group)
         mean32 = mean.to(torch.float32)

@@ -7,10 +7,13 @@
 
 One "step" = one propagate iteration of BASELINE.json's metric workload: CSR x dense SpMM with
 the L2 normalisation fused into its epilogue (src/embedding.rs:106-136, one loop body of
-embed_full) on the synthetic power-law graph |V| = 10M, |E| = nnz ~ 200M, d = 256, plus, for
-N > 1, the all-gather of the row-partitioned next iterate (cleora_amd/sharded.py).  The graph,
-X and the CSR are resident in HBM before the timed region.  Total work is fixed as N grows
-("strong" scaling, as BASELINE.json quotes the same graph at 1/2/4/8 GPUs).
+embed_full) on the synthetic power-law graph |V| = 10M, |E| = nnz ~ 200M, d = 256.  For N > 1
+(cleora_amd/sharded.py) the default is the COLUMN partition — each rank owns d/N columns of X
+and the whole CSR, and the only collective per iteration is an all-reduce of the n row
+sums-of-squares; `--partition row` selects north_star's literal layout (row blocks + in-place
+all-gather of the 10 GB iterate), which is xGMI-bound.  The graph, X and the CSR
+are resident in HBM before the timed region.  Total work is fixed as N grows ("strong" scaling,
+as BASELINE.json quotes the same graph at 1/2/4/8 GPUs).
 
 Prints ONE JSON line on rank 0.  `value` = nnz * d * steps / seconds (edge*dim/s, whole job);
 `roofline` is for the dominant kernel (spmm_rows_kernel) from HIP events recorded inside the
@@ -78,8 +81,13 @@ def main():
     ap.add_argument("--overlap-steps", type=int, default=0,
                     help="row blocks per rank per iteration (gather of block k overlaps SpMM of k+1); "
                          "0 = 1 on one GPU, 4 otherwise")
+    ap.add_argument("--partition", default="auto", choices=["auto", "row", "column"],
+                    help="multi-GPU partition: 'column' = each rank owns d/N columns of X (one all-reduce of "
+                         "n floats per iteration); 'row' = row blocks + in-place all-gather of X (north_star's "
+                         "literal layout, 10 GB per iteration over xGMI); auto = column for N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,32 +99,70 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+    partition = args.partition
+    if partition == "auto":
+        partition = "column" if world > 1 else "row"
+    if partition == "column" and args.dim % (4 * world) != 0:
+        partition = "row"
 
     d = args.dim
     steps_per_iter = args.overlap_steps or (1 if world == 1 else 4)
     g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)  # same seed on every rank
     n, nnz = g["n"], g["nnz"]
-    sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world,
-                              steps_per_iter, sharded.HipBackend(dev))
-    # algorithmic bytes of this rank's dominant-kernel launches (rows the rows-kernel owns)
     deg = torch.diff(g["rowptr"])
-    launch_bytes = []
-    for k in range(steps_per_iter):
-        r0 = min((k * world + rank) * sg.block, n)
-        r1 = min(r0 + sg.block, n)
-        dk = deg[r0:r1]
-        main_rows = dk <= sg.blocks[k].info().hub_threshold
-        launch_bytes.append(algorithmic_bytes(int(dk[main_rows].sum()), sg.block, sg.block, d))
     hashes = synth.entity_hashes(n, 0, dev)
-    x = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
-    x_next = torch.zeros_like(x)
     L = _hip.lib()
-    _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d,
-                                 torch.cuda.current_stream().cuda_stream))
+    backend = sharded.HipBackend(dev)
+    launch_bytes = []
+    if partition == "row":
+        sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world,
+                                  steps_per_iter, backend)
+        blocks = sg.blocks
+        # algorithmic bytes of this rank's dominant-kernel launches (rows the rows-kernel owns)
+        for k in range(steps_per_iter):
+            r0 = min((k * world + rank) * sg.block, n)
+            r1 = min(r0 + sg.block, n)
+            dk = deg[r0:r1]
+            main_rows = dk <= sg.blocks[k].info().hub_threshold
+            launch_bytes.append(algorithmic_bytes(int(dk[main_rows].sum()), sg.block, sg.block, d))
+        x = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
+        x_next = torch.zeros_like(x)
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d,
+                                     torch.cuda.current_stream().cuda_stream))
+        kernel_name = "spmm_rows_kernel<64,1,4,true>"
+        par = (f"row-block-cyclic x{world}, {steps_per_iter} block(s)/rank/iter"
+               + (", in-place RCCL all-gather overlapped with the next block" if world > 1 else ""))
+
+        def iterate():
+            nonlocal x, x_next
+            sg.propagate(_hip.LEFT, x, x_next)
+            x, x_next = x_next, x
+    else:
+        cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend)
+        blocks = [cg.block]
+        dl = cg.dl
+        main_rows = deg <= cg.block.info().hub_threshold
+        launch_bytes.append(algorithmic_bytes(int(deg[main_rows].sum()), n, n, dl))
+        x = torch.empty((n, dl), dtype=torch.float32, device=dev)
+        x_next = torch.empty_like(x)
+        rowsq = torch.zeros(n, dtype=torch.float32, device=dev)
+        # columns [c0, c0 + dl) of the deterministic init: init_value depends on hash + col + seed only
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, dl, cg.c0, x.data_ptr(), dl,
+                                     torch.cuda.current_stream().cuda_stream))
+        g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
+        kernel_name = f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true>"
+        par = (f"column partition x{world}: every rank owns {dl} of {d} columns and the whole CSR; "
+               f"one RCCL all-reduce of n f32 row sums-of-squares per iteration, no exchange of X")
+
+        def iterate():
+            nonlocal x, x_next
+            cg.propagate(_hip.LEFT, x, x_next, rowsq)
+            x, x_next = x_next, x
     keep_full = g if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
-    del g, deg, hashes
+    del deg, hashes
+    if partition == "row":
+        del g
     torch.cuda.empty_cache()
 
     def sync():
@@ -126,15 +172,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sg.propagate(_hip.LEFT, x, x_next)
-        x, x_next = x_next, x
-    for blk in sg.blocks:
+        iterate()
+    for blk in blocks:
         blk.set_timing(True)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sg.propagate(_hip.LEFT, x, x_next)
-        x, x_next = x_next, x
+        iterate()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -144,7 +188,7 @@ def main():
 
     # dominant kernel: average launch duration from the HIP events recorded in the timed region
     rows_ms, calls, other_ms = 0.0, 0, 0.0
-    for blk in sg.blocks:
+    for blk in blocks:
         ms, c = blk.get_timing()
         blk.set_timing(False)
         rows_ms += ms[1]
@@ -154,7 +198,10 @@ def main():
     avg_bytes = sum(launch_bytes) / len(launch_bytes)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     finite = bool(torch.isfinite(x[:n]).all())
-    norm_err = float((x[:n].double().pow(2).sum(1).sqrt() - 1).abs().max())
+    sumsq = x[:n].double().pow(2).sum(1)
+    if partition == "column" and world > 1:
+        dist.all_reduce(sumsq)
+    norm_err = float((sumsq.sqrt() - 1).abs().max())
 
     if rank == 0:
         traffic = None
@@ -168,7 +215,8 @@ def main():
                 traffic = None
         out = {
             "metric": "propagate edges*dim/sec (SpMM + fused L2 norm"
-                      + (" + all-gather" if world > 1 else "") + "), |V|=10M |E|=200M d=256",
+                      + ("" if world == 1 else (" + all-gather of X" if partition == "row" else " + all-reduce of row norms"))
+                      + "), |V|=10M |E|=200M d=256",
             "value": nnz * d * args.steps / elapsed,
             "unit": "edge*dim/s",
             "iterations_per_sec": args.steps / elapsed,
@@ -179,10 +227,8 @@ def main():
             "config": {"workload": f"synthetic power-law graph, reflexive column semantics "
                                    f"(BASELINE config 3): n={n}, nnz={nnz}, d={d}, left Markov",
                        "n": n, "nnz": nnz, "d": d,
-                       "parallelism": f"row-block-cyclic x{world}, {steps_per_iter} block(s)/rank/iter"
-                                      + (", in-place RCCL all-gather overlapped with the next block" if world > 1 else ""),
-                       "seed": 2},
-            "roofline": {"bound": "hbm", "kernel": "spmm_rows_kernel<64,1,4,true>",
+                       "parallelism": par, "partition": partition, "seed": 2},
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,

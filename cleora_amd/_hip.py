@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcleora_hip.so")
 
 OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4
 LEFT, SYMMETRIC = 0, 1
-F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF = 1, 2, 4, 8
+F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE = 1, 2, 4, 8, 16, 32
 
 c_u64, c_u32, c_i64, c_int, c_f32 = (ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_float)
@@ -48,8 +48,8 @@ SIGNATURES = {
     "cleora_graph_get_info": (c_int, [vp, ctypes.POINTER(GraphInfo)]),
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
-    "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
-    "cleora_rowops_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
+    "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
+    "cleora_rowops_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_init_dev": (c_int, [vp, c_u64, c_u32, c_i64, vp, c_u64, vp]),
     "cleora_reduce_workspace": (c_u64, [c_u64]),
     "cleora_reduce_sum_f64_dev": (c_int, [vp, c_u64, vp, vp, vp]),

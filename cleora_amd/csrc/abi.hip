@@ -316,15 +316,16 @@ int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls) {
 int cleora_propagate_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx,
                          uint32_t d, float *y, uint64_t ldy, uint32_t flags,
                          float residual_weight, const float *x_self, double *row_sqdiff,
-                         void *stream) {
+                         float *row_sumsq, void *stream) {
     return launch_propagate(g, markov_type, x, ldx, d, y, ldy, flags, residual_weight, x_self,
-                            row_sqdiff, S(stream));
+                            row_sqdiff, row_sumsq, S(stream));
 }
 
 int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                       uint32_t flags, float residual_weight, const float *x_self,
-                      double *row_sqdiff, void *stream) {
-    return launch_rowops(x, ldx, n, d, y, ldy, flags, residual_weight, x_self, row_sqdiff, S(stream));
+                      double *row_sqdiff, float *row_sumsq, void *stream) {
+    return launch_rowops(x, ldx, n, d, y, ldy, flags, residual_weight, x_self, row_sqdiff, row_sumsq,
+                         S(stream));
 }
 
 int cleora_init_dev(const uint64_t *entity_hash_dev, uint64_t n, uint32_t d, int64_t seed,
@@ -374,7 +375,7 @@ int cleora_propagate(const cleora_graph *g, int markov_type, const float *x_host
     if ((rc = x.alloc(xb)) != CLEORA_OK || (rc = y.alloc(yb)) != CLEORA_OK) return rc;
     CL_HIP(hipMemcpy(x.p, x_host, xb, hipMemcpyHostToDevice));
     rc = launch_propagate(g, markov_type, x.as<float>(), d, d, y.as<float>(), d, 0, 0.f, nullptr,
-                          nullptr, nullptr);
+                          nullptr, nullptr, nullptr);
     if (rc != CLEORA_OK) return rc;
     CL_HIP(hipMemcpy(y_host, y.p, yb, hipMemcpyDeviceToHost));
     return CLEORA_OK;
@@ -390,7 +391,7 @@ int cleora_l2_normalize(const float *x_host, uint64_t n, uint32_t d, float *y_ho
     if ((rc = x.alloc(bytes)) != CLEORA_OK) return rc;
     CL_HIP(hipMemcpy(x.p, x_host, bytes, hipMemcpyHostToDevice));
     rc = launch_rowops(x.as<float>(), d, n, d, x.as<float>(), d, CLEORA_F_L2NORM, 0.f, nullptr,
-                       nullptr, nullptr);
+                       nullptr, nullptr, nullptr);
     if (rc != CLEORA_OK) return rc;
     CL_HIP(hipMemcpy(y_host, x.p, bytes, hipMemcpyDeviceToHost));
     return CLEORA_OK;
@@ -447,7 +448,7 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
     for (uint64_t it = 0; it < max_iterations; ++it) {
         const bool test = check && it > 0;  // embedding.rs:169
         rc = launch_propagate(g, markov_type, src, d, d, dst, d, base | (test ? CLEORA_F_SQDIFF : 0u),
-                              residual_weight, src, test ? sq.as<double>() : nullptr, nullptr);
+                              residual_weight, src, test ? sq.as<double>() : nullptr, nullptr, nullptr);
         if (rc != CLEORA_OK) return rc;
         std::swap(src, dst);
         if (test) {

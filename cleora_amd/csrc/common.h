@@ -71,10 +71,10 @@ namespace cleora {
 // spmm.hip
 int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                      float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
-                     double *row_sqdiff, hipStream_t stream);
+                     double *row_sqdiff, float *row_sumsq, hipStream_t stream);
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
-                  hipStream_t stream);
+                  float *row_sumsq, hipStream_t stream);
 // rowops.hip
 int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, float *x, uint64_t ldx,
                 hipStream_t stream);

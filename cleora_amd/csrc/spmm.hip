@@ -34,6 +34,7 @@ struct RowArgs {
     const float *x_self;
     uint64_t ldxs;
     double *row_sqdiff;
+    float *row_sumsq;
     float rw, alpha;
     uint32_t flags;  // CLEORA_F_* with RESIDUAL already gated on 0 < rw < 1
     uint32_t d;
@@ -178,9 +179,11 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
                 acc[v][q] = fadd(fmul(ra.alpha, acc[v][q]), fmul(ra.rw, xs[v][q]));
     }
 
-    if (ra.flags & CLEORA_F_L2NORM) {
+    if (ra.flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ | CLEORA_F_SCALE)) {
         float s = 0.f;
-        if (ra.flags & CLEORA_F_FASTNORM) {
+        if (ra.flags & CLEORA_F_SCALE) {
+            s = ra.row_sumsq[row];  // complete (all-reduced) sum of squares of the whole row
+        } else if (ra.flags & CLEORA_F_FASTNORM) {
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
@@ -203,13 +206,16 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
                 }
             }
         }
-        // norm = sum_sq.sqrt().max(1e-10); inv = 1/norm; v *= inv    (src/embedding.rs:98-102)
-        const float norm = fmaxf(sqrtf(s), 1e-10f);
-        const float inv = (1.0f / norm);
+        if ((ra.flags & CLEORA_F_ROWSQ) && gl == 0) ra.row_sumsq[row] = s;
+        if (ra.flags & (CLEORA_F_L2NORM | CLEORA_F_SCALE)) {
+            // norm = sum_sq.sqrt().max(1e-10); inv = 1/norm; v *= inv    (src/embedding.rs:98-102)
+            const float norm = fmaxf(sqrtf(s), 1e-10f);
+            const float inv = (1.0f / norm);
 #pragma unroll
-        for (int v = 0; v < V; ++v)
+            for (int v = 0; v < V; ++v)
 #pragma unroll
-            for (int q = 0; q < W; ++q) acc[v][q] = fmul(acc[v][q], inv);
+                for (int q = 0; q < W; ++q) acc[v][q] = fmul(acc[v][q], inv);
+        }
     }
 
     if (ra.flags & CLEORA_F_SQDIFF) {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64
         float v = j < d ? xr[j] : 0.f;
         if ((ra.flags & CLEORA_F_RESIDUAL) && j < d) v = fadd(fmul(ra.alpha, v), fmul(ra.rw, xs[j]));
         if (j < d) yr[j] = v;
-        if (ra.flags & CLEORA_F_L2NORM) {
+        if ((ra.flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ)) && !(ra.flags & CLEORA_F_SCALE)) {
             const float sq = fmul(v, v);
             if (ra.flags & CLEORA_F_FASTNORM) {
                 float t = sq;
@@ -388,13 +394,16 @@ __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64
         }
     }
     float inv = 1.0f;
-    if (ra.flags & CLEORA_F_L2NORM) inv = (1.0f / fmaxf(sqrtf(s), 1e-10f));
+    if (ra.flags & CLEORA_F_SCALE) s = ra.row_sumsq[row];
+    if ((ra.flags & CLEORA_F_ROWSQ) && lane == 0) ra.row_sumsq[row] = s;
+    const bool scale = ra.flags & (CLEORA_F_L2NORM | CLEORA_F_SCALE);
+    if (scale) inv = (1.0f / fmaxf(sqrtf(s), 1e-10f));
     double ds = 0.0;
     for (uint32_t j0 = 0; j0 < d; j0 += 64) {
         const uint32_t j = j0 + lane;
         if (j < d) {
             float v = yr[j];
-            if (ra.flags & CLEORA_F_L2NORM) v = fmul(v, inv);
+            if (scale) v = fmul(v, inv);
             if (ra.flags & CLEORA_F_SQDIFF) {
                 const double delta = (double)fsub(v, xs[j]);
                 ds += delta * delta;
@@ -504,7 +513,7 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
 
 int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                      float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
-                     double *row_sqdiff, hipStream_t stream) {
+                     double *row_sqdiff, float *row_sumsq, hipStream_t stream) {
     CL_REQUIRE(g != nullptr, "graph handle is NULL");
     CL_REQUIRE(kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC, "unknown markov_type");
     CL_REQUIRE(g->val[kind] != nullptr, "graph has no values for this markov_type");
@@ -517,6 +526,8 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
         CL_REQUIRE(x_self != nullptr, "x_self is required for RESIDUAL / SQDIFF on a row shard");
     }
     if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
+    if (flags & (CLEORA_F_ROWSQ | CLEORA_F_SCALE)) CL_REQUIRE(row_sumsq != nullptr, "row_sumsq is NULL");
+    CL_REQUIRE(!((flags & CLEORA_F_ROWSQ) && (flags & CLEORA_F_SCALE)), "ROWSQ and SCALE are exclusive");
     if (g->n_rows == 0) return CLEORA_OK;
 
     std::lock_guard<std::mutex> lock(g->mu);
@@ -544,6 +555,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
     a.r.x_self = x_self;
     a.r.ldxs = ldx;
     a.r.row_sqdiff = row_sqdiff;
+    a.r.row_sumsq = row_sumsq;
     a.r.rw = rw;
     a.r.alpha = 1.0f - rw;
     a.r.flags = flags;
@@ -564,19 +576,21 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
         const int rc = propagate_panel(g, p, w4, stream);
         if (rc != CLEORA_OK) return rc;
     }
-    if (flags & (CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF))
-        return launch_rowops(y, ldy, g->n_rows, d, y, ldy, flags, rw, x_self, row_sqdiff, stream);
+    if (flags & (CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF | CLEORA_F_ROWSQ | CLEORA_F_SCALE))
+        return launch_rowops(y, ldy, g->n_rows, d, y, ldy, flags, rw, x_self, row_sqdiff, row_sumsq, stream);
     return CLEORA_OK;
 }
 
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
-                  hipStream_t stream) {
+                  float *row_sumsq, hipStream_t stream) {
     CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
     if ((flags & CLEORA_F_RESIDUAL) && !(rw > 0.0f && rw < 1.0f)) flags &= ~CLEORA_F_RESIDUAL;
     if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) CL_REQUIRE(x_self != nullptr, "x_self is NULL");
     if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
+    if (flags & (CLEORA_F_ROWSQ | CLEORA_F_SCALE)) CL_REQUIRE(row_sumsq != nullptr, "row_sumsq is NULL");
+    CL_REQUIRE(!((flags & CLEORA_F_ROWSQ) && (flags & CLEORA_F_SCALE)), "ROWSQ and SCALE are exclusive");
     if (n == 0) return CLEORA_OK;
     RowArgs ra{};
     ra.y = y;
@@ -584,6 +598,7 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
     ra.x_self = x_self;
     ra.ldxs = ldx;
     ra.row_sqdiff = row_sqdiff;
+    ra.row_sumsq = row_sumsq;
     ra.rw = rw;
     ra.alpha = 1.0f - rw;
     ra.flags = flags;

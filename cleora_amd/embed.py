@@ -169,7 +169,7 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
             flags |= _hip.F_RESIDUAL
         for i in range(int(num_iterations)):
             _hip.check(L.cleora_propagate_dev(g.handle, kind, cur.ptr, d, d, nxt.ptr, d, flags,
-                                              float(residual_weight), cur.ptr, None, None))
+                                              float(residual_weight), cur.ptr, None, None, None))
             result = nxt
             if whitener is not None:
                 whitener.whiten(nxt.ptr, d, wht.ptr, d)
@@ -180,7 +180,7 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
             stop = False
             if check and i > 0:                           # :122-125, f64 RMSE vs the previous iterate
                 _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF, 0.0,
-                                               cur.ptr, sq.ptr, None))
+                                               cur.ptr, sq.ptr, None, None))
                 _hip.check(L.cleora_reduce_sum_f64_dev(sq.ptr, n, ws.ptr, tot.ptr, None))
                 _hip.check(L.cleora_stream_sync(None))
                 rmse = float(np.sqrt(tot.to_host()[0] / (float(n) * d)))

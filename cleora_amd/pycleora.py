@@ -131,7 +131,7 @@ class SparseMatrix:
             dx = self._upload("x", x)
             dy = self._buf("y", (n, d))
             _hip.check(_hip.lib().cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, 0, 0.0,
-                                                       None, None, None))
+                                                       None, None, None, None))
             return dy.to_host()
 
     def left_markov_propagate(self, x, num_workers=None):

@@ -48,6 +48,11 @@ extern "C" {
                                  sequential order (last-ulp differences; default is sequential) */
 #define CLEORA_F_RESIDUAL 4u  /* y = (1-rw)*y + rw*x_self before the norm (src/embedding.rs:121-129) */
 #define CLEORA_F_SQDIFF 8u    /* row_sqdiff[r] = sum_j (y[r][j]-x_self[r][j])^2 in f64 (src/embedding.rs:169-176) */
+#define CLEORA_F_ROWSQ 16u    /* OUT: row_sumsq[r] = sum_j y[r][j]^2 (f32, the order of src/embedding.rs:94-97); with
+                                 L2NORM absent the row is left unscaled — used when a row's columns live on
+                                 several GPUs and the sums must be all-reduced before the scale */
+#define CLEORA_F_SCALE 32u    /* IN: row_sumsq[r] is the complete sum of squares; y[r] *= 1/max(sqrt(.),1e-10)
+                                 (src/embedding.rs:98-102) without recomputing it */
 
 typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct SparseMatrix, src/sparse_matrix.rs:56-78) */
 
@@ -115,17 +120,18 @@ int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
  * Rows without edges produce zeros (the reference zero-fills first, :21/:47).
  * x: n_cols x d (ldx); y: n_rows x d (ldy); x_self: the n_rows rows of the previous iterate
  * that correspond to this shard's rows (ld = ldx), needed by RESIDUAL / SQDIFF;
- * row_sqdiff: f64[n_rows] or NULL.  x and y must not alias. */
+ * row_sqdiff: f64[n_rows] or NULL; row_sumsq: f32[n_rows] (ROWSQ out / SCALE in) or NULL.
+ * x and y must not alias. */
 int cleora_propagate_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx,
                          uint32_t d, float *y, uint64_t ldy, uint32_t flags,
                          float residual_weight, const float *x_self, double *row_sqdiff,
-                         void *stream);
+                         float *row_sumsq, void *stream);
 
 /* Row-wise epilogue alone: NdArrayMatrix::l2_normalize_inplace (src/embedding.rs:88-104) when
  * flags = CLEORA_F_L2NORM; same flags as above.  x may equal y (in place). */
 int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                       uint32_t flags, float residual_weight, const float *x_self,
-                      double *row_sqdiff, void *stream);
+                      double *row_sqdiff, float *row_sumsq, void *stream);
 
 /* initialize_deterministically_rust + init_value (src/lib.rs:69-81, 478-488) from the cached
  * XXH64 entity hashes (hash_entity, src/entity.rs:109-114).  Bit-exact (integer arithmetic). */

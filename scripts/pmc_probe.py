@@ -29,11 +29,11 @@ x = torch.empty((n, d), dtype=torch.float32, device=dev)
 y = torch.empty_like(x)
 s = torch.cuda.current_stream().cuda_stream
 _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, s))
-_hip.check(L.cleora_rowops_dev(x.data_ptr(), d, n, d, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, s))
+_hip.check(L.cleora_rowops_dev(x.data_ptr(), d, n, d, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, None, s))
 x, y = y, x
 for _ in range(args.iters):
     _hip.check(L.cleora_propagate_dev(graph.handle, 0, x.data_ptr(), d, d, y.data_ptr(), d,
-                                      _hip.F_L2NORM, 0.0, None, None, s))
+                                      _hip.F_L2NORM, 0.0, None, None, None, s))
     x, y = y, x
 torch.cuda.synchronize()
 info = graph.info()

@@ -48,14 +48,14 @@ def main():
     for flags in (args.flags, args.flags | _hip.F_FASTNORM, 0):
         for _ in range(2):
             _hip.check(L.cleora_propagate_dev(graph.handle, 0, x.data_ptr(), d, d, y.data_ptr(), d,
-                                              flags, 0.0, None, None, stream))
+                                              flags, 0.0, None, None, None, stream))
             x, y = y, x
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
             _hip.check(L.cleora_propagate_dev(graph.handle, 0, x.data_ptr(), d, d, y.data_ptr(), d,
-                                              flags, 0.0, None, None, stream))
+                                              flags, 0.0, None, None, None, stream))
             x, y = y, x
         e1.record()
         torch.cuda.synchronize()
@@ -68,7 +68,7 @@ def main():
     # property: left Markov matrix is row-stochastic => A @ const = const
     ones = torch.full((n, d), 0.25, dtype=torch.float32, device=dev)
     _hip.check(L.cleora_propagate_dev(graph.handle, 0, ones.data_ptr(), d, d, y.data_ptr(), d, 0, 0.0,
-                                      None, None, stream))
+                                      None, None, None, stream))
     torch.cuda.synchronize()
     print("row-stochastic check max|A*c - c| =", float((y - 0.25).abs().max()))
 

@@ -17,7 +17,7 @@ def dev_propagate(g, x, flags=0, kind=0):
     n_rows, d = g.info().n_rows, x.shape[1]
     dx, dy = _hip.DevArray.from_host(x), _hip.DevArray((n_rows, d), np.float32)
     L.cleora_memset(dy.ptr, 0xFF, dy.nbytes, None)
-    _hip.check(L.cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, flags, 0.0, None, None, None))
+    _hip.check(L.cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, flags, 0.0, None, None, None, None))
     _hip.check(L.cleora_stream_sync(None))
     return dy.to_host()
 
@@ -112,7 +112,7 @@ def test_properties_at_baseline_sizes(config):
 
     def prop(gr, x, flags=0, kind=0):
         y = torch.empty_like(x)
-        _hip.check(L.cleora_propagate_dev(gr.handle, kind, x.data_ptr(), d, d, y.data_ptr(), d, flags, 0.0, None, None, s))
+        _hip.check(L.cleora_propagate_dev(gr.handle, kind, x.data_ptr(), d, d, y.data_ptr(), d, flags, 0.0, None, None, None, s))
         return y
 
     # 1. left Markov matrix is row-stochastic: A @ c = c (each row sums to 1 within f32 rounding)

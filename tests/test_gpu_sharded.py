@@ -52,3 +52,49 @@ def test_whitened_loop_on_blocks():
     got = x[:n].cpu().numpy()
     s = np.sign((got * want).sum(axis=0))
     assert np.abs(got * s - want).max() <= 2e-3 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("d,parts", [(256, 2), (256, 8), (64, 4), (24, 2)])
+def test_column_slices_rowsq_then_scale(d, parts):
+    """The two-pass form a column-partitioned rank runs: SpMM + ROWSQ per slice, sum the partial
+    sums of squares (what the all-reduce does), SCALE.  SpMM elements are bit-exact; the norm is a
+    sum of per-slice partials (tolerance)."""
+    dev = torch.device("cuda:0")
+    n = 3000
+    rowptr, col, vl, vs = random_csr(n, 9, seed=21, empty_frac=0.03, hubs=[(5, 1500)])
+    t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
+    be = sharded.HipBackend(dev)
+    x0 = np.random.default_rng(22).standard_normal((n, d)).astype(np.float32)
+    dl = d // parts
+    rw = 0.25
+    graphs = [sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None),
+                                         d, r, parts, be) for r in range(parts)]
+    xs = [torch.from_numpy(np.ascontiguousarray(x0[:, g.c0:g.c0 + dl])).to(dev) for g in graphs]
+    ys = [torch.empty_like(v) for v in xs]
+    sqs = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in graphs]
+    flags = _hip.F_RESIDUAL | _hip.F_ROWSQ
+    for g, xl, yl, sq in zip(graphs, xs, ys, sqs):
+        be.propagate(g.block, 0, xl, yl, flags, rw, xl, None, sq)
+    raw = torch.cat(ys, dim=1).cpu().numpy()
+    y = oracle.spmm(rowptr, col, vl, x0)
+    blended = (np.float32(1.0) - np.float32(rw)) * y + np.float32(rw) * x0
+    hub = np.zeros(n, bool)
+    hub[5] = True
+    np.testing.assert_array_equal(raw[~hub], blended[~hub])             # unnormalised rows: bit-exact
+    total = torch.stack(sqs).sum(0)                                      # the all-reduce
+    np.testing.assert_allclose(total.cpu().numpy(), (blended.astype(np.float64) ** 2).sum(1), rtol=2e-6)
+    sqd = torch.zeros(n, dtype=torch.float64, device=dev)
+    acc = 0.0
+    for g, xl, yl in zip(graphs, xs, ys):
+        be.rowops(yl, yl, _hip.F_SCALE | _hip.F_SQDIFF, 0.0, xl, sqd, total)
+        acc += float(sqd.sum())
+    got = torch.cat(ys, dim=1).cpu().numpy()
+    want = oracle.l2_normalize(blended)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-7)
+    delta = (want - x0).astype(np.float64)
+    assert abs(acc - (delta * delta).sum()) <= 1e-5 * (delta * delta).sum()
+    # world == 1 goes through the fused single-pass kernel and stays bit-exact
+    g1 = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, d, 0, 1, be)
+    x1, _ = sharded.embed_column_sharded(g1, 0, torch.from_numpy(x0).to(dev), 2)
+    want2, _ = oracle.embed(rowptr, col, vl, x0, 2)
+    np.testing.assert_allclose(x1.cpu().numpy(), want2, rtol=0, atol=2e-6)

@@ -33,7 +33,7 @@ def run_dev(g, kind, x, flags=0, rw=0.0, x_self=None, want_sqdiff=False):
     dxs = _hip.DevArray.from_host(x_self) if x_self is not None else None
     dsq = _hip.DevArray((n_rows,), np.float64) if want_sqdiff else None
     _hip.check(L.cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, flags, rw,
-                                      dxs.ptr if dxs else None, dsq.ptr if dsq else None, None))
+                                      dxs.ptr if dxs else None, dsq.ptr if dsq else None, None, None))
     _hip.check(L.cleora_stream_sync(None))
     y = dy.to_host()
     return (y, dsq.to_host()) if want_sqdiff else y

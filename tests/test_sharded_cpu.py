@@ -23,12 +23,24 @@ class OracleBackend:
         return {"rowptr": rowptr.numpy().astype(np.uint64), "col": col.numpy().view(np.uint32),
                 "val": [val_left.numpy(), val_sym.numpy() if val_sym is not None else None]}
 
-    def propagate(self, block, kind, x, y, flags, rw=0.0, x_self=None, row_sqdiff=None):
+    def propagate(self, block, kind, x, y, flags, rw=0.0, x_self=None, row_sqdiff=None, row_sumsq=None):
         out = oracle.spmm(block["rowptr"], block["col"], block["val"][kind], x.numpy())
         if (flags & _hip.F_RESIDUAL) and 0.0 < rw < 1.0:
             out = (np.float32(1.0) - np.float32(rw)) * out + np.float32(rw) * x_self.numpy()
+        if flags & _hip.F_ROWSQ:
+            row_sumsq.copy_(torch.from_numpy((out * out).sum(axis=1, dtype=np.float32)))
         if flags & _hip.F_L2NORM:
             out = oracle.l2_normalize(out)
+        if flags & _hip.F_SQDIFF:
+            delta = (out - x_self.numpy()).astype(np.float64)
+            row_sqdiff.copy_(torch.from_numpy((delta * delta).sum(axis=1)))
+        y.copy_(torch.from_numpy(out))
+
+    def rowops(self, x, y, flags, rw=0.0, x_self=None, row_sqdiff=None, row_sumsq=None):
+        out = x.numpy().copy()
+        if flags & _hip.F_SCALE:
+            norm = np.maximum(np.sqrt(row_sumsq.numpy()), np.float32(1e-10))
+            out = out * (np.float32(1.0) / norm)[:, None]
         if flags & _hip.F_SQDIFF:
             delta = (out - x_self.numpy()).astype(np.float64)
             row_sqdiff.copy_(torch.from_numpy((delta * delta).sum(axis=1)))
@@ -113,3 +125,48 @@ def test_block_size_alignment():
     for n, w, s in ((10, 1, 1), (1001, 2, 3), (9_999_997, 8, 4), (5, 8, 4)):
         b = sharded.block_size(n, w, s)
         assert b % 4 == 0 and b * w * s >= n and (b - 4) * w * s < n or b == 4
+
+
+def _col_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, d = 700, 24
+        rowptr, col, vl, vs = random_csr(n, 7, seed=13, empty_frac=0.05)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.kind == "u" else a)
+        cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
+                                        torch.from_numpy(vs), d, rank, world, OracleBackend())
+        x0 = np.random.default_rng(14).standard_normal((n, d)).astype(np.float32)
+        res = {}
+        for kind, rw, thr in ((0, 0.0, 0.0), (1, 0.4, 0.0), (0, 0.0, 2e-3)):
+            xl, ran = sharded.embed_column_sharded(cg, kind, torch.from_numpy(np.ascontiguousarray(x0[:, cg.c0:cg.c0 + cg.dl])),
+                                                   10, rw, thr)
+            res[(kind, rw, thr)] = (cg.gather_columns(xl).numpy().copy(), ran)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_partition_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_col_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, d = 700, 24
+    rowptr, col, vl, vs = random_csr(n, 7, seed=13, empty_frac=0.05)
+    x0 = np.random.default_rng(14).standard_normal((n, d)).astype(np.float32)
+    for key in got[0][1]:
+        kind, rw, thr = key
+        want, it = oracle.embed(rowptr, col, (vl, vs)[kind], x0, 10, residual_weight=rw, convergence_threshold=thr)
+        for rank, res in got:
+            x, ran = res[key]
+            assert ran == it
+            # the row norm is a sum of per-slice partial sums: last-ulp differences per iteration
+            np.testing.assert_allclose(x, want, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(got[0][1][key][0], got[1][1][key][0])   # replicas identical

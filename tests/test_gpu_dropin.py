@@ -100,3 +100,42 @@ def test_embed_with_initial_embeddings_and_convergence(karate):
     np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
     with pytest.raises(ValueError, match="initial_embeddings has 3 rows"):
         dev_embed.embed(g, 12, 2, initial_embeddings=np.zeros((3, 12), np.float32))
+
+
+def test_config5_flavour_hypergraph_d1024_whitened():
+    """BASELINE config 5 in miniature: `complex::reflexive::product` hyperedges (arity 2..16, Zipf
+    members) through the C++ builder, d = 1024, whitening every iteration, device-resident loop vs
+    the numpy restatement of the reference loop over the oracle SpMM."""
+    rng = np.random.default_rng(55)
+    n_products, n_lines = 6000, 24000
+    zipf = np.minimum(rng.zipf(1.3, size=n_lines * 16) - 1, n_products - 1)
+    lines, pos = [], 0
+    for _ in range(n_lines):
+        k = int(min(16, 2 + rng.poisson(6)))
+        lines.append(" ".join(f"p{v}" for v in zipf[pos:pos + k]))
+        pos += k
+    g = SparseMatrix.from_iterator(iter(lines), "complex::reflexive::product")
+    rows, cols, vals, n, _ = g.to_sparse_csr()
+    rowptr = np.zeros(n + 1, np.uint64)
+    rowptr[1:] = np.cumsum(np.bincount(rows, minlength=n)).astype(np.uint64)
+    d = 1024
+    x0 = g.initialize_deterministically(d, 0)
+    prop = lambda x: oracle.spmm(rowptr, cols, vals, x)
+    # one iteration: the covariance of a propagated random init is well conditioned, so the whole
+    # whitened matrix is determined up to the eigenvector basis -> compare rotation-invariant cosines
+    got = dev_embed.embed(g, d, 1)                                    # whiten=True, l2
+    want, _ = ow.embed_slow(prop, x0, 1, whiten=True)
+    assert got.shape == (n, d) and np.isfinite(got).all()
+    assert np.abs(cosine_matrix(got[:500]) - cosine_matrix(want[:500])).max() < 2e-3
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), np.linalg.norm(want, axis=1), rtol=2e-3)
+    # two iterations: the second covariance has a long tail of f32-noise-level eigenvalues whose
+    # eigenvectors are arbitrary (in the reference too); the leading, well-separated components are
+    # reproducible up to sign
+    got2 = dev_embed.embed(g, d, 2)
+    want2, _ = ow.embed_slow(prop, x0, 2, whiten=True)
+    k = 3
+    sgn = np.sign((got2[:, :k] * want2[:, :k]).sum(axis=0))
+    assert np.abs(got2[:, :k] * sgn - want2[:, :k]).max() <= 5e-3 * np.abs(want2[:, :k]).max()
+    # and the whole output still has identity covariance on the non-clamped directions
+    c = np.cov(got2.astype(np.float64).T)
+    assert np.abs(np.diag(c)[:64] - 1.0).max() < 1e-2

@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once
+    need = [os.path.join(ROOT, "cleora_amd", "libcleora_hip.so"), os.path.join(ROOT, "cleora_amd", "libcleora_host.so")]
+    if not all(os.path.exists(p) for p in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")

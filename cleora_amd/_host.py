@@ -19,6 +19,7 @@ SIGNATURES = {
     "cleora_host_build_from_files": (c_int, [ctypes.POINTER(ctypes.c_char_p), c_u64, ctypes.c_char_p,
                                              c_u32, ctypes.POINTER(vp)]),
     "cleora_host_free": (None, [vp]),
+    "cleora_host_set_threads": (None, [c_u32]),
     "cleora_host_empty": (c_int, [ctypes.POINTER(vp)]),
     "cleora_host_sizes": (c_int, [vp, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
     "cleora_host_copy": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -59,6 +60,12 @@ def xxh64(data: bytes, seed: int = 0) -> int:
 
 def pack_strings(strings):
     """list[str] -> (utf-8 bytes, offsets u64[n+1])."""
+    joined = "".join(strings)
+    if joined.isascii():   # one encode instead of one per string: character counts are byte counts
+        offsets = np.zeros(len(strings) + 1, dtype=np.uint64)
+        if strings:
+            offsets[1:] = np.cumsum(np.fromiter(map(len, strings), dtype=np.uint64, count=len(strings)))
+        return joined.encode("ascii"), offsets
     enc = [s.encode("utf-8") for s in strings]
     offsets = np.zeros(len(enc) + 1, dtype=np.uint64)
     if enc:

@@ -13,6 +13,7 @@
 #include <fstream>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -202,121 +203,199 @@ struct cleora_hostgraph {
 
 namespace {
 
+// ---- the builder ------------------------------------------------------------------------------------
+// Four phases, deterministic for any thread count (the result is always the reference's
+// single-consumer result: every f32 sum is accumulated in input-line order):
+//   A  parallel over line chunks : parse_line + XXH64 of every token        (pipeline.rs:223-240, entity.rs:109-114)
+//   B  sequential, line order    : first-seen interning, Row::occurrence / row_sum, hyperedge_trim_n
+//                                  partitions                              (sparse_matrix_builder.rs:58-70,170-233)
+//   C  parallel over ROW RANGES  : thread t owns rows [lo_t, hi_t) and accumulates E[r, c] for its rows
+//                                  while scanning the hyperedges in order (no locks, no atomics)
+//   D  parallel per row range    : sort by (row, col), Markov normalisation; ranges concatenate into CSR
+struct ParsedLine {
+    uint32_t tok_begin = 0;   // into Parsed::hash / Parsed::span
+    uint32_t na = 0, nb = 0;  // tokens of the descriptor's two node lists (reflexive: the same list, nb == na)
+    uint16_t ncols = 0;       // 0 = skipped line
+    bool reflexive = false;
+};
+
+struct Parsed {
+    std::vector<ParsedLine> lines;
+    std::vector<uint64_t> hash;                        // per token
+    std::vector<std::pair<const char *, uint32_t>> span;  // per token: text
+    std::vector<uint8_t> column;                       // per token: column id
+};
+
 struct Builder {
     std::vector<Column> cols;
     Descriptor desc;
-    uint32_t trim_n;
-    Interner interner;
-    std::vector<std::string> ids;
-    std::vector<uint64_t> hashes;
-    std::vector<uint8_t> column_ids;
-    std::vector<uint32_t> occurrence;  // Row::occurrence
-    std::vector<float> row_sum;        // Row::row_sum
-    EdgeTable edges;
-    std::vector<uint32_t> nodes, a, b;  // scratch
+    uint32_t trim_n = 16;
+    unsigned threads = 1;
 
-    uint32_t intern(std::string_view tok, uint8_t column) {
-        const uint64_t h = xxh64(reinterpret_cast<const uint8_t *>(tok.data()), tok.size(), 0);
-        bool added;
-        const uint32_t ix = interner.find_or_add(h, added);
-        if (added) {
-            ids.emplace_back(tok); hashes.push_back(h); column_ids.push_back(column);
-            occurrence.push_back(0); row_sum.push_back(0.f);
-        }
-        return ix;
-    }
-
-    // get_high_low_nodes (sparse_matrix_builder.rs:195-208): keep the trim_n nodes with the highest
-    // occurrence first.  The reference's select_nth_unstable leaves the order of ties to pdqselect;
-    // here ties keep their position in the line (documented divergence).
-    size_t high_first(std::vector<uint32_t> &v) {
-        if (v.size() <= trim_n) return v.size();
-        std::stable_sort(v.begin(), v.end(), [&](uint32_t x, uint32_t y) { return occurrence[x] > occurrence[y]; });
-        return trim_n;
-    }
-
-    void line(std::string_view raw) {
-        // parse_line (src/pipeline.rs:223-240)
+    // phase A: one line -> tokens of column a then column b (or the single reflexive column)
+    void parse(std::string_view raw, Parsed &out) const {
+        ParsedLine pl;
+        pl.tok_begin = (uint32_t)out.hash.size();
         std::string_view t = trim(raw);
         std::vector<std::string_view> columns;
         bool comma = false;
         if (t.find('\t') != std::string_view::npos) columns = split(t, "\t");
         else if (t.find(',') != std::string_view::npos) { columns = split(t, ","); comma = true; }
         else columns.push_back(t);
-        if (columns.size() != cols.size()) return;  // wrong width: skipped (pipeline.rs:60-79)
-        // process_row_and_get_edges (src/entity.rs:67-106)
-        nodes.clear();
-        uint32_t slice[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        uint32_t offset = 0, refl = 0;
+        if (columns.size() != cols.size()) { out.lines.push_back(pl); return; }  // skipped (pipeline.rs:60-79)
         for (size_t i = 0; i < columns.size(); ++i) {
             std::string_view c = comma ? trim(columns[i]) : columns[i];
             auto toks = split(c, " ");
-            if (cols[i].complex) {
-                for (auto tk : toks) nodes.push_back(intern(tk, (uint8_t)i));
-                const uint32_t len = (uint32_t)toks.size();
-                if (i < 2) { slice[i][0] = offset; slice[i][1] = offset + len; }
-                if (cols[i].reflexive) {
-                    const size_t rid = cols.size() + refl++;
-                    if (rid < 4) { slice[rid][0] = offset; slice[rid][1] = offset + len; }
-                }
-                offset += len;
-            } else {
-                nodes.push_back(intern(toks[0], (uint8_t)i));
-                if (i < 2) { slice[i][0] = offset; slice[i][1] = offset + 1; }
-                offset += 1;
+            size_t take = cols[i].complex ? toks.size() : 1;   // non-complex: first token only (entity.rs:94)
+            for (size_t k = 0; k < take; ++k) {
+                out.hash.push_back(xxh64(reinterpret_cast<const uint8_t *>(toks[k].data()), toks[k].size(), 0));
+                out.span.emplace_back(toks[k].data(), (uint32_t)toks[k].size());
+                out.column.push_back((uint8_t)i);
             }
+            if (i == 0) pl.na = (uint32_t)take; else pl.nb = (uint32_t)take;
         }
-        // handle_hyperedge (src/sparse_matrix_builder.rs:170-193)
-        a.assign(nodes.begin() + slice[desc.a_id][0], nodes.begin() + slice[desc.a_id][1]);
-        b.assign(nodes.begin() + slice[desc.b_id][0], nodes.begin() + slice[desc.b_id][1]);
-        const uint32_t na = (uint32_t)a.size(), nb = (uint32_t)b.size();
-        for (uint32_t x : a) { occurrence[x] += nb; row_sum[x] += 1.0f / (float)nb; }
-        for (uint32_t x : b) { occurrence[x] += na; row_sum[x] += 1.0f / (float)na; }
-        const float value = 1.0f / (float)(na * nb);
-        const size_t ah = high_first(a), bh = high_first(b);
-        auto combos = [&](size_t a0, size_t a1, size_t b0, size_t b1) {
-            for (size_t i = a0; i < a1; ++i)
-                for (size_t j = b0; j < b1; ++j) { edges.add(a[i], b[j], value); edges.add(b[j], a[i], value); }
-        };
-        combos(0, ah, 0, bh);            // high x high
-        combos(0, ah, bh, b.size());     // high x low
-        combos(ah, a.size(), 0, bh);     // low  x high      (low x low is dropped)
+        pl.ncols = (uint16_t)cols.size();
+        pl.reflexive = cols.size() == 1;
+        if (pl.reflexive) pl.nb = pl.na;
+        out.lines.push_back(pl);
     }
 
-    cleora_hostgraph *finish() {
+    cleora_hostgraph *build(const std::vector<std::string_view> &lines) {
+        const size_t nl = lines.size();
+        unsigned T = threads ? threads : 1;
+        if (nl < 20000) T = 1;
+        // ---- A ----
+        std::vector<Parsed> chunks(T);
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T; ++t)
+                pool.emplace_back([&, t] {
+                    const size_t lo = nl * t / T, hi = nl * (t + 1) / T;
+                    chunks[t].lines.reserve(hi - lo);
+                    for (size_t i = lo; i < hi; ++i) parse(lines[i], chunks[t]);
+                });
+            for (auto &th : pool) th.join();
+        }
+        // ---- B ----
+        Interner interner;
         auto *g = new cleora_hostgraph();
         g->desc = desc;
-        g->ids = std::move(ids);
-        g->hashes = std::move(hashes);
-        g->column_ids = std::move(column_ids);
-        g->row_sum = row_sum;
+        std::vector<uint32_t> occurrence;
+        std::vector<float> &row_sum = g->row_sum;
+        // hyperedges in line order: node indices of list a then list b (after the trim reorder),
+        // with the number of "high" nodes of each list
+        struct Hyper { uint64_t begin; uint32_t na, nb, ah, bh; float value; };
+        std::vector<Hyper> hypers;
+        std::vector<uint32_t> nodes;
+        hypers.reserve(nl);
+        auto high_first = [&](uint32_t *v, size_t n) -> size_t {
+            // get_high_low_nodes (sparse_matrix_builder.rs:195-208); ties keep line order (documented)
+            if (n <= trim_n) return n;
+            std::stable_sort(v, v + n, [&](uint32_t x, uint32_t y) { return occurrence[x] > occurrence[y]; });
+            return trim_n;
+        };
+        for (unsigned t = 0; t < T; ++t) {
+            const Parsed &P = chunks[t];
+            for (const ParsedLine &pl : P.lines) {
+                if (!pl.ncols) continue;
+                const uint32_t ntok = pl.reflexive ? pl.na : pl.na + pl.nb;
+                const uint64_t begin = nodes.size();
+                for (uint32_t k = 0; k < ntok; ++k) {
+                    bool added;
+                    const uint64_t h = P.hash[pl.tok_begin + k];
+                    const uint32_t ix = interner.find_or_add(h, added);
+                    if (added) {
+                        g->ids.emplace_back(P.span[pl.tok_begin + k].first, P.span[pl.tok_begin + k].second);
+                        g->hashes.push_back(h);
+                        g->column_ids.push_back(P.column[pl.tok_begin + k]);
+                        occurrence.push_back(0);
+                        row_sum.push_back(0.f);
+                    }
+                    nodes.push_back(ix);
+                }
+                if (pl.reflexive)
+                    for (uint32_t k = 0; k < pl.na; ++k) { const uint32_t v = nodes[begin + k]; nodes.push_back(v); }
+                uint32_t *a = nodes.data() + begin, *b = a + pl.na;
+                const uint32_t na = pl.na, nb = pl.nb;
+                for (uint32_t k = 0; k < na; ++k) { occurrence[a[k]] += nb; row_sum[a[k]] += 1.0f / (float)nb; }
+                for (uint32_t k = 0; k < nb; ++k) { occurrence[b[k]] += na; row_sum[b[k]] += 1.0f / (float)na; }
+                Hyper h;
+                h.begin = begin; h.na = na; h.nb = nb;
+                h.value = 1.0f / (float)(na * nb);
+                h.ah = (uint32_t)high_first(a, na);
+                h.bh = (uint32_t)high_first(b, nb);
+                hypers.push_back(h);
+            }
+            chunks[t] = Parsed();  // release
+        }
         const size_t n = g->ids.size();
-        // reduce (src/sparse_matrix_builder.rs:275-343): sort by (row, col), slices, normalise
-        std::vector<std::pair<uint64_t, float>> ent;
-        ent.reserve(edges.count);
-        for (size_t i = 0; i < edges.keys.size(); ++i)
-            if (edges.keys[i] != EdgeTable::EMPTY) ent.emplace_back(edges.keys[i], edges.vals[i]);
-        std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
+        // ---- C + D ----
+        unsigned T2 = (hypers.size() < 20000 || n < 1024) ? 1 : T;
+        struct Part { std::vector<std::pair<uint64_t, float>> ent; };
+        std::vector<Part> parts(T2);
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T2; ++t)
+                pool.emplace_back([&, t] {
+                    const uint32_t lo = (uint32_t)(n * t / T2), hi = (uint32_t)(n * (t + 1) / T2);
+                    EdgeTable edges;
+                    auto add = [&](uint32_t r, uint32_t c, float v) { if (r >= lo && r < hi) edges.add(r, c, v); };
+                    for (const Hyper &h : hypers) {
+                        const uint32_t *a = nodes.data() + h.begin, *b = a + h.na;
+                        auto combos = [&](size_t a0, size_t a1, size_t b0, size_t b1) {
+                            for (size_t i = a0; i < a1; ++i)
+                                for (size_t j = b0; j < b1; ++j) { add(a[i], b[j], h.value); add(b[j], a[i], h.value); }
+                        };
+                        combos(0, h.ah, 0, h.bh);        // high x high
+                        combos(0, h.ah, h.bh, h.nb);     // high x low
+                        combos(h.ah, h.na, 0, h.bh);     // low  x high   (low x low dropped)
+                    }
+                    auto &ent = parts[t].ent;
+                    ent.reserve(edges.count);
+                    for (size_t i = 0; i < edges.keys.size(); ++i)
+                        if (edges.keys[i] != EdgeTable::EMPTY) ent.emplace_back(edges.keys[i], edges.vals[i]);
+                    std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
+                });
+            for (auto &th : pool) th.join();
+        }
+        // reduce (sparse_matrix_builder.rs:275-343): rows ascending = parts in order
+        size_t nnz = 0;
+        std::vector<size_t> base(T2 + 1, 0);
+        for (unsigned t = 0; t < T2; ++t) { base[t] = nnz; nnz += parts[t].ent.size(); }
+        base[T2] = nnz;
         g->rowptr.assign(n + 1, 0);
-        g->col.resize(ent.size()); g->val_left.resize(ent.size()); g->val_sym.resize(ent.size());
-        for (size_t k = 0; k < ent.size(); ++k) {
-            const uint32_t r = (uint32_t)(ent[k].first >> 32), c = (uint32_t)ent[k].first;
-            g->rowptr[r + 1]++;
-            g->col[k] = c;
-            const float v = ent[k].second, rs = row_sum[r], cs = row_sum[c];
-            g->val_left[k] = v / rs;
-            g->val_sym[k] = v / std::sqrt(rs * cs);
+        g->col.resize(nnz); g->val_left.resize(nnz); g->val_sym.resize(nnz);
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < T2; ++t)
+                pool.emplace_back([&, t] {
+                    const auto &ent = parts[t].ent;
+                    for (size_t k = 0; k < ent.size(); ++k) {
+                        const uint32_t r = (uint32_t)(ent[k].first >> 32), c = (uint32_t)ent[k].first;
+                        g->rowptr[r + 1]++;   // rows of different parts are disjoint
+                        const size_t o = base[t] + k;
+                        g->col[o] = c;
+                        const float v = ent[k].second, rs = row_sum[r], cs = row_sum[c];
+                        g->val_left[o] = v / rs;
+                        g->val_sym[o] = v / std::sqrt(rs * cs);
+                    }
+                });
+            for (auto &th : pool) th.join();
         }
         for (size_t r = 0; r < n; ++r) g->rowptr[r + 1] += g->rowptr[r];
         return g;
     }
 };
 
+unsigned g_threads = 0;  // 0 = hardware concurrency
+
 bool make_builder(Builder &b, const char *columns, uint32_t trim_n) {
     if (!columns) { g_err = "columns is NULL"; return false; }
     if (!parse_fields(columns, b.cols)) return false;
     if (!relation(b.cols, b.desc)) return false;
     b.trim_n = trim_n;
+    unsigned hw = std::thread::hardware_concurrency();
+    b.threads = g_threads ? g_threads : (hw ? (hw > 64 ? 64 : hw) : 1);
     return true;
 }
 
@@ -347,9 +426,9 @@ int cleora_host_build_from_lines(const char *data, const uint64_t *offsets, uint
     if (!out || (n_lines && (!data || !offsets))) { g_err = "NULL argument"; return -1; }
     Builder b;
     if (!make_builder(b, columns, trim_n)) return -1;
-    for (uint64_t i = 0; i < n_lines; ++i)
-        b.line(std::string_view(data + offsets[i], offsets[i + 1] - offsets[i]));
-    *out = b.finish();
+    std::vector<std::string_view> lines(n_lines);
+    for (uint64_t i = 0; i < n_lines; ++i) lines[i] = std::string_view(data + offsets[i], offsets[i + 1] - offsets[i]);
+    *out = b.build(lines);
     return 0;
 }
 
@@ -358,18 +437,30 @@ int cleora_host_build_from_files(const char *const *paths, uint64_t n_paths, con
     if (!out || !paths) { g_err = "NULL argument"; return -1; }
     Builder b;
     if (!make_builder(b, columns, trim_n)) return -1;
-    std::string ln;
+    std::vector<std::string> blobs;
+    std::vector<std::string_view> lines;
+    blobs.reserve(n_paths);
     for (uint64_t i = 0; i < n_paths; ++i) {
         std::ifstream f(paths[i], std::ios::binary);
         if (!f) continue;  // read_file logs and skips (src/pipeline.rs:193-199)
-        while (std::getline(f, ln)) {
-            if (!ln.empty() && ln.back() == '\r') ln.pop_back();  // BufRead::lines strips "\r\n"
-            if (!ln.empty()) b.line(ln);
+        blobs.emplace_back((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        const std::string &blob = blobs.back();
+        size_t pos = 0;
+        while (pos < blob.size()) {
+            size_t q = blob.find('\n', pos);
+            if (q == std::string::npos) q = blob.size();
+            size_t e = q;
+            if (e > pos && blob[e - 1] == '\r') --e;  // BufRead::lines strips "\r\n"
+            if (e > pos) lines.emplace_back(blob.data() + pos, e - pos);  // empty lines skipped (:205)
+            pos = q + 1;
         }
     }
-    *out = b.finish();
+    *out = b.build(lines);
     return 0;
 }
+
+/* 0 = one worker per hardware thread (capped at 64).  The result does not depend on it. */
+void cleora_host_set_threads(uint32_t n) { g_threads = n; }
 
 void cleora_host_free(cleora_hostgraph *g) { delete g; }
 

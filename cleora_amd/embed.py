@@ -151,46 +151,77 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
         return x0
 
     with graph._lock:
-        g = graph._graph()
-        cur = _hip.DevArray.from_host(x0)
-        nxt = _hip.DevArray((n, d), np.float32)
-        wht = _hip.DevArray((n, d), np.float32) if whiten else None
-        whitener = DeviceWhitener(n, d) if (whiten and n > 1) else None
-        check = convergence_threshold > 0
-        sq = _hip.DevArray((n,), np.float64) if check else None
-        ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None
-        tot = _hip.DevArray((1,), np.float64) if check else None
-        flags = (_hip.F_L2NORM if normalization == "l2" else 0)
-        # the reference's slow path blends for any rw > 0 (:114); the kernel gates on 0 < rw < 1
-        # like the Rust loop (src/embedding.rs:116).  rw >= 1 is rejected rather than guessed.
-        if residual_weight >= 1.0:
-            raise ValueError("residual_weight must be < 1 on the device path")
-        if residual_weight > 0:
-            flags |= _hip.F_RESIDUAL
-        for i in range(int(num_iterations)):
-            _hip.check(L.cleora_propagate_dev(g.handle, kind, cur.ptr, d, d, nxt.ptr, d, flags,
-                                              float(residual_weight), cur.ptr, None, None, None))
-            result = nxt
-            if whitener is not None:
-                whitener.whiten(nxt.ptr, d, wht.ptr, d)
-                result = wht
-            if callback is not None:
-                _hip.check(L.cleora_stream_sync(None))
-                callback(i, result.to_host())
-            stop = False
-            if check and i > 0:                           # :122-125, f64 RMSE vs the previous iterate
-                _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF, 0.0,
-                                               cur.ptr, sq.ptr, None, None))
-                _hip.check(L.cleora_reduce_sum_f64_dev(sq.ptr, n, ws.ptr, tot.ptr, None))
-                _hip.check(L.cleora_stream_sync(None))
-                rmse = float(np.sqrt(tot.to_host()[0] / (float(n) * d)))
-                stop = rmse < convergence_threshold
-            # rotate buffers: `result` becomes the current iterate
-            if result is wht:
-                cur, wht = wht, cur
-            else:
-                cur, nxt = nxt, cur
-            if stop:
-                break
-        _hip.check(L.cleora_stream_sync(None))
-        return cur.to_host()
+        return _device_loop(graph._graph(), n, x0, kind, int(num_iterations), normalization, callback,
+                            float(residual_weight), float(convergence_threshold), whiten)
+
+
+def embed_csr(rowptr, col, val, initial_embeddings, num_iterations=DEFAULT_NUM_ITERATIONS,
+              normalization="l2", callback=None, residual_weight=0.0, convergence_threshold=0.0,
+              whiten=True, device=0):
+    """The same device-resident loop over a USER-SUPPLIED CSR adjacency: the
+    reference's embed_weighted / embed_directed / embed_edge_features / attention variants
+    (pycleora/__init__.py:206-410, 784-852) each build a scipy CSR and then run exactly
+    `adj @ X` + `_postprocess_iteration` per iteration — this is that loop on the MI355X for any
+    adjacency they construct.  rowptr[n+1], col[nnz], val[nnz]; initial_embeddings n x d."""
+    x0 = np.ascontiguousarray(np.asarray(initial_embeddings).astype(np.float32))
+    n = int(np.asarray(rowptr).shape[0]) - 1
+    if x0.ndim != 2 or x0.shape[0] != n:
+        raise ValueError(f"initial_embeddings has shape {x0.shape} but the adjacency has {n} rows")
+    if normalization not in ("l2", "none"):
+        raise ValueError("normalization must be 'l2' or 'none' on the device path")
+    if n == 0 or x0.shape[1] == 0 or num_iterations <= 0:
+        return x0
+    g = _hip.Graph.from_host(rowptr, col, val, None, n_cols=n, device=device)
+    try:
+        return _device_loop(g, n, x0, _hip.LEFT, int(num_iterations), normalization, callback,
+                            float(residual_weight), float(convergence_threshold), whiten)
+    finally:
+        g.close()
+
+
+def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residual_weight,
+                 convergence_threshold, whiten):
+    L = _hip.lib()
+    d = x0.shape[1]
+    cur = _hip.DevArray.from_host(x0)
+    nxt = _hip.DevArray((n, d), np.float32)
+    wht = _hip.DevArray((n, d), np.float32) if whiten else None
+    whitener = DeviceWhitener(n, d) if (whiten and n > 1) else None
+    check = convergence_threshold > 0
+    sq = _hip.DevArray((n,), np.float64) if check else None
+    ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None
+    tot = _hip.DevArray((1,), np.float64) if check else None
+    flags = (_hip.F_L2NORM if normalization == "l2" else 0)
+    # the reference's slow path blends for any rw > 0 (:114); the kernel gates on 0 < rw < 1
+    # like the Rust loop (src/embedding.rs:116).  rw >= 1 is rejected rather than guessed.
+    if residual_weight >= 1.0:
+        raise ValueError("residual_weight must be < 1 on the device path")
+    if residual_weight > 0:
+        flags |= _hip.F_RESIDUAL
+    for i in range(int(num_iterations)):
+        _hip.check(L.cleora_propagate_dev(g.handle, kind, cur.ptr, d, d, nxt.ptr, d, flags,
+                                          float(residual_weight), cur.ptr, None, None, None))
+        result = nxt
+        if whitener is not None:
+            whitener.whiten(nxt.ptr, d, wht.ptr, d)
+            result = wht
+        if callback is not None:
+            _hip.check(L.cleora_stream_sync(None))
+            callback(i, result.to_host())
+        stop = False
+        if check and i > 0:                           # :122-125, f64 RMSE vs the previous iterate
+            _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF, 0.0,
+                                           cur.ptr, sq.ptr, None, None))
+            _hip.check(L.cleora_reduce_sum_f64_dev(sq.ptr, n, ws.ptr, tot.ptr, None))
+            _hip.check(L.cleora_stream_sync(None))
+            rmse = float(np.sqrt(tot.to_host()[0] / (float(n) * d)))
+            stop = rmse < convergence_threshold
+        # rotate buffers: `result` becomes the current iterate
+        if result is wht:
+            cur, wht = wht, cur
+        else:
+            cur, nxt = nxt, cur
+        if stop:
+            break
+    _hip.check(L.cleora_stream_sync(None))
+    return cur.to_host()

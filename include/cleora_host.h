@@ -44,6 +44,8 @@ int cleora_host_build_from_lines(const char *data, const uint64_t *offsets, uint
 int cleora_host_build_from_files(const char *const *paths, uint64_t n_paths, const char *columns,
                                  uint32_t hyperedge_trim_n, cleora_hostgraph **out);
 void cleora_host_free(cleora_hostgraph *g);
+/* Worker threads of the builder (0 = hardware threads, max 64).  The graph is identical for any value. */
+void cleora_host_set_threads(uint32_t n);
 
 /* n = entities, nnz = stored (directed) edges, ids_bytes = total UTF-8 bytes of all entity ids. */
 int cleora_host_sizes(const cleora_hostgraph *g, uint64_t *n, uint64_t *nnz, uint64_t *ids_bytes);

@@ -83,6 +83,14 @@ def parse_line(line: str):
     return [t.split(" ")]
 
 
+def edges_iter(hashes, slices, col_a, col_b):
+    """Hyperedge::edges_iter (src/entity.rs:31-41): cartesian product of the two column slices,
+    first column major — the order in which handle_combinations visits pairs."""
+    a = hashes[slices[col_a][0]:slices[col_a][1]]
+    b = hashes[slices[col_b][0]:slices[col_b][1]]
+    return [(x, y) for x in a for y in b]
+
+
 class RefGraph:
     """Result of the build: the same fields as struct SparseMatrix
     (src/sparse_matrix.rs:56-78) in SoA/CSR form."""

@@ -139,3 +139,22 @@ def test_config5_flavour_hypergraph_d1024_whitened():
     # and the whole output still has identity covariance on the non-clamped directions
     c = np.cov(got2.astype(np.float64).T)
     assert np.abs(np.diag(c)[:64] - 1.0).max() < 1e-2
+
+
+def test_embed_csr_user_adjacency():
+    """N3: the device loop over a user-supplied CSR (what embed_weighted / embed_directed build with
+    scipy): directed, weighted, not row-normalised."""
+    from tests.graphs import random_csr
+    n, d = 1500, 48
+    rowptr, col, _, _ = random_csr(n, 7, seed=77, empty_frac=0.05)
+    val = np.random.default_rng(78).random(col.shape[0], dtype=np.float32) * 3.0
+    x0 = np.random.default_rng(79).standard_normal((n, d)).astype(np.float32)
+    got = dev_embed.embed_csr(rowptr, col, val, x0, 5, whiten=False)
+    want, _ = ow.embed_slow(lambda x: oracle.spmm(rowptr, col, val, x), x0, 5, whiten=False)
+    np.testing.assert_allclose(got, want, rtol=0, atol=3e-6)
+    gotw = dev_embed.embed_csr(rowptr, col, val, x0, 2, whiten=True)
+    wantw, _ = ow.embed_slow(lambda x: oracle.spmm(rowptr, col, val, x), x0, 2, whiten=True)
+    s = np.sign((gotw * wantw).sum(axis=0))
+    assert np.abs(gotw * s - wantw).max() <= 2e-3 * np.abs(wantw).max()
+    with pytest.raises(ValueError, match="initial_embeddings has shape"):
+        dev_embed.embed_csr(rowptr, col, val, x0[:10], 2)

@@ -42,6 +42,12 @@ def test_insta_snapshots(snaps, name, kind, sym):
     assert (delta == 0).sum() >= 3198, f"{name}: only {(delta == 0).sum()}/3200 exact"
 
 
+def test_cartesian_product_order_unit_test():
+    """The reference's only unit test in src/ (src/entity.rs:122-139), replayed on the oracle."""
+    combos = refgraph.edges_iter([10, 20, 30, 40, 50], {0: (0, 2), 1: (2, 5)}, 0, 1)
+    assert combos == [(10, 30), (10, 40), (10, 50), (20, 30), (20, 40), (20, 50)]
+
+
 def test_stdrng_first_words():
     # self-consistency: two generators agree and the stream is not degenerate
     a, b = stdrng.StdRng(2137), stdrng.StdRng(2137)

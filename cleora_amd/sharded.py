@@ -171,12 +171,19 @@ class ShardedGraph:
         kdim = d if n_components is None else min(int(n_components), d)
         transform = torch.empty((d, kdim), dtype=torch.float32, device=y.device)
         if self.rank == 0:
-            cov = gram.cpu().numpy() * (1.0 / (self.n - 1))
-            from .embed import eigh_descending
-            w, v = eigh_descending(cov, "auto" if y.is_cuda else "host")
-            w, v = w[:kdim], v[:, :kdim]
-            scale = 1.0 / np.sqrt(np.maximum(w, 1e-10))
-            transform.copy_(torch.from_numpy(np.ascontiguousarray((v * scale).astype(np.float32))))
+            if y.is_cuda:
+                # eigh on the device (rocSOLVER through torch): no D2H of the covariance and no host
+                # BLAS thread pool inside the loop (see embed.eigh_descending)
+                w, v = torch.linalg.eigh(gram * (1.0 / (self.n - 1)))
+                w, v = torch.flip(w, [0])[:kdim], torch.flip(v, [1])[:, :kdim]   # descending (:147-149)
+                scale = 1.0 / torch.sqrt(torch.clamp(w, min=1e-10))                 # :155
+                transform.copy_((v * scale).to(torch.float32))
+            else:
+                cov = gram.numpy() * (1.0 / (self.n - 1))
+                w, v = np.linalg.eigh(cov)
+                idx = np.argsort(w)[::-1][:kdim]
+                scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))
+                transform.copy_(torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32))))
         if self.world > 1:
             dist.broadcast(transform, src=0, group=self.group)
         mean32 = mean.to(torch.float32)

@@ -267,6 +267,9 @@ class ColumnShardedGraph:
         self.block = backend.make_block(rowptr.to(torch.int64), col, val_left, val_sym, n,
                                         hub_threshold, hub_segment)
         self.nnz = int(col.numel())
+        # row chunks used when the whitening step switches to a row layout (equal splits, padded)
+        self.rows_per = -(-n // world)
+        self.n_pad = self.rows_per * world
 
     def propagate(self, kind, x, x_next, rowsq, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None):
         """x, x_next: (n, d/P) column slices; rowsq: f32[n] scratch.  One iteration."""
@@ -282,6 +285,50 @@ class ColumnShardedGraph:
         if second:
             self.backend.rowops(x_next, x_next, second, 0.0, x if (flags & _hip.F_SQDIFF) else None,
                                 row_sqdiff, rowsq if norm else None)
+
+    def whiten(self, y_local, out_local):
+        """whiten_embeddings (pycleora/__init__.py:130-164) for a column-partitioned matrix.
+        The Gram matrix couples every pair of columns, so the step runs in a ROW layout:
+        all-to-all (each rank receives all d columns of its n/P rows: (P-1)/P^2 of the matrix
+        per rank, 8x less than an all-gather at P = 8) -> row-local f64 column sums / centred Gram,
+        all-reduced (d and d*d doubles) -> eigh on the device, replicated -> row-local projection ->
+        all-to-all back to columns.  y_local, out_local: (n_pad, d/P), rows >= n zero."""
+        P, rp, dl, d = self.world, self.rows_per, self.dl, self.d
+        if P > 1:
+            recv = torch.empty((P, rp, dl), dtype=y_local.dtype, device=y_local.device)
+            dist.all_to_all_single(recv.view(-1), y_local[: self.n_pad].reshape(-1), group=self.group)
+            rows = recv.permute(1, 0, 2).reshape(rp, d).contiguous()      # my rows, all columns
+        else:
+            rows = y_local[: self.n_pad]
+        nv = max(0, min(rp, self.n - self.rank * rp))
+        cs = self.backend.colsum(rows[:nv]) if nv else torch.zeros(d, dtype=torch.float64, device=rows.device)
+        if P > 1:
+            dist.all_reduce(cs, group=self.group)
+        mean = cs / float(self.n)
+        gram = self.backend.gram(rows[:nv], mean) if nv else torch.zeros((d, d), dtype=torch.float64, device=rows.device)
+        if P > 1:
+            dist.all_reduce(gram, group=self.group)
+        # every rank holds the same all-reduced Gram: eigh is replicated (deterministic routine),
+        # but the transform is still broadcast from rank 0 so the ranks cannot drift apart
+        cov = gram * (1.0 / (self.n - 1))
+        if cov.is_cuda:
+            w, v = torch.linalg.eigh(cov)
+        else:
+            import numpy as np
+            wn, vn = np.linalg.eigh(cov.numpy())
+            w, v = torch.from_numpy(wn), torch.from_numpy(vn)
+        w, v = torch.flip(w, [0]), torch.flip(v, [1])
+        transform = (v * (1.0 / torch.sqrt(torch.clamp(w, min=1e-10)))).to(torch.float32).contiguous()
+        if P > 1:
+            dist.broadcast(transform, src=0, group=self.group)
+        proj = torch.zeros((rp, d), dtype=torch.float32, device=rows.device)
+        if nv:
+            self.backend.project(rows[:nv], mean.to(torch.float32), transform, proj[:nv])
+        if P > 1:
+            send = proj.view(rp, P, dl).permute(1, 0, 2).contiguous()       # column block j -> rank j
+            dist.all_to_all_single(out_local[: self.n_pad].view(-1), send.view(-1), group=self.group)
+        else:
+            out_local[: self.n_pad].copy_(proj)
 
     def gather_columns(self, x_local):
         """(n, d) on every rank from the (n, d/P) slices (not part of the iteration)."""
@@ -299,12 +346,23 @@ class ColumnShardedGraph:
 
 
 def embed_column_sharded(cg, kind, x0_local, iterations, residual_weight=0.0,
-                         convergence_threshold=0.0, flags=_hip.F_L2NORM):
-    """embed_full / embed_full_with_convergence over a ColumnShardedGraph.
-    x0_local: this rank's (n, d/P) columns of the initial matrix.  Returns (x_local, iterations_run)."""
+                         convergence_threshold=0.0, flags=_hip.F_L2NORM, whiten=False):
+    """embed_full / embed_full_with_convergence over a ColumnShardedGraph; whiten=True runs the
+    default embed() loop (normalise, then whiten, every iteration) and needs x0_local padded to
+    cg.n_pad rows.  x0_local: this rank's (n or n_pad, d/P) columns of the initial matrix.
+    Returns (x_local, iterations_run)."""
     x = x0_local
     x_next = torch.zeros_like(x0_local)
     rowsq = torch.zeros(cg.n, dtype=torch.float32, device=x.device)
+    if whiten:
+        if x0_local.shape[0] < cg.n_pad:
+            raise ValueError(f"whiten=True needs {cg.n_pad} (padded) rows, got {x0_local.shape[0]}")
+        y = torch.zeros_like(x0_local)
+        for _ in range(iterations):
+            cg.propagate(kind, x[: cg.n], y[: cg.n], rowsq, flags | _hip.F_RESIDUAL, residual_weight)
+            cg.whiten(y, x_next)
+            x, x_next = x_next, x
+        return x, iterations
     check = convergence_threshold > 0
     flags = flags | _hip.F_RESIDUAL
     sq = torch.zeros(cg.n, dtype=torch.float64, device=x.device) if check else None

@@ -98,3 +98,22 @@ def test_column_slices_rowsq_then_scale(d, parts):
     x1, _ = sharded.embed_column_sharded(g1, 0, torch.from_numpy(x0).to(dev), 2)
     want2, _ = oracle.embed(rowptr, col, vl, x0, 2)
     np.testing.assert_allclose(x1.cpu().numpy(), want2, rtol=0, atol=2e-6)
+
+
+def test_column_layout_whitened_loop_single_rank():
+    """ColumnShardedGraph.whiten on the HIP backend (world 1: the row-layout switch is the identity;
+    the all-to-all path itself is covered under gloo in tests/test_sharded_cpu.py)."""
+    dev = torch.device("cuda:0")
+    n, d = 2501, 32
+    rowptr, col, vl, vs = random_csr(n, 8, seed=31)
+    t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
+    cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, d, 0, 1,
+                                    sharded.HipBackend(dev))
+    x0 = np.random.default_rng(32).standard_normal((n, d)).astype(np.float32)
+    xp = np.zeros((cg.n_pad, d), np.float32)
+    xp[:n] = x0
+    x, _ = sharded.embed_column_sharded(cg, 0, torch.from_numpy(xp).to(dev), 3, whiten=True)
+    want, _ = ow.embed_slow(lambda v: oracle.spmm(rowptr, col, vl, v), x0, 3, whiten=True)
+    got = x[:n].cpu().numpy()
+    s = np.sign((got * want).sum(axis=0))
+    assert np.abs(got * s - want).max() <= 2e-3 * np.abs(want).max()

@@ -142,6 +142,10 @@ def _col_worker(rank, world, port, q):
             xl, ran = sharded.embed_column_sharded(cg, kind, torch.from_numpy(np.ascontiguousarray(x0[:, cg.c0:cg.c0 + cg.dl])),
                                                    10, rw, thr)
             res[(kind, rw, thr)] = (cg.gather_columns(xl).numpy().copy(), ran)
+        xp = np.zeros((cg.n_pad, cg.dl), np.float32)
+        xp[:n] = x0[:, cg.c0:cg.c0 + cg.dl]
+        xw, _ = sharded.embed_column_sharded(cg, 0, torch.from_numpy(xp), 3, whiten=True)
+        res["whiten"] = cg.gather_columns(xw)[:n].numpy().copy()
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -161,6 +165,12 @@ def test_column_partition_world2():
     n, d = 700, 24
     rowptr, col, vl, vs = random_csr(n, 7, seed=13, empty_frac=0.05)
     x0 = np.random.default_rng(14).standard_normal((n, d)).astype(np.float32)
+    from oracle import whiten as ow
+    want_w, _ = ow.embed_slow(lambda x: oracle.spmm(rowptr, col, vl, x), x0, 3, whiten=True)
+    ws = [res.pop("whiten") for _, res in got]
+    np.testing.assert_array_equal(ws[0], ws[1])
+    sgn = np.sign((ws[0] * want_w).sum(axis=0))
+    assert np.abs(ws[0] * sgn - want_w).max() <= 2e-3 * np.abs(want_w).max()
     for key in got[0][1]:
         kind, rw, thr = key
         want, it = oracle.embed(rowptr, col, (vl, vs)[kind], x0, 10, residual_weight=rw, convergence_threshold=thr)

@@ -113,13 +113,26 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float *__restrict__ x
     }
 }
 
+// 32 columns per block, 8 threads per column: each adds a contiguous eighth of the block partials in
+// order, the eight sums are then added in order (fixed order => deterministic).
 __global__ __launch_bounds__(256) void colsum_stage2(const double *__restrict__ part, int nb,
                                                      uint32_t d, double *__restrict__ out) {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
+    __shared__ double sm[8][32];
+    const int cl = threadIdx.x & 31, p = threadIdx.x >> 5;
+    const uint32_t c = blockIdx.x * 32 + cl;
+    const int per = (nb + 7) / 8;
+    const int b0 = p * per, b1 = (b0 + per) < nb ? (b0 + per) : nb;
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[(uint64_t)b * d + c];
-    out[c] = s;
+    if (c < d)
+        for (int b = b0; b < b1; ++b) s += part[(uint64_t)b * d + c];
+    sm[p][cl] = s;
+    __syncthreads();
+    if (p == 0 && c < d) {
+        double t = sm[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sm[k][cl];
+        out[c] = t;
+    }
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -171,7 +184,7 @@ int launch_colsum(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     else
         hipLaunchKernelGGL(colsum_stage1<1>, dim3(nb), dim3(256), 0, stream, x, ldx, n, d, tc,
                            rows_per_block ? rows_per_block : 1, ws);
-    hipLaunchKernelGGL(colsum_stage2, dim3((d + 255) / 256), dim3(256), 0, stream, ws, nb, d, out);
+    hipLaunchKernelGGL(colsum_stage2, dim3((d + 31) / 32), dim3(256), 0, stream, ws, nb, d, out);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

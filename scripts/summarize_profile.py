@@ -42,6 +42,17 @@ with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
         w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                     r["MinNs"], r["MaxNs"], r["StdDev"]])
 
+# 1b. whitening kernels (rocprofv3 --kernel-trace --stats of scripts/whiten_probe.py), if captured
+wpath = os.path.join(src, "wstats", "whiten_kernel_stats.csv")
+if os.path.exists(wpath):
+    wrows = [r for r in csv.DictReader(open(wpath)) if "cleora" in r["Name"]]
+    with open(os.path.join(dst, f"{tag}_whiten_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in wrows:
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+
 # 2. PMC
 probe = open(os.path.join(src, "fetch.log")).read()
 m = re.search(r"PMC_PROBE n=(\d+) nnz=(\d+) d=(\d+)", probe)

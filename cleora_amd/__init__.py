@@ -22,3 +22,29 @@ def install():
     if "pycleora" in sys.modules or importlib.util.find_spec("pycleora") is not None:
         _mod.SparseMatrix.__module__ = "pycleora.pycleora"
     return _mod
+
+
+def accelerate(package=None):
+    """Optional second step after install(): rebind the reference package's own hot-path entry
+    points to the device-resident versions, so that its CLI / benchmark / CleoraEmbedder (which all
+    call `pycleora.embed`, pycleora/cli.py:148, __init__.py:885) keep the iterate in HBM instead of
+    crossing PCIe twice per iteration and whitening in numpy:
+        pycleora.embed              -> cleora_amd.embed.embed           (same signature)
+        pycleora.whiten_embeddings  -> cleora_amd.embed.whiten_embeddings
+    Normalisations the device path does not run ('l1', 'spectral') are forwarded to the original."""
+    import importlib
+
+    from . import embed as _dev
+    pkg = package if package is not None else importlib.import_module("pycleora")
+    original_embed = pkg.embed
+
+    def embed(graph, *args, **kwargs):
+        norm = kwargs.get("normalization", args[3] if len(args) > 3 else "l2")
+        if norm not in ("l2", "none") or not isinstance(graph, _dev.SparseMatrix):
+            return original_embed(graph, *args, **kwargs)
+        return _dev.embed(graph, *args, **kwargs)
+
+    embed.__wrapped__ = original_embed
+    pkg.embed = embed
+    pkg.whiten_embeddings = _dev.whiten_embeddings
+    return pkg

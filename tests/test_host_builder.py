@@ -175,3 +175,25 @@ def test_install_shim():
             sys.modules.pop("pycleora.pycleora", None)
         else:
             sys.modules["pycleora.pycleora"] = saved
+
+
+def test_accelerate_rebinds_reference_entry_points():
+    """cleora_amd.accelerate() on a stand-in package object: l2/none go to the device loop, other
+    normalisations and foreign graph types are forwarded to the original function."""
+    import types
+    import cleora_amd
+    from cleora_amd import embed as dev
+    calls = []
+    pkg = types.SimpleNamespace(embed=lambda g, *a, **k: calls.append(("orig", k.get("normalization"))) or "orig",
+                                whiten_embeddings=lambda x: x)
+    cleora_amd.accelerate(pkg)
+    assert pkg.whiten_embeddings is dev.whiten_embeddings and pkg.embed.__wrapped__ is not None
+    assert pkg.embed(object(), 8, 2) == "orig"                                  # not our SparseMatrix
+    g = SparseMatrix.from_iterator(iter(["a b", "b c"]), "complex::reflexive::n")
+    assert pkg.embed(g, 8, 2, normalization="l1") == "orig"
+    assert calls == [("orig", None), ("orig", "l1")]
+    with pytest.raises(RuntimeError):          # l2 goes to the device path: no GPU here, and no fallback
+        if __import__("cleora_amd._hip", fromlist=["x"]).device_count() == 0:
+            pkg.embed(g, 8, 2, whiten=False)
+        else:
+            raise RuntimeError("gpu present")

@@ -1,8 +1,9 @@
 // cleora_host.cpp — host-side graph construction for the drop-in (include/cleora_host.h).
 // Written from the behaviour of the reference's Rust builder (citations: paths under the
-// reference checkout); data structures and control flow are this project's own: entities are
-// interned to dense indices as lines are scanned, edges accumulate in one open-addressing table
-// keyed by (row << 32 | col), and the CSR comes out of a radix sort of those keys.
+// reference checkout); data structures and control flow are this project's own: tokens are hashed
+// in parallel, entities are interned to dense indices in line order, each worker owns a contiguous
+// row range and accumulates its edges in a private open-addressing table keyed by (row << 32 | col),
+// and the CSR is the concatenation of the workers' sorted ranges (see `struct Builder`).
 #include "../../include/cleora_host.h"
 
 #include <algorithm>

@@ -58,6 +58,7 @@ SIGNATURES = {
     "cleora_gram_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_centered_gram_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp, vp]),
     "cleora_project_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp]),
+    "cleora_cosine_scores_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp]),
     "cleora_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),
     "cleora_l2_normalize": (c_int, [vp, c_u64, c_u32, vp]),
     "cleora_init": (c_int, [vp, c_u64, c_u32, c_i64, vp]),

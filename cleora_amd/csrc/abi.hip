@@ -347,6 +347,11 @@ int cleora_colsum_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, doub
     return launch_colsum(x, ldx, n, d, workspace, colsum_dev, S(stream));
 }
 
+int cleora_cosine_scores_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *query_dev,
+                             float *scores_dev, void *stream) {
+    return launch_cosine(x, ldx, n, d, query_dev, scores_dev, S(stream));
+}
+
 uint64_t cleora_gram_workspace(uint64_t n, uint32_t d) { return gram_workspace(n, d); }
 
 int cleora_centered_gram_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,

@@ -83,6 +83,8 @@ int launch_reduce_sum(const double *v, uint64_t n, double *ws, double *out, hipS
 uint64_t colsum_workspace(uint64_t n, uint32_t d);
 int launch_colsum(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *ws, double *out,
                   hipStream_t stream);
+int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *q, float *scores,
+                  hipStream_t stream);
 // whiten.hip
 uint64_t gram_workspace(uint64_t n, uint32_t d);
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,

@@ -135,9 +135,42 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double *__restrict__ 
     }
 }
 
+// ---- cosine scores against one query (find_most_similar, pycleora/__init__.py:753-781) --------------
+// scores[r] = (x[r] . q) / max(||x[r]||, 1e-10); one wavefront per row, one pass over X (HBM-bound).
+__global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ x, uint64_t ldx, uint64_t n,
+                                                     uint32_t d, const float *__restrict__ q,
+                                                     float *__restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + row * ldx;
+    float dot = 0.f, sq = 0.f;
+    for (uint32_t c = lane; c < d; c += 64) {
+        const float v = xr[c];
+        dot += v * q[c];
+        sq += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        dot += __shfl_xor(dot, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+    }
+    if (lane == 0) scores[row] = dot / fmaxf(sqrtf(sq), 1e-10f);
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
+
+int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *q, float *scores,
+                  hipStream_t stream) {
+    CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
+    CL_REQUIRE(x != nullptr && q != nullptr && scores != nullptr, "x / q / scores is NULL");
+    if (n == 0) return CLEORA_OK;
+    hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, x, ldx, n, d, q, scores);
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
 
 int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, float *x, uint64_t ldx,
                 hipStream_t stream) {

@@ -228,3 +228,27 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
             break
     _hip.check(L.cleora_stream_sync(None))
     return cur.to_host()
+
+
+def find_most_similar(graph, embeddings, query_entity, top_k=10, exclude_self=True):
+    """Same contract as pycleora.find_most_similar (pycleora/__init__.py:753-781): cosine
+    similarity of every entity to the query, top_k as a list of dicts.  The normalise + GEMV runs
+    as one pass over X on the device; the top-k selection of the n scores stays on the host."""
+    query_idx = graph.get_entity_index(query_entity)
+    x = np.ascontiguousarray(embeddings, dtype=np.float32)
+    n, d = x.shape
+    q = x[query_idx]
+    q = (q / max(float(np.linalg.norm(q)), 1e-10)).astype(np.float32)
+    L = _hip.lib()
+    dx, dq = _hip.DevArray.from_host(x), _hip.DevArray.from_host(q)
+    ds = _hip.DevArray((n,), np.float32)
+    _hip.check(L.cleora_cosine_scores_dev(dx.ptr, d, n, d, dq.ptr, ds.ptr, None))
+    _hip.check(L.cleora_stream_sync(None))
+    sims = ds.to_host()
+    if exclude_self:
+        sims[query_idx] = -1.0
+    k = min(int(top_k), n)
+    part = np.argpartition(-sims, k - 1)[:k] if k < n else np.arange(n)
+    order = part[np.argsort(-sims[part], kind="stable")]
+    ids = graph.entity_ids
+    return [{"entity_id": ids[int(i)], "index": int(i), "similarity": float(sims[int(i)])} for i in order]

@@ -166,6 +166,14 @@ int cleora_project_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                        const float *mean_f32_dev, const float *transform_dev, uint32_t k,
                        float *out, uint64_t ldo, void *stream);
 
+/* ---- similarity ---------------------------------------------------- */
+
+/* scores[r] = (x[r] . query) / max(||x[r]||, 1e-10): the row-normalise + GEMV of find_most_similar /
+ * predict_links (pycleora/__init__.py:636-681, 753-781) in one pass over X.  `query` is expected
+ * already normalised (d floats, device). */
+int cleora_cosine_scores_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                             const float *query_dev, float *scores_dev, void *stream);
+
 /* ---- host-pointer entry points: what the PyO3 methods call ------------------------- */
 
 /* SparseMatrix::markov_propagate → NdArrayMatrix::multiply (src/lib.rs:29-47, src/embedding.rs:15-39).

@@ -158,3 +158,18 @@ def test_embed_csr_user_adjacency():
     assert np.abs(gotw * s - wantw).max() <= 2e-3 * np.abs(wantw).max()
     with pytest.raises(ValueError, match="initial_embeddings has shape"):
         dev_embed.embed_csr(rowptr, col, val, x0[:10], 2)
+
+
+def test_find_most_similar(karate):
+    k, g = karate
+    emb = k["embed_fast_d16"]
+    got = dev_embed.find_most_similar(g, emb, "0", top_k=5)
+    normed = emb / np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-10)
+    sims = normed @ normed[0]
+    sims[0] = -1.0
+    want = np.argsort(sims)[::-1][:5]
+    assert [r["index"] for r in got] == [int(i) for i in want]
+    np.testing.assert_allclose([r["similarity"] for r in got], sims[want], atol=2e-6)
+    assert got[0]["entity_id"] == g.entity_ids[int(want[0])]
+    with pytest.raises(ValueError, match="not found"):
+        dev_embed.find_most_similar(g, emb, "nope")

@@ -168,8 +168,11 @@ def test_find_most_similar(karate):
     sims = normed @ normed[0]
     sims[0] = -1.0
     want = np.argsort(sims)[::-1][:5]
-    assert [r["index"] for r in got] == [int(i) for i in want]
+    # after 40 iterations many karate rows are nearly parallel: ties may be ordered differently,
+    # so compare the score profile and check every reported index against its true score
     np.testing.assert_allclose([r["similarity"] for r in got], sims[want], atol=2e-6)
-    assert got[0]["entity_id"] == g.entity_ids[int(want[0])]
+    for r in got:
+        assert abs(sims[r["index"]] - r["similarity"]) < 2e-6 and r["entity_id"] == g.entity_ids[r["index"]]
+    assert 0 not in [r["index"] for r in got]
     with pytest.raises(ValueError, match="not found"):
         dev_embed.find_most_similar(g, emb, "nope")

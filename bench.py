@@ -85,11 +85,10 @@ def main():
                     help="multi-GPU partition: 'column' = each rank owns d/N columns of X (one all-reduce of "
                          "n floats per iteration); 'row' = row blocks + in-place all-gather of X (north_star's "
                          "literal layout, 10 GB per iteration over xGMI); auto = column for N > 1")
-    ap.add_argument("--placement-candidates", type=int, default=4,
-                    help="allocate this many candidate iterate buffers, time one step for every ordered pair "
-                         "before the timed region and keep the fastest ping-pong pair (2 = no tuning).  The same "
-                         "kernel runs 34.4-38.1 ms depending on WHICH two allocations hold X and Y "
-                         "(DESIGN.md, placement sensitivity); the choice is made outside the timed region.")
+    ap.add_argument("--placement-candidates", type=int, default=8,
+                    help="before the timed region, try up to this many allocations as the partner buffer of X "
+                         "and keep the fastest ping-pong pair (1 = no tuning).  The same kernel runs 34.4-39.9 ms "
+                         "depending on WHICH two allocations hold X and Y (DESIGN.md §3.1, placement sensitivity).")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -172,18 +171,22 @@ def main():
         del g
     torch.cuda.empty_cache()
 
-    # ---- placement tuning (outside the timed region): pick the fastest (X, Y) pair of allocations ----
+    # ---- placement tuning (outside the timed region) ---------------------------------------------
+    # The same launch runs 34.4-39.9 ms depending on WHICH two allocations hold X and Y: a pair is
+    # slow when both buffers fall into the same (unknown, physical) placement class — unaffected by
+    # offsets inside the allocations (scripts/alloc_probe*.py).  So X stays where it is
+    # and candidate partners are allocated one by one (with spacer allocations in between to move the
+    # allocator along) until one is clearly faster than the slowest seen, or the budget is used.
     placement = None
-    ncand = max(2, args.placement_candidates)
-    if ncand > 2:
-        cands = [x, x_next] + [torch.zeros_like(x) for _ in range(ncand - 2)]
-        src = x.clone()
+    ncand = max(1, args.placement_candidates)
+    if ncand > 1:
+        base, src = x, x.clone()
 
         def step_time(a, b):
             nonlocal x, x_next
             a.copy_(src)
             x, x_next = a, b
-            iterate()                       # warm (x, x_next swapped by iterate)
+            iterate()                       # warm (iterate swaps x / x_next)
             x, x_next = a, b
             a.copy_(src)
             torch.cuda.synchronize()
@@ -194,21 +197,20 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1)
 
-        times = {}
-        for i in range(ncand):
-            for j in range(ncand):
-                if i != j:
-                    times[(i, j)] = step_time(cands[i], cands[j])
-        if world > 1:   # every rank must make the same choice only for symmetry of reporting; pairs are local
-            pass
-        best = min(((i, j) for i in range(ncand) for j in range(i + 1, ncand)),
-                   key=lambda p: times[p] + times[(p[1], p[0])])
-        worst = max(times.values())
-        x, x_next = cands[best[0]], cands[best[1]]
+        tried, spacers = [], []
+        for k in range(ncand):
+            cand = x_next if k == 0 else torch.zeros_like(base)
+            tried.append((step_time(base, cand) + step_time(cand, base), cand))
+            lo, hi = min(t for t, _ in tried), max(t for t, _ in tried)
+            if k >= 1 and lo < 0.95 * hi:
+                break
+            spacers.append(torch.empty(int((0.6 + 0.83 * (k + 1)) * 2 ** 30), dtype=torch.uint8, device=dev))
+        best_t, best = min(tried, key=lambda p: p[0])
+        x, x_next = base, best
         x.copy_(src)
-        placement = {"candidates": ncand, "chosen_pair_ms": [times[best], times[(best[1], best[0])]],
-                     "slowest_pair_ms": worst, "fastest_pair_ms": min(times.values())}
-        del cands, src
+        placement = {"partners_tried": len(tried), "pair_ms_tried": [round(t / 2, 3) for t, _ in tried],
+                     "chosen_pair_ms": round(best_t / 2, 3)}
+        del tried, spacers, src, best, base
         torch.cuda.empty_cache()
 
     def sync():

@@ -198,11 +198,15 @@ def main():
             return e0.elapsed_time(e1)
 
         tried, spacers = [], []
+        # with several ranks every iterate() contains a collective, so all ranks must run the SAME
+        # number of trial steps: a fixed count and no data-dependent early exit
+        if world > 1:
+            ncand = min(ncand, 4)
         for k in range(ncand):
             cand = x_next if k == 0 else torch.zeros_like(base)
             tried.append((step_time(base, cand) + step_time(cand, base), cand))
             lo, hi = min(t for t, _ in tried), max(t for t, _ in tried)
-            if k >= 1 and lo < 0.95 * hi:
+            if world == 1 and k >= 1 and lo < 0.95 * hi:
                 break
             spacers.append(torch.empty(int((0.6 + 0.83 * (k + 1)) * 2 ** 30), dtype=torch.uint8, device=dev))
         best_t, best = min(tried, key=lambda p: p[0])

@@ -145,11 +145,14 @@ def main():
             sg.propagate(_hip.LEFT, x, x_next)
             x, x_next = x_next, x
     else:
-        cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend)
-        blocks = [cg.block]
+        cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend,
+                                        steps=steps_per_iter)
+        blocks = cg.blocks
         dl = cg.dl
-        n_hub = int((deg > cg.block.info().hub_threshold).sum())
-        launch_bytes.append(algorithmic_bytes(nnz, n - n_hub, n, dl))
+        for blk, (r0, r1) in zip(cg.blocks, cg.row_blocks):
+            dk = deg[r0:r1]
+            n_hub = int((dk > blk.info().hub_threshold).sum())
+            launch_bytes.append(algorithmic_bytes(int(dk.sum()), (r1 - r0) - n_hub, r1 - r0, dl))
         x = torch.empty((n, dl), dtype=torch.float32, device=dev)
         x_next = torch.empty_like(x)
         rowsq = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -159,7 +162,8 @@ def main():
         g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
         kernel_name = f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true>"
         par = (f"column partition x{world}: every rank owns {dl} of {d} columns and the whole CSR; "
-               f"one RCCL all-reduce of n f32 row sums-of-squares per iteration, no exchange of X")
+               f"RCCL all-reduce of the n f32 row sums-of-squares per iteration in {steps_per_iter} row block(s) "
+               f"(block k's reduce overlaps block k+1's SpMM), no exchange of X")
 
         def iterate():
             nonlocal x, x_next

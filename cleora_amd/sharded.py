@@ -257,34 +257,57 @@ class ColumnShardedGraph:
     """
 
     def __init__(self, n, rowptr, col, val_left, val_sym, d, rank, world, backend,
-                 hub_threshold=0, hub_segment=0, group=None):
+                 hub_threshold=0, hub_segment=0, group=None, steps=1):
         if d % world != 0:
             raise ValueError(f"feature_dim {d} must be divisible by the number of ranks {world}")
         self.n, self.d, self.rank, self.world = n, d, rank, world
         self.dl = d // world
         self.c0 = rank * self.dl
         self.backend, self.group = backend, group
-        self.block = backend.make_block(rowptr.to(torch.int64), col, val_left, val_sym, n,
-                                        hub_threshold, hub_segment)
         self.nnz = int(col.numel())
+        # `steps` row blocks per iteration: the all-reduce of block k's row sums overlaps the SpMM
+        # of block k+1 (the blocks are zero-copy views of the one CSR every rank holds)
+        self.steps = max(1, min(int(steps), max(1, n)))
+        rp64 = rowptr.to(torch.int64)
+        bounds = [n * k // self.steps for k in range(self.steps + 1)]
+        self.row_blocks, self.blocks = [], []
+        for k in range(self.steps):
+            r0, r1 = bounds[k], bounds[k + 1]
+            e0, e1 = int(rp64[r0]), int(rp64[r1])
+            brp = (rp64[r0:r1 + 1] - e0).contiguous()
+            self.blocks.append(backend.make_block(brp, col[e0:e1], val_left[e0:e1],
+                                                  val_sym[e0:e1] if val_sym is not None else None, n,
+                                                  hub_threshold, hub_segment))
+            self.row_blocks.append((r0, r1))
+        self.block = self.blocks[0]
         # row chunks used when the whitening step switches to a row layout (equal splits, padded)
         self.rows_per = -(-n // world)
         self.n_pad = self.rows_per * world
 
     def propagate(self, kind, x, x_next, rowsq, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None):
         """x, x_next: (n, d/P) column slices; rowsq: f32[n] scratch.  One iteration."""
-        if self.world == 1:
-            self.backend.propagate(self.block, kind, x, x_next, flags, rw, x, row_sqdiff)
-            return
         norm = flags & _hip.F_L2NORM
+        if self.world == 1:   # nothing to reduce: the fused single-pass epilogue
+            for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
+                self.backend.propagate(blk, kind, x, x_next[r0:r1], flags, rw, x[r0:r1],
+                                       row_sqdiff[r0:r1] if row_sqdiff is not None else None)
+            return
         first = (flags & ~(_hip.F_L2NORM | _hip.F_SQDIFF)) | (_hip.F_ROWSQ if norm else 0)
-        self.backend.propagate(self.block, kind, x, x_next, first, rw, x, None, rowsq if norm else None)
-        if norm:
-            dist.all_reduce(rowsq, group=self.group)
+        works = []
+        for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
+            self.backend.propagate(blk, kind, x, x_next[r0:r1], first, rw, x[r0:r1], None,
+                                   rowsq[r0:r1] if norm else None)
+            if norm:
+                works.append(dist.all_reduce(rowsq[r0:r1], group=self.group, async_op=True))
         second = (_hip.F_SCALE if norm else 0) | (flags & _hip.F_SQDIFF)
-        if second:
-            self.backend.rowops(x_next, x_next, second, 0.0, x if (flags & _hip.F_SQDIFF) else None,
-                                row_sqdiff, rowsq if norm else None)
+        for k, (r0, r1) in enumerate(self.row_blocks):
+            if norm:
+                works[k].wait()
+            if second:
+                self.backend.rowops(x_next[r0:r1], x_next[r0:r1], second, 0.0,
+                                    x[r0:r1] if (flags & _hip.F_SQDIFF) else None,
+                                    row_sqdiff[r0:r1] if row_sqdiff is not None else None,
+                                    rowsq[r0:r1] if norm else None)
 
     def whiten(self, y_local, out_local):
         """whiten_embeddings (pycleora/__init__.py:130-164) for a column-partitioned matrix.

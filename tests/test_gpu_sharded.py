@@ -117,3 +117,19 @@ def test_column_layout_whitened_loop_single_rank():
     got = x[:n].cpu().numpy()
     s = np.sign((got * want).sum(axis=0))
     assert np.abs(got * s - want).max() <= 2e-3 * np.abs(want).max()
+
+
+def test_column_layout_row_blocks_single_rank():
+    """steps > 1 (the row blocks whose all-reduces overlap the next block's SpMM) on the HIP backend."""
+    dev = torch.device("cuda:0")
+    n, d = 4001, 64
+    rowptr, col, vl, vs = random_csr(n, 9, seed=41, empty_frac=0.02, hubs=[(100, 1800)])
+    t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
+    cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), d, 0, 1,
+                                    sharded.HipBackend(dev), steps=3)
+    assert len(cg.blocks) == 3 and cg.row_blocks[-1][1] == n
+    x0 = np.random.default_rng(42).standard_normal((n, d)).astype(np.float32)
+    for kind, val, rw in ((0, vl, 0.0), (1, vs, 0.3)):
+        x, _ = sharded.embed_column_sharded(cg, kind, torch.from_numpy(x0).to(dev), 3, rw)
+        want, _ = oracle.embed(rowptr, col, val, x0, 3, residual_weight=rw)
+        np.testing.assert_allclose(x.cpu().numpy(), want, rtol=0, atol=2e-6)

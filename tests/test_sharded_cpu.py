@@ -127,7 +127,7 @@ def test_block_size_alignment():
         assert b % 4 == 0 and b * w * s >= n and (b - 4) * w * s < n or b == 4
 
 
-def _col_worker(rank, world, port, q):
+def _col_worker(rank, world, port, q, steps=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -135,7 +135,7 @@ def _col_worker(rank, world, port, q):
         rowptr, col, vl, vs = random_csr(n, 7, seed=13, empty_frac=0.05)
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.kind == "u" else a)
         cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
-                                        torch.from_numpy(vs), d, rank, world, OracleBackend())
+                                        torch.from_numpy(vs), d, rank, world, OracleBackend(), steps=steps)
         x0 = np.random.default_rng(14).standard_normal((n, d)).astype(np.float32)
         res = {}
         for kind, rw, thr in ((0, 0.0, 0.0), (1, 0.4, 0.0), (0, 0.0, 2e-3)):
@@ -151,11 +151,12 @@ def _col_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_column_partition_world2():
+@pytest.mark.parametrize("steps", [1, 3])
+def test_column_partition_world2(steps):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_col_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_col_worker, args=(r, world, port, q, steps)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]

@@ -94,6 +94,37 @@ int check_csr_host(uint64_t n_rows, uint64_t n_cols, uint64_t nnz, const uint64_
     return CLEORA_OK;
 }
 
+// Device-side bounds check of adopted column indices (cleora_graph_create_dev cannot afford a host
+// copy of nnz entries): an out-of-range index would otherwise turn into a wild gather.
+__global__ __launch_bounds__(256) void max_u32_kernel(const uint32_t *__restrict__ v, uint64_t n,
+                                                      uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+        m = v[i] > m ? v[i] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)m, o, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+int check_cols_dev(const uint32_t *col_dev, uint64_t nnz, uint64_t n_cols) {
+    if (nnz == 0) return CLEORA_OK;
+    uint32_t *d_max = nullptr, h_max = 0;
+    CL_HIP(hipMalloc(&d_max, sizeof(uint32_t)));
+    hipError_t e = hipMemset(d_max, 0, sizeof(uint32_t));
+    if (e == hipSuccess) {
+        const uint64_t want = (nnz + 255) / 256;
+        hipLaunchKernelGGL(max_u32_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, nullptr, col_dev, nnz, d_max);
+        e = hipMemcpy(&h_max, d_max, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_max);
+    CL_HIP(e);
+    CL_REQUIRE((uint64_t)h_max < n_cols, "column index out of range");
+    return CLEORA_OK;
+}
+
 void free_graph(cleora_graph *g) {
     if (!g) return;
     (void)hipSetDevice(g->device);
@@ -243,6 +274,7 @@ int cleora_graph_create_dev(int device, uint64_t n_rows, uint64_t n_cols, uint64
     std::vector<uint64_t> rp(n_rows + 1);
     CL_HIP(hipMemcpy(rp.data(), rowptr_dev, (n_rows + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if ((rc = check_csr_host(n_rows, n_cols, nnz, rp.data(), nullptr)) != CLEORA_OK) return rc;
+    if ((rc = check_cols_dev(col_dev, nnz, n_cols)) != CLEORA_OK) return rc;
 
     cleora_graph *g = new (std::nothrow) cleora_graph();
     if (!g) {

@@ -147,3 +147,18 @@ def test_properties_at_baseline_sizes(config):
         for k in range(b, e):
             acc += vsh[k] * xh[colh[k]]
         np.testing.assert_array_equal(ys[r], acc)
+
+
+def test_adopted_device_csr_is_bounds_checked():
+    import torch
+    dev = torch.device("cuda:0")
+    rowptr = torch.tensor([0, 2, 3], dtype=torch.int64, device=dev)
+    val = torch.ones(3, dtype=torch.float32, device=dev)
+    good = torch.tensor([0, 1, 1], dtype=torch.int32, device=dev)
+    _hip.Graph.from_device(2, 2, 3, rowptr.data_ptr(), good.data_ptr(), val.data_ptr(), None, 0, keepalive=(rowptr, good, val))
+    bad = torch.tensor([0, 7, 1], dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError, match="column index out of range"):
+        _hip.Graph.from_device(2, 2, 3, rowptr.data_ptr(), bad.data_ptr(), val.data_ptr(), None, 0)
+    bad_rp = torch.tensor([0, 3, 2], dtype=torch.int64, device=dev)
+    with pytest.raises(ValueError, match="rowptr"):
+        _hip.Graph.from_device(2, 2, 3, bad_rp.data_ptr(), good.data_ptr(), val.data_ptr(), None, 0)

@@ -162,3 +162,38 @@ def test_adopted_device_csr_is_bounds_checked():
     bad_rp = torch.tensor([0, 3, 2], dtype=torch.int64, device=dev)
     with pytest.raises(ValueError, match="rowptr"):
         _hip.Graph.from_device(2, 2, 3, bad_rp.data_ptr(), good.data_ptr(), val.data_ptr(), None, 0)
+
+
+def test_more_than_2_pow_32_edges():
+    """Maximum-size indexing: nnz > 2^32 (the papers100M regime, BASELINE config 4) needs 64-bit edge
+    offsets end to end.  4.4M rows x 1000 edges = 4.4e9 stored entries, d = 4 so X stays small."""
+    import torch
+    dev = torch.device("cuda:0")
+    if torch.cuda.get_device_properties(0).total_memory < 100 * 2 ** 30:
+        pytest.skip("needs ~40 GB of HBM")
+    n, deg, d = 4_400_000, 1000, 4
+    nnz = n * deg
+    assert nnz > 2 ** 32
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(9)
+    col = torch.randint(0, n, (nnz,), generator=gen, device=dev, dtype=torch.int32)
+    val = torch.full((nnz,), 1.0 / deg, dtype=torch.float32, device=dev)
+    rowptr = torch.arange(0, nnz + 1, deg, dtype=torch.int64, device=dev)
+    g = _hip.Graph.from_device(n, n, nnz, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), None, 0,
+                               keepalive=(rowptr, col, val))
+    x = torch.randn((n, d), dtype=torch.float32, device=dev)
+    y = torch.empty_like(x)
+    L = _hip.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    _hip.check(L.cleora_propagate_dev(g.handle, 0, x.data_ptr(), d, d, y.data_ptr(), d, 0, 0.0, None, None, None, s))
+    torch.cuda.synchronize()
+    # rows from the first, middle and LAST part of the edge array (offsets beyond 2^32)
+    for r in (0, 1, n // 2, n - 2, n - 1):
+        b = r * deg
+        want = (x[col[b:b + deg].long()].double() * (1.0 / deg)).sum(0)
+        assert float((y[r].double() - want).abs().max()) < 1e-5, r
+    # row-stochastic: a constant propagates to itself on every row, including the tail
+    c = torch.full((n, d), 0.5, dtype=torch.float32, device=dev)
+    _hip.check(L.cleora_propagate_dev(g.handle, 0, c.data_ptr(), d, d, y.data_ptr(), d, 0, 0.0, None, None, None, s))
+    torch.cuda.synchronize()
+    assert float((y - 0.5).abs().max()) < 1e-4

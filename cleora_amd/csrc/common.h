@@ -30,6 +30,16 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                          \
     } while (0)
 
+// A launch's x extent in work-items (blocks * 256) is a 32-bit field of the dispatch packet: a 1-D
+// grid of more than 2^24 256-thread blocks is silently truncated (seen at |V| = 111M: 27.7M blocks).
+// Big 1-D problems therefore use a 2-D grid of at most 2^23 x N blocks and linearise it in the kernel.
+constexpr unsigned kMaxGridX = 1u << 23;
+inline dim3 grid_1d_as_2d(uint64_t blocks) {
+    if (blocks <= kMaxGridX) return dim3((unsigned)(blocks ? blocks : 1));
+    return dim3(kMaxGridX, (unsigned)((blocks + kMaxGridX - 1) / kMaxGridX));
+}
+#define CLEORA_LINEAR_BLOCK() ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x)
+
 constexpr uint32_t kDefaultHubThreshold = 1024;  // edges; longer rows are split
 constexpr uint32_t kDefaultHubSegment = 256;     // edges per split segment
 

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *__restrict__ 
                                                    uint32_t d, int64_t seed, float *__restrict__ x,
                                                    uint64_t ldx) {
     const int lane = threadIdx.x & 63;
-    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const uint64_t h = hash[row];
     float *xr = x + row * ldx;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ x
                                                      uint32_t d, const float *__restrict__ q,
                                                      float *__restrict__ scores) {
     const int lane = threadIdx.x & 63;
-    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const float *xr = x + row * ldx;
     float dot = 0.f, sq = 0.f;
@@ -167,7 +167,7 @@ int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const fl
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && q != nullptr && scores != nullptr, "x / q / scores is NULL");
     if (n == 0) return CLEORA_OK;
-    hipLaunchKernelGGL(cosine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, x, ldx, n, d, q, scores);
+    hipLaunchKernelGGL(cosine_kernel, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, x, ldx, n, d, q, scores);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }
@@ -177,7 +177,7 @@ int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, floa
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(hash != nullptr && x != nullptr, "hash / x is NULL");
     if (n == 0) return CLEORA_OK;
-    hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, hash, n, d,
+    hipLaunchKernelGGL(init_kernel, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, hash, n, d,
                        seed, x, ldx);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;

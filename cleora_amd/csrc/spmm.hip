@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
     const int gbase = lane & ~(G - 1);
-    uint64_t item = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    uint64_t item = CLEORA_LINEAR_BLOCK() * (256 / G) + (threadIdx.x / G);
     bool active = item < a.n_items;
     if constexpr (G == 64) {
         if (!active) return;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void rowops_kernel(const float *x, uint64_t ld
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
     const int gbase = lane & ~(G - 1);
-    const uint64_t row = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    const uint64_t row = CLEORA_LINEAR_BLOCK() * (256 / G) + (threadIdx.x / G);
     if (row >= n) return;
     float acc[V][W];
     load_row<G, V, W, false>(x + row * ldx, gl, ra.d, acc);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void rowops_kernel(const float *x, uint64_t ld
 __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64_t ldx, uint64_t n,
                                                           const RowArgs ra) {
     const int lane = threadIdx.x & 63;
-    const uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const float *xr = x + row * ldx;
     const float *xs = (ra.flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) ? ra.x_self + row * ra.ldxs : nullptr;
@@ -447,8 +447,8 @@ bool dispatch_shape(uint32_t d, bool w4, F &&f) {
     return false;
 }
 
-inline unsigned grid_for(uint64_t items, int per_block) {
-    return (unsigned)((items + per_block - 1) / per_block);
+inline dim3 grid_for(uint64_t items, int per_block) {
+    return grid_1d_as_2d((items + per_block - 1) / per_block);
 }
 
 int ensure_partial(const cleora_graph *g, uint32_t d) {
@@ -490,7 +490,7 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
     if (a.n_items) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
             hipLaunchKernelGGL((spmm_rows_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value, (decltype(FULL)::value != 0)>),
-                               dim3(grid_for(a.n_items, 256 / decltype(G)::value)), dim3(256), 0, stream, a);
+                               grid_for(a.n_items, 256 / decltype(G)::value), dim3(256), 0, stream, a);
         });
     }
     mark(g, stream);
@@ -607,10 +607,10 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
                     (!x_self || aligned16(x_self));
     const bool ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
         hipLaunchKernelGGL((rowops_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
-                           dim3(grid_for(n, 256 / decltype(G)::value)), dim3(256), 0, stream, x, ldx, n, ra);
+                           grid_for(n, 256 / decltype(G)::value), dim3(256), 0, stream, x, ldx, n, ra);
     });
     if (!ok) {
-        hipLaunchKernelGGL(rowops_wide_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, x, ldx, n, ra);
+        hipLaunchKernelGGL(rowops_wide_kernel, grid_for(n, 4), dim3(256), 0, stream, x, ldx, n, ra);
     }
     CL_HIP(hipGetLastError());
     return CLEORA_OK;

@@ -282,6 +282,7 @@ struct ProjArgs {
     float *out;
     uint64_t ldo;
     uint32_t nb_n;    // column blocks
+    uint64_t n_blocks;
     int w4x, w4t;
 };
 
@@ -290,8 +291,10 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     __shared__ __attribute__((aligned(16))) float Bs[PK][PN];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1;
-    const uint32_t bn = blockIdx.x % a.nb_n;
-    const uint64_t bm = blockIdx.x / a.nb_n;
+    const uint64_t bid = CLEORA_LINEAR_BLOCK();
+    if (bid >= a.n_blocks) return;
+    const uint32_t bn = (uint32_t)(bid % a.nb_n);
+    const uint64_t bm = bid / a.nb_n;
     const uint64_t m0 = bm * PM;
     const uint32_t n0 = bn * PN;
 
@@ -435,8 +438,8 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.w4x = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
     a.w4t = (k % 4 == 0) && aligned16(t);
     const uint64_t blocks = ((n + PM - 1) / PM) * a.nb_n;
-    CL_REQUIRE(blocks < (1ull << 31), "too many row blocks");
-    hipLaunchKernelGGL(project_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    a.n_blocks = blocks;
+    hipLaunchKernelGGL(project_kernel, grid_1d_as_2d(blocks), dim3(256), 0, stream, a);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

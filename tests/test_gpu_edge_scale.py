@@ -197,3 +197,40 @@ def test_more_than_2_pow_32_edges():
     _hip.check(L.cleora_propagate_dev(g.handle, 0, c.data_ptr(), d, d, y.data_ptr(), d, 0, 0.0, None, None, None, s))
     torch.cuda.synchronize()
     assert float((y - 0.5).abs().max()) < 1e-4
+
+
+def test_more_than_2_pow_24_blocks():
+    """Launches of more than 2^24 workgroups (|V| > 67M at one row per wavefront — the papers100M
+    regime): the work-item extent of a 1-D grid is a 32-bit field and silently truncates, so the
+    big kernels linearise a 2-D grid.  72M rows, d = 3 (scalar path: one row per wavefront)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, deg, d = 72_000_000, 2, 3
+    nnz = n * deg
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(10)
+    col = torch.randint(0, n, (nnz,), generator=gen, device=dev, dtype=torch.int32)
+    val = torch.full((nnz,), 0.5, dtype=torch.float32, device=dev)
+    rowptr = torch.arange(0, nnz + 1, deg, dtype=torch.int64, device=dev)
+    g = _hip.Graph.from_device(n, n, nnz, rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), None, 0,
+                               keepalive=(rowptr, col, val))
+    L = _hip.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    hashes = torch.arange(n, device=dev, dtype=torch.int64) * 2654435761
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    y = torch.full((n, d), float("nan"), dtype=torch.float32, device=dev)
+    _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 5, x.data_ptr(), d, s))
+    tail = oracle.init(hashes[-3:].cpu().numpy().view(np.uint64), d, 5)
+    np.testing.assert_array_equal(x[-3:].cpu().numpy(), tail)                       # init reaches the last rows
+    _hip.check(L.cleora_propagate_dev(g.handle, 0, x.data_ptr(), d, d, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, None, s))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(y).all())                                             # every row was written
+    c2 = col.view(n, deg).long()
+    want = (x[c2[:, 0]] * 0.5 + x[c2[:, 1]] * 0.5)
+    want = want / want.norm(dim=1, keepdim=True).clamp(min=1e-10)
+    assert float((y - want).abs().max()) < 1e-6
+    q = torch.tensor([0.6, 0.0, 0.8], dtype=torch.float32, device=dev)
+    sc = torch.full((n,), float("nan"), dtype=torch.float32, device=dev)
+    _hip.check(L.cleora_cosine_scores_dev(y.data_ptr(), d, n, d, q.data_ptr(), sc.data_ptr(), s))
+    torch.cuda.synchronize()
+    assert float((sc - (y * q).sum(1)).abs().max()) < 1e-5          # (not y @ q: the BLAS gemv is itself wrong beyond 2^24 rows)

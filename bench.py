@@ -289,7 +289,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
                          "launches": calls, "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0},
+                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                         # SURVEY.md §8(d) secondary model: every operand once (lower bound on traffic)
+                         "compulsory_bytes_per_iteration": nnz * 8 + (n + 1) * 8 + 2 * n * d * 4},
             "checks": {"finite": finite, "max_abs_row_norm_minus_1": norm_err},
             "placement_tuning": placement,
         }

@@ -14,6 +14,7 @@
 #include <fstream>
 #include <string>
 #include <string_view>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -210,8 +211,9 @@ namespace {
 //   A  parallel over line chunks : parse_line + XXH64 of every token        (pipeline.rs:223-240, entity.rs:109-114)
 //   B  sequential, line order    : first-seen interning, Row::occurrence / row_sum, hyperedge_trim_n
 //                                  partitions                              (sparse_matrix_builder.rs:58-70,170-233)
-//   C  parallel over ROW RANGES  : thread t owns rows [lo_t, hi_t) and accumulates E[r, c] for its rows
-//                                  while scanning the hyperedges in order (no locks, no atomics)
+//   C  parallel, two steps       : producers route every E[r, c] update of their chunk of hyperedges to the
+//                                  bucket of the row's owner (rows are cut into ranges of equal work);
+//                                  each owner drains its buckets in chunk order = line order (no locks)
 //   D  parallel per row range    : sort by (row, col), Markov normalisation; ranges concatenate into CSR
 struct ParsedLine {
     uint32_t tok_begin = 0;   // into Parsed::hash / Parsed::span
@@ -263,6 +265,13 @@ struct Builder {
 
     cleora_hostgraph *build(const std::vector<std::string_view> &lines) {
         const size_t nl = lines.size();
+        const bool timing = getenv("CLEORA_HOST_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
+            if (timing) fprintf(stderr, "[cleora_host] %-28s %8.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
+            t0 = now();
+        };
+        auto t0 = now();
         unsigned T = threads ? threads : 1;
         if (nl < 20000) T = 1;
         // ---- A ----
@@ -277,6 +286,7 @@ struct Builder {
                 });
             for (auto &th : pool) th.join();
         }
+        lap("A parse + hash", t0);
         // ---- B ----
         Interner interner;
         auto *g = new cleora_hostgraph();
@@ -330,35 +340,91 @@ struct Builder {
             chunks[t] = Parsed();  // release
         }
         const size_t n = g->ids.size();
+        lap("B intern + row stats", t0);
         // ---- C + D ----
         unsigned T2 = (hypers.size() < 20000 || n < 1024) ? 1 : T;
         struct Part { std::vector<std::pair<uint64_t, float>> ent; };
         std::vector<Part> parts(T2);
+        // contiguous row ranges of (about) equal WORK, not equal row count: first-seen order puts the
+        // popular entities first, and Row::occurrence counts the pair updates a row takes part in
+        std::vector<uint32_t> bound(T2 + 1, (uint32_t)n);
         {
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < T2; ++t)
-                pool.emplace_back([&, t] {
-                    const uint32_t lo = (uint32_t)(n * t / T2), hi = (uint32_t)(n * (t + 1) / T2);
-                    EdgeTable edges;
-                    auto add = [&](uint32_t r, uint32_t c, float v) { if (r >= lo && r < hi) edges.add(r, c, v); };
-                    for (const Hyper &h : hypers) {
-                        const uint32_t *a = nodes.data() + h.begin, *b = a + h.na;
-                        auto combos = [&](size_t a0, size_t a1, size_t b0, size_t b1) {
-                            for (size_t i = a0; i < a1; ++i)
-                                for (size_t j = b0; j < b1; ++j) { add(a[i], b[j], h.value); add(b[j], a[i], h.value); }
-                        };
-                        combos(0, h.ah, 0, h.bh);        // high x high
-                        combos(0, h.ah, h.bh, h.nb);     // high x low
-                        combos(h.ah, h.na, 0, h.bh);     // low  x high   (low x low dropped)
-                    }
-                    auto &ent = parts[t].ent;
-                    ent.reserve(edges.count);
-                    for (size_t i = 0; i < edges.keys.size(); ++i)
-                        if (edges.keys[i] != EdgeTable::EMPTY) ent.emplace_back(edges.keys[i], edges.vals[i]);
-                    std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
-                });
-            for (auto &th : pool) th.join();
+            uint64_t total = 0;
+            for (size_t r = 0; r < n; ++r) total += occurrence[r];
+            uint64_t acc = 0;
+            unsigned next = 1;
+            bound[0] = 0;
+            for (size_t r = 0; r < n && next < T2; ++r) {
+                acc += occurrence[r];
+                while (next < T2 && acc * T2 >= total * next) bound[next++] = (uint32_t)(r + 1);
+            }
         }
+        if (T2 == 1) {
+            EdgeTable edges;
+            for (const Hyper &h : hypers) {
+                const uint32_t *a = nodes.data() + h.begin, *b = a + h.na;
+                auto combos = [&](size_t a0, size_t a1, size_t b0, size_t b1) {
+                    for (size_t i = a0; i < a1; ++i)
+                        for (size_t j = b0; j < b1; ++j) { edges.add(a[i], b[j], h.value); edges.add(b[j], a[i], h.value); }
+                };
+                combos(0, h.ah, 0, h.bh);        // high x high
+                combos(0, h.ah, h.bh, h.nb);     // high x low
+                combos(h.ah, h.na, 0, h.bh);     // low  x high   (low x low dropped)
+            }
+            auto &ent = parts[0].ent;
+            ent.reserve(edges.count);
+            for (size_t i = 0; i < edges.keys.size(); ++i)
+                if (edges.keys[i] != EdgeTable::EMPTY) ent.emplace_back(edges.keys[i], edges.vals[i]);
+            std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
+        } else {
+            // C1: producers (one per contiguous chunk of hyperedges) route every update to the bucket
+            //     of the row's owner;  C2: owner t drains bucket[0][t], bucket[1][t], ... — i.e. its
+            //     updates in global line order — into a private table, then sorts its rows.
+            struct Upd { uint32_t r, c; float v; };
+            std::vector<uint16_t> owner_of(n);
+            for (unsigned t = 0; t < T2; ++t)
+                for (uint32_t r = bound[t]; r < bound[t + 1]; ++r) owner_of[r] = (uint16_t)t;
+            std::vector<std::vector<std::vector<Upd>>> bucket(T2, std::vector<std::vector<Upd>>(T2));
+            {
+                std::vector<std::thread> pool;
+                const size_t nh = hypers.size();
+                for (unsigned sidx = 0; sidx < T2; ++sidx)
+                    pool.emplace_back([&, sidx] {
+                        auto &mine = bucket[sidx];
+                        auto emit = [&](uint32_t r, uint32_t c, float v) { mine[owner_of[r]].push_back({r, c, v}); };
+                        for (size_t k = nh * sidx / T2; k < nh * (sidx + 1) / T2; ++k) {
+                            const Hyper &h = hypers[k];
+                            const uint32_t *a = nodes.data() + h.begin, *b = a + h.na;
+                            auto combos = [&](size_t a0, size_t a1, size_t b0, size_t b1) {
+                                for (size_t i = a0; i < a1; ++i)
+                                    for (size_t j = b0; j < b1; ++j) { emit(a[i], b[j], h.value); emit(b[j], a[i], h.value); }
+                            };
+                            combos(0, h.ah, 0, h.bh);
+                            combos(0, h.ah, h.bh, h.nb);
+                            combos(h.ah, h.na, 0, h.bh);
+                        }
+                    });
+                for (auto &th : pool) th.join();
+            }
+            {
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < T2; ++t)
+                    pool.emplace_back([&, t] {
+                        EdgeTable edges;
+                        for (unsigned sidx = 0; sidx < T2; ++sidx) {
+                            for (const Upd &u : bucket[sidx][t]) edges.add(u.r, u.c, u.v);
+                            std::vector<Upd>().swap(bucket[sidx][t]);
+                        }
+                        auto &ent = parts[t].ent;
+                        ent.reserve(edges.count);
+                        for (size_t i = 0; i < edges.keys.size(); ++i)
+                            if (edges.keys[i] != EdgeTable::EMPTY) ent.emplace_back(edges.keys[i], edges.vals[i]);
+                        std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
+                    });
+                for (auto &th : pool) th.join();
+            }
+        }
+        lap("C accumulate + sort", t0);
         // reduce (sparse_matrix_builder.rs:275-343): rows ascending = parts in order
         size_t nnz = 0;
         std::vector<size_t> base(T2 + 1, 0);
@@ -384,6 +450,7 @@ struct Builder {
             for (auto &th : pool) th.join();
         }
         for (size_t r = 0; r < n; ++r) g->rowptr[r + 1] += g->rowptr[r];
+        lap("D normalise + CSR", t0);
         return g;
     }
 };

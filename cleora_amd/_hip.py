@@ -46,6 +46,7 @@ SIGNATURES = {
                                         ctypes.POINTER(vp)]),
     "cleora_graph_destroy": (c_int, [vp]),
     "cleora_graph_get_info": (c_int, [vp, ctypes.POINTER(GraphInfo)]),
+    "cleora_graph_set_hot_cache": (c_int, [vp, c_i64]),
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
     "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
@@ -182,6 +183,10 @@ class Graph:
         gi = GraphInfo()
         check(lib().cleora_graph_get_info(self.handle, ctypes.byref(gi)))
         return gi
+
+    def set_hot_cache(self, hot_bytes):
+        """-1 automatic, 0 off, > 0 forced byte budget (include/cleora_hip.h)."""
+        check(lib().cleora_graph_set_hot_cache(self.handle, int(hot_bytes)))
 
     def set_timing(self, enable):
         check(lib().cleora_graph_set_timing(self.handle, 1 if enable else 0))

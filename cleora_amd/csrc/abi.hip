@@ -139,6 +139,7 @@ void free_graph(cleora_graph *g) {
     (void)hipFree(g->seg_row);
     (void)hipFree(g->seg_begin);
     (void)hipFree(g->hub_partial);
+    (void)hipFree(g->col_hot);
     for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_used) (void)hipEventDestroy(e);
     delete g;
@@ -317,6 +318,18 @@ int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info) {
     info->hub_segment = g->hub_segment;
     info->device = g->device;
     info->has_symmetric = g->val[1] != nullptr;
+    return CLEORA_OK;
+}
+
+int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    std::lock_guard<std::mutex> lock(g->mu);
+    g->hot_bytes = hot_bytes;
+    g->hot_rows_target = 0;   // rebuild (or drop) the marks on the next launch
+    if (hot_bytes == 0 && g->col_hot) {
+        (void)hipFree(g->col_hot);
+        g->col_hot = nullptr;
+    }
     return CLEORA_OK;
 }
 

@@ -69,6 +69,12 @@ struct cleora_graph {
     mutable float *hub_partial = nullptr;
     mutable uint64_t hub_partial_elems = 0;
 
+    // hot-column marking for the gather cache policy (hot.hip): col with bit 31 set on the most
+    // referenced rows; hot_bytes < 0 = automatic, 0 = off, > 0 = forced byte budget
+    mutable int64_t hot_bytes = -1;
+    mutable uint32_t *col_hot = nullptr;
+    mutable uint64_t hot_rows_target = 0;
+
     // optional per-kernel timing (cleora_graph_set_timing): 4 events per propagate call,
     // recorded on the launch stream: [hub_partial | rows | hub_finish]
     mutable bool timing = false;
@@ -85,6 +91,8 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
                   float *row_sumsq, hipStream_t stream);
+// hot.hip
+const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx);
 // rowops.hip
 int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, float *x, uint64_t ldx,
                 hipStream_t stream);

@@ -46,6 +46,7 @@ struct SpmmArgs {
     const float *val;
     const float *x;
     uint64_t ldx;
+    uint64_t x_bytes;      // span of x (whole-matrix buffer descriptor of the sub-wave hot path)
     uint64_t n_items;      // hub segments + rows
     uint64_t n_segments;
     uint32_t hub_threshold;
@@ -117,8 +118,55 @@ __device__ __forceinline__ void store_row(float *__restrict__ p, int gl, uint32_
     }
 }
 
+// One gathered row.  HOT: bit 31 of the column index marks a frequently referenced row; those are
+// loaded with the default cache policy and every other (cold) row non-temporally, so the cold stream
+// does not evict the hot set (hot.hip: -10 % at C3).  The
+// policy is an immediate of buffer_load, so the row goes through a buffer descriptor: built from the
+// (wave-uniform) row pointer when a whole wavefront owns the row — its num_records = d*4 also does
+// the tail bounds check — or spanning the whole matrix (< 4 GiB) for sub-wave groups.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int G, int V, int W, bool FULL, bool HOT>
+__device__ __forceinline__ void gather_row(const SpmmArgs &a, uint32_t c, int gl, uint32_t d,
+                                           float (&r)[V][W]) {
+    if constexpr (!HOT) {
+        load_row<G, V, W, FULL>(a.x + (uint64_t)c * a.ldx, gl, d, r);
+    } else {
+        static_assert(W == 4, "hot policy is implemented for the float4 path");
+        const uint32_t cc = c & 0x7fffffffu;
+        const bool hot = (c >> 31) != 0;
+        if constexpr (G == 64) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(a.x + (uint64_t)cc * a.ldx), 0,
+                                                              (int)(d * 4u), 0x00020000);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int off = (v * 64 + gl) * 16;
+                u32x4 t;
+                if (hot) t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                else t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2);       // aux 2 = nt
+                r[v][0] = __uint_as_float(t.x); r[v][1] = __uint_as_float(t.y);
+                r[v][2] = __uint_as_float(t.z); r[v][3] = __uint_as_float(t.w);
+            }
+        } else {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)(uint32_t)a.x_bytes, 0x00020000);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const uint32_t j = (uint32_t)(v * G + gl) * 4u;
+                const int off = (int)((uint32_t)((uint64_t)cc * a.ldx + j) * 4u);
+                u32x4 t = {0u, 0u, 0u, 0u};
+                if (FULL || j < d) {
+                    if (hot) t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+                    else t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 2);
+                }
+                r[v][0] = __uint_as_float(t.x); r[v][1] = __uint_as_float(t.y);
+                r[v][2] = __uint_as_float(t.z); r[v][3] = __uint_as_float(t.w);
+            }
+        }
+    }
+}
+
 // acc += sum over edges [beg, end) in stored order.  For G == 64 beg/end are wave-uniform.
-template <int G, int V, int W, bool FULL>
+template <int G, int V, int W, bool FULL, bool HOT = false>
 __device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint64_t end, int gl,
                                            int gbase, float (&acc)[V][W]) {
     constexpr int U = (8 / V) > 0 ? (8 / V) : 1;
@@ -137,7 +185,7 @@ __device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t c = bcast_u32<G>(cv, k + u, gbase);
-                load_row<G, V, W, FULL>(a.x + (uint64_t)c * a.ldx, gl, d, r[u]);
+                gather_row<G, V, W, FULL, HOT>(a, c, gl, d, r[u]);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -152,7 +200,7 @@ __device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint
             float r[V][W];
             const uint32_t c = bcast_u32<G>(cv, k, gbase);
             const float w = bcast_f32<G>(wv, k, gbase);
-            load_row<G, V, W, FULL>(a.x + (uint64_t)c * a.ldx, gl, d, r);
+            gather_row<G, V, W, FULL, HOT>(a, c, gl, d, r);
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
@@ -251,7 +299,7 @@ __device__ __forceinline__ void zero(float (&acc)[V][W]) {
 // ---- main kernel ---------------------------------------------------------------------------
 // Work items: first the hub SEGMENTS (so the longest work starts first), then one item per row.
 // A segment item writes its partial sum to scratch; a row item runs the epilogue and writes Y.
-template <int G, int V, int W, bool FULL>
+template <int G, int V, int W, bool FULL, bool HOT = false>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
@@ -287,7 +335,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
     }
     float acc[V][W];
     zero<G, V, W>(acc);
-    accumulate<G, V, W, FULL>(a, beg, end, gl, gbase, acc);
+    accumulate<G, V, W, FULL, HOT>(a, beg, end, gl, gbase, acc);
     if (active) {
         if (is_seg) store_row<G, V, W, FULL>(a.partial + item * (uint64_t)a.r.d, gl, a.r.d, acc);
         else finish_row<G, V, W, FULL>(a.r, row, gl, gbase, acc);
@@ -489,8 +537,22 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
     a.n_items = g->n_hub_segments + g->n_rows;
     if (a.n_items) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
-            hipLaunchKernelGGL((spmm_rows_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value, (decltype(FULL)::value != 0)>),
-                               grid_for(a.n_items, 256 / decltype(G)::value), dim3(256), 0, stream, a);
+            constexpr int kG = decltype(G)::value, kV = decltype(V)::value, kW = decltype(W)::value;
+            constexpr bool kFull = decltype(FULL)::value != 0;
+            if constexpr (kW == 4) {
+                // hot-column cache policy: needs the marked column copy and, for sub-wave groups, a
+                // matrix that one buffer descriptor can span
+                const uint32_t *hot = (kG == 64 || a.x_bytes < (1ull << 32)) ? ensure_hot_cols(g, d, a.ldx) : nullptr;
+                if (hot) {
+                    SpmmArgs h = a;
+                    h.col = hot;
+                    hipLaunchKernelGGL((spmm_rows_kernel<kG, kV, kW, kFull, true>),
+                                       grid_for(h.n_items, 256 / kG), dim3(256), 0, stream, h);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((spmm_rows_kernel<kG, kV, kW, kFull, false>),
+                               grid_for(a.n_items, 256 / kG), dim3(256), 0, stream, a);
         });
     }
     mark(g, stream);
@@ -543,6 +605,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
     a.val = g->val[kind];
     a.x = x;
     a.ldx = ldx;
+    a.x_bytes = g->n_cols * ldx * sizeof(float);
     a.hub_threshold = g->hub_threshold;
     a.seg_row = g->seg_row;
     a.seg_begin = g->seg_begin;

@@ -103,6 +103,14 @@ int cleora_graph_create_dev(int device, uint64_t n_rows, uint64_t n_cols, uint64
 int cleora_graph_destroy(cleora_graph *g);
 int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info);
 
+/* Gather cache policy (no reference counterpart; changes no result bit).  The most frequently
+ * referenced embedding rows — those with the largest in-degree, up to `hot_bytes` of X — are gathered
+ * with the default cache policy and all other rows non-temporally, so the cold stream does not evict
+ * the hot set: measured -10 % on the C3 graph.
+ * hot_bytes < 0: automatic (768 MiB budget when X is >= 1 GiB; the default), 0: off, > 0: forced budget.
+ * Needs n_cols < 2^31 (the mark is bit 31 of a private copy of `col`: +4 B per edge of HBM). */
+int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes);
+
 /* Per-kernel timing for roofline reporting (no reference counterpart).  While enabled, every
  * cleora_propagate_dev call on this graph brackets its three kernels with HIP events on the
  * launch stream.  cleora_graph_get_timing waits for the recorded events, returns the summed

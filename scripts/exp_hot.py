@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Experiment: hot/cold cache policy split for the gathers (bit 31 of col = hot row)."""
+import ctypes, os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cleora_amd import synth
+L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libexp.so"))
+vp = ctypes.c_void_p
+L.exp_launch.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint32, vp, vp]
+dev = torch.device("cuda:0")
+g = synth.power_law_graph(10_000_000, 95_000_000, 2, dev)
+n, nnz, d = g["n"], g["nnz"], 256
+col = g["col"]
+indeg = torch.bincount(col.long(), minlength=n)
+x = torch.randn((n, d), device=dev); x /= x.norm(dim=1, keepdim=True)
+ys = [torch.zeros_like(x) for _ in range(3)]
+s = torch.cuda.current_stream().cuda_stream
+def run(v, colt, y, reps=4):
+    for _ in range(2):
+        assert L.exp_launch(v, g["rowptr"].data_ptr(), colt.data_ptr(), g["val_left"].data_ptr(), x.data_ptr(), y.data_ptr(), n, 1024, None, s) == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        L.exp_launch(v, g["rowptr"].data_ptr(), colt.data_ptr(), g["val_left"].data_ptr(), x.data_ptr(), y.data_ptr(), n, 1024, None, s)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+# pick the y buffer that pairs fastest with x for the baseline, use it for everything
+base = [(run(0, col, y), y) for y in ys]
+t0, y = min(base, key=lambda p: p[0])
+print("baseline per y buffer:", [round(t, 2) for t, _ in base], flush=True)
+ref = y.clone()
+print(json.dumps({"variant": "buffer loads, all default", "ms": round(run(18, col, y), 2), "baseline_ms": round(t0, 2)}), flush=True)
+for hot_nodes in (250_000, 500_000, 1_000_000, 2_000_000, 3_000_000, 5_000_000, 9_999_000):
+    thr = torch.topk(indeg, hot_nodes).values[-1]
+    hot = indeg >= thr
+    frac = float(indeg[hot].sum()) / nnz
+    colh = (col.long() | (hot[col.long()].long() << 31)).to(torch.int32)   # bit 31 = hot
+    ms = run(11, colh, y)
+    print(json.dumps({"hot_nodes": int(hot.sum()), "hot_share_of_gathers": round(frac, 3), "variant": "cold nt / hot default",
+                      "ms": round(ms, 2), "equal": bool(torch.equal(y, ref))}), flush=True)
+thr = torch.topk(indeg, 1_000_000).values[-1]
+hot = indeg >= thr
+colh = (col.long() | (hot[col.long()].long() << 31)).to(torch.int32)
+for v, name in ((12, "cold nt / hot sc0"), (13, "cold nt / hot sc1"), (14, "cold nt+sc1 / hot default"), (15, "cold sc1 / hot default"),
+                (16, "cold sc0 / hot default"), (17, "cold nt+sc0 / hot default")):
+    print(json.dumps({"hot_nodes": int(hot.sum()), "variant": name, "ms": round(run(v, colh, y), 2), "equal": bool(torch.equal(y, ref))}), flush=True)

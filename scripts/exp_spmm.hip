@@ -169,6 +169,100 @@ __global__ __launch_bounds__(256) void k_lds(const Args a) {
     }
 }
 
+// One 1 KiB row through a buffer descriptor built from the (wave-uniform) row pointer; the cache
+// policy is an immediate of the instruction, so the two flavours cannot be merged by the compiler.
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+template <int AUX_A = 2, int AUX_B = 0>
+__device__ __forceinline__ v4f ld_policy(const float *rowp, int lane, bool first) {
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, 0, 1024, 0x00020000);
+    v4u t;
+    if (first) t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, AUX_A);   // aux: 1 = sc0, 2 = nt, 16 = sc1
+    else t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, 0, AUX_B);
+    v4f r;
+    r.x = __uint_as_float(t.x); r.y = __uint_as_float(t.y); r.z = __uint_as_float(t.z); r.w = __uint_as_float(t.w);
+    return r;
+}
+
+// Same idea with plain global loads: the nt flavour reads through a pointer laundered by an empty asm so
+// the compiler cannot merge it with the default-policy load of the other branch (it would drop `nt`).
+__device__ __forceinline__ v4f ld_global_policy(const float *p, bool nt) {
+    if (nt) {
+        const float *q = p;
+        asm volatile("" : "+v"(q));
+        return __builtin_nontemporal_load(reinterpret_cast<const v4f *>(q));
+    }
+    return *reinterpret_cast<const v4f *>(p);
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_hot_global(const Args a) {
+    const int lane = threadIdx.x & 63;
+    uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n) return;
+    row = uni64(row);
+    uint64_t beg = uni64(a.rowptr[row]), end = uni64(a.rowptr[row + 1]);
+    if (end - beg > a.hub_threshold) return;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint64_t e = beg; e < end; e += 64) {
+        const uint32_t cnt = (end - e) < 64 ? (uint32_t)(end - e) : 64u;
+        uint32_t cv = 0;
+        float wv = 0.f;
+        if ((uint32_t)lane < cnt) { cv = a.col[e + lane]; wv = a.val[e + lane]; }
+        uint32_t k = 0;
+        for (; k + U <= cnt; k += U) {
+            v4f r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t c = rl(cv, k + u);
+                r[u] = ld_global_policy(a.x + (uint64_t)(c & 0x7fffffffu) * 256 + lane * 4, (c >> 31) != 0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) fma_sep(acc, rlf(wv, k + u), r[u]);
+        }
+        for (; k < cnt; ++k) {
+            const uint32_t c = rl(cv, k);
+            fma_sep(acc, rlf(wv, k), ld_global_policy(a.x + (uint64_t)(c & 0x7fffffffu) * 256 + lane * 4, (c >> 31) != 0));
+        }
+    }
+    finish(acc, a.y + row * 256, lane, false);
+}
+
+// Hot/cold split: bit 31 of the column index marks a "hot" (high in-degree) row; hot rows are gathered
+// with the default cache policy, cold rows non-temporally, to keep the hot set resident in L2/MALL.
+template <int U, bool HOT_NT, int AUX_A = 2, int AUX_B = 0>
+__global__ __launch_bounds__(256) void k_hot(const Args a) {
+    const int lane = threadIdx.x & 63;
+    uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n) return;
+    row = uni64(row);
+    uint64_t beg = uni64(a.rowptr[row]), end = uni64(a.rowptr[row + 1]);
+    if (end - beg > a.hub_threshold) return;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (uint64_t e = beg; e < end; e += 64) {
+        const uint32_t cnt = (end - e) < 64 ? (uint32_t)(end - e) : 64u;
+        uint32_t cv = 0;
+        float wv = 0.f;
+        if ((uint32_t)lane < cnt) { cv = a.col[e + lane]; wv = a.val[e + lane]; }
+        uint32_t k = 0;
+        for (; k + U <= cnt; k += U) {
+            v4f r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t c = rl(cv, k + u);
+                r[u] = ld_policy<AUX_A, AUX_B>(a.x + (uint64_t)(c & 0x7fffffffu) * 256, lane, (c >> 31) != (HOT_NT ? 1u : 0u));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) fma_sep(acc, rlf(wv, k + u), r[u]);
+        }
+        for (; k < cnt; ++k) {
+            const uint32_t c = rl(cv, k);
+            v4f r = ld_policy<AUX_A, AUX_B>(a.x + (uint64_t)(c & 0x7fffffffu) * 256, lane, (c >> 31) != (HOT_NT ? 1u : 0u));
+            fma_sep(acc, rlf(wv, k), r);
+        }
+    }
+    finish(acc, a.y + row * 256, lane, false);
+}
+
 extern "C" int exp_launch(int variant, const uint64_t *rowptr, const uint32_t *col, const float *val,
                           const float *x, float *y, uint64_t n, uint32_t hub_threshold,
                           const uint32_t *order, void *stream) {
@@ -186,6 +280,17 @@ extern "C" int exp_launch(int variant, const uint64_t *rowptr, const uint32_t *c
         case 7: hipLaunchKernelGGL((k_lds<32, 2048>), dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, a); break;
         case 8: hipLaunchKernelGGL((k_lds<64, 4096>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, a); break;
         case 9: hipLaunchKernelGGL((k_basic<8, false, false, 128>), dim3((unsigned)((n + 1) / 2)), dim3(128), 0, s, a); break;
+        case 10: hipLaunchKernelGGL((k_hot<8, false>), dim3(g4), dim3(256), 0, s, a); break;  // HOT rows nt (control)
+        case 11: hipLaunchKernelGGL((k_hot<8, true>), dim3(g4), dim3(256), 0, s, a); break;   // COLD rows nt, hot default
+        // k_hot<U, true, A, B>: COLD rows (bit 31 clear) get AUX_A, hot rows AUX_B
+        case 12: hipLaunchKernelGGL((k_hot<8, true, 2, 1>), dim3(g4), dim3(256), 0, s, a); break;    // hot nt, cold sc0
+        case 13: hipLaunchKernelGGL((k_hot<8, true, 2, 16>), dim3(g4), dim3(256), 0, s, a); break;   // hot nt, cold sc1
+        case 14: hipLaunchKernelGGL((k_hot<8, true, 18, 0>), dim3(g4), dim3(256), 0, s, a); break;   // hot nt+sc1
+        case 15: hipLaunchKernelGGL((k_hot<8, true, 16, 0>), dim3(g4), dim3(256), 0, s, a); break;   // hot sc1
+        case 16: hipLaunchKernelGGL((k_hot<8, true, 1, 0>), dim3(g4), dim3(256), 0, s, a); break;    // hot sc0
+        case 17: hipLaunchKernelGGL((k_hot<8, true, 3, 0>), dim3(g4), dim3(256), 0, s, a); break;    // hot nt+sc0
+        case 18: hipLaunchKernelGGL((k_hot<8, true, 0, 0>), dim3(g4), dim3(256), 0, s, a); break;    // buffer loads, all default
+        case 19: hipLaunchKernelGGL((k_hot_global<8>), dim3(g4), dim3(256), 0, s, a); break;       // global loads, hot nt
         default: return -1;
     }
     return (int)hipGetLastError();

@@ -186,3 +186,29 @@ def test_embed_loop_bit_exact():
                               _hip.ptr(out), ctypes.byref(it)))
     assert it.value == it_want and it_want < 50
     np.testing.assert_array_equal(out, want)
+
+
+@pytest.mark.parametrize("d", [256, 512, 1024, 2048, 128, 64, 32, 8, 100, 260, 1000])
+def test_hot_column_policy_changes_no_bit(d):
+    """The gather cache policy (hot rows = most referenced columns, loaded `nt` through a buffer
+    descriptor) must not change any result bit; forced on with a small byte budget."""
+    n = 3000 if d <= 512 else 700
+    rng = np.random.default_rng(900 + d)
+    deg = rng.poisson(10, n).astype(np.int64)
+    deg[5] = 2500                                                    # one split row
+    rowptr = np.zeros(n + 1, np.uint64)
+    rowptr[1:] = np.cumsum(deg).astype(np.uint64)
+    nnz = int(rowptr[-1])
+    col = np.minimum((rng.pareto(1.0, nnz) * 20).astype(np.int64), n - 1).astype(np.uint32)   # skewed popularity
+    val = rng.random(nnz, dtype=np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, val)
+    base = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
+    for budget in (d * 4 * 50, d * 4 * 1000):
+        g.set_hot_cache(budget)
+        np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM), base)
+    g.set_hot_cache(0)
+    np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM), base)
+    mask = np.ones(n, bool)
+    mask[5] = False
+    np.testing.assert_array_equal(base[mask], oracle.l2_normalize(oracle.spmm(rowptr, col, val, x))[mask])

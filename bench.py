@@ -269,6 +269,8 @@ def main():
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
+        hot_rows = int(blocks[0].info().hot_rows)      # gather cache policy (cleora_graph_set_hot_cache), 0 = inactive
+        kernel_name = kernel_name[:-1] + (",true>" if hot_rows else ",false>")
         out = {
             "metric": "propagate edges*dim/sec (SpMM + fused L2 norm"
                       + ("" if world == 1 else (" + all-gather of X" if partition == "row" else " + all-reduce of row norms"))
@@ -288,7 +290,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
-                         "launches": calls, "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
+                         "launches": calls, "gather_cache_policy_hot_rows": hot_rows,
+                         "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
                          "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
                          # SURVEY.md §8(d) secondary model: every operand once (lower bound on traffic)
                          "compulsory_bytes_per_iteration": nnz * 8 + (n + 1) * 8 + 2 * n * d * 4},

@@ -23,7 +23,7 @@ vp = ctypes.c_void_p
 
 class GraphInfo(ctypes.Structure):
     _fields_ = [("n_rows", c_u64), ("n_cols", c_u64), ("nnz", c_u64), ("n_hub_rows", c_u64),
-                ("n_hub_segments", c_u64), ("device_bytes", c_u64), ("hub_threshold", c_u32),
+                ("n_hub_segments", c_u64), ("device_bytes", c_u64), ("hot_rows", c_u64), ("hub_threshold", c_u32),
                 ("hub_segment", c_u32), ("device", ctypes.c_int32), ("has_symmetric", ctypes.c_int32)]
 
 

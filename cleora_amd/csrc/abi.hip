@@ -313,7 +313,11 @@ int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info) {
     info->nnz = g->nnz;
     info->n_hub_rows = g->n_hub_rows;
     info->n_hub_segments = g->n_hub_segments;
-    info->device_bytes = g->device_bytes;
+    {
+        std::lock_guard<std::mutex> lock(g->mu);
+        info->device_bytes = g->device_bytes + (g->col_hot ? g->nnz * sizeof(uint32_t) : 0);
+        info->hot_rows = (g->col_hot && g->hot_rows_target) ? g->hot_rows_marked : 0;
+    }
     info->hub_threshold = g->hub_threshold;
     info->hub_segment = g->hub_segment;
     info->device = g->device;

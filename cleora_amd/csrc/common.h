@@ -74,6 +74,8 @@ struct cleora_graph {
     mutable int64_t hot_bytes = -1;
     mutable uint32_t *col_hot = nullptr;
     mutable uint64_t hot_rows_target = 0;
+    mutable uint64_t hot_rows_marked = 0;
+    mutable uint32_t auto_launches = 0;     // automatic mode arms itself on the third eligible launch
 
     // optional per-kernel timing (cleora_graph_set_timing): 4 events per propagate call,
     // recorded on the launch stream: [hub_partial | rows | hub_finish]

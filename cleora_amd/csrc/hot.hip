@@ -25,13 +25,21 @@ __global__ __launch_bounds__(256) void indegree_kernel(const uint32_t *__restric
         atomicAdd(&indeg[col[i]], 1u);
 }
 
+// Block-private histogram in LDS (in-degrees cluster on a few small values: global atomics on those bins
+// serialised to 23 ms at n = 10M; this is ~0.1 ms), then one global atomic per non-empty bin per block.
 __global__ __launch_bounds__(256) void degree_hist_kernel(const uint32_t *__restrict__ indeg, uint64_t n,
                                                           uint32_t *__restrict__ bins) {
+    __shared__ uint32_t sm[kDegBins];
+    for (int b = threadIdx.x; b < kDegBins; b += 256) sm[b] = 0;
+    __syncthreads();
     for (uint64_t i = CLEORA_LINEAR_BLOCK() * 256 + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * gridDim.y * 256) {
         const uint32_t v = indeg[i];
-        atomicAdd(&bins[v < kDegBins - 1 ? v : kDegBins - 1], 1u);
+        atomicAdd(&sm[v < kDegBins - 1 ? v : kDegBins - 1], 1u);
     }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kDegBins; b += 256)
+        if (sm[b]) atomicAdd(&bins[b], sm[b]);
 }
 
 __global__ __launch_bounds__(256) void mark_kernel(const uint32_t *__restrict__ col, uint64_t nnz,
@@ -53,8 +61,14 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
     const uint64_t row_bytes = (uint64_t)d * sizeof(float);
     const uint64_t x_bytes = g->n_cols * ldx * sizeof(float);
     uint64_t budget;
-    if (g->hot_bytes < 0) {                           // auto: only when X is far larger than the caches
+    if (g->hot_bytes < 0) {                           // auto: only when X is far larger than the caches ...
         if (x_bytes < (1ull << 30)) return nullptr;
+        // ... and a row fills a whole wavefront's load: on 128 / 64 / 32-column panels (the column
+        // partition at P = 2 / 4 / 8) the policy measured +0 / +2 / +7 % (scripts/column_probe.py).
+        if (d < 256) return nullptr;
+        // ... and the graph is evidently being iterated: the marks cost ~13 ms to build at C3 scale
+        // (one pass of random atomics over col) and return ~3 ms per launch.
+        if (g->auto_launches < 2) { ++g->auto_launches; return nullptr; }
         budget = 768ull << 20;
     } else {
         budget = (uint64_t)g->hot_bytes;
@@ -79,8 +93,8 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
     std::vector<uint32_t> h(kDegBins);
     bool ok = hipMemcpy(h.data(), bins, kDegBins * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
     uint32_t threshold = kDegBins;                     // smallest in-degree that is still "hot"
+    uint64_t cum = 0;
     if (ok) {
-        uint64_t cum = 0;
         for (int b = kDegBins - 1; b >= 1; --b) {
             if (cum + h[b] > want && cum > 0) break;
             cum += h[b];
@@ -94,6 +108,7 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
     (void)hipFree(bins);
     if (!ok) return nullptr;
     g->hot_rows_target = want;
+    g->hot_rows_marked = cum;
     return g->col_hot;
 }
 

@@ -61,6 +61,7 @@ typedef struct cleora_graph_info {
     uint64_t n_hub_rows;      /* rows longer than hub_threshold: split across waves */
     uint64_t n_hub_segments;
     uint64_t device_bytes;    /* HBM held by the handle */
+    uint64_t hot_rows;        /* rows the gather cache policy currently keeps cacheable; 0 = policy inactive */
     uint32_t hub_threshold, hub_segment;
     int32_t device;
     int32_t has_symmetric;

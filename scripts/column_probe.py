@@ -28,13 +28,15 @@ for P in (1, 2, 4, 8):
             rowsq.mul_(float(P))  # stand-in for the all-reduce (keeps the norms sane)
             be.rowops(y, y, _hip.F_SCALE, 0.0, None, None, rowsq)
         x, y = y, x
-    for _ in range(3): step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): step()
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(json.dumps({"emulated_world": P, "cols_per_rank": dl, "ms_per_iter_without_allreduce": round(ms, 3),
-                      "speedup_vs_P1_upper_bound": None}), flush=True)
+    for hot in (0, -1, 128 << 20, 256 << 20, 512 << 20):      # gather cache policy: off, automatic, forced budgets
+        cg.block.set_hot_cache(hot)
+        for _ in range(3): step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): step()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(json.dumps({"emulated_world": P, "cols_per_rank": dl, "hot_bytes": hot,
+                          "ms_per_iter_without_allreduce": round(ms, 3)}), flush=True)
     del cg, x, y

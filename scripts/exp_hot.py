@@ -31,7 +31,7 @@ t0, y = min(base, key=lambda p: p[0])
 print("baseline per y buffer:", [round(t, 2) for t, _ in base], flush=True)
 ref = y.clone()
 print(json.dumps({"variant": "buffer loads, all default", "ms": round(run(18, col, y), 2), "baseline_ms": round(t0, 2)}), flush=True)
-for hot_nodes in (250_000, 500_000, 1_000_000, 2_000_000, 3_000_000, 5_000_000, 9_999_000):
+for hot_nodes in (30_000, 100_000, 250_000, 500_000, 1_000_000, 2_000_000, 3_000_000, 5_000_000, 9_999_000):
     thr = torch.topk(indeg, hot_nodes).values[-1]
     hot = indeg >= thr
     frac = float(indeg[hot].sum()) / nnz
@@ -43,5 +43,7 @@ thr = torch.topk(indeg, 1_000_000).values[-1]
 hot = indeg >= thr
 colh = (col.long() | (hot[col.long()].long() << 31)).to(torch.int32)
 for v, name in ((12, "cold nt / hot sc0"), (13, "cold nt / hot sc1"), (14, "cold nt+sc1 / hot default"), (15, "cold sc1 / hot default"),
-                (16, "cold sc0 / hot default"), (17, "cold nt+sc0 / hot default")):
+                (16, "cold sc0 / hot default"), (17, "cold nt+sc0 / hot default"),
+                (11, "cold nt / hot default"), (20, "cold nt + nt stores"), (21, "cold nt + nt CSR streams"), (22, "cold nt + nt stores + nt CSR"),
+                (23, "cold nt, 16 gathers in flight"), (24, "cold nt, 4 gathers in flight"), (11, "cold nt / hot default (again)")):
     print(json.dumps({"hot_nodes": int(hot.sum()), "variant": name, "ms": round(run(v, colh, y), 2), "equal": bool(torch.equal(y, ref))}), flush=True)

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void k_hot_global(const Args a) {
 
 // Hot/cold split: bit 31 of the column index marks a "hot" (high in-degree) row; hot rows are gathered
 // with the default cache policy, cold rows non-temporally, to keep the hot set resident in L2/MALL.
-template <int U, bool HOT_NT, int AUX_A = 2, int AUX_B = 0>
+// EXTRA bit 0: Y rows stored non-temporally; bit 1: the CSR col / val streams loaded non-temporally.
+template <int U, bool HOT_NT, int AUX_A = 2, int AUX_B = 0, int EXTRA = 0>
 __global__ __launch_bounds__(256) void k_hot(const Args a) {
     const int lane = threadIdx.x & 63;
     uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -242,7 +243,10 @@ __global__ __launch_bounds__(256) void k_hot(const Args a) {
         const uint32_t cnt = (end - e) < 64 ? (uint32_t)(end - e) : 64u;
         uint32_t cv = 0;
         float wv = 0.f;
-        if ((uint32_t)lane < cnt) { cv = a.col[e + lane]; wv = a.val[e + lane]; }
+        if ((uint32_t)lane < cnt) {
+            if constexpr (EXTRA & 2) { cv = __builtin_nontemporal_load(a.col + e + lane); wv = __builtin_nontemporal_load(a.val + e + lane); }
+            else { cv = a.col[e + lane]; wv = a.val[e + lane]; }
+        }
         uint32_t k = 0;
         for (; k + U <= cnt; k += U) {
             v4f r[U];
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void k_hot(const Args a) {
             fma_sep(acc, rlf(wv, k), r);
         }
     }
-    finish(acc, a.y + row * 256, lane, false);
+    finish(acc, a.y + row * 256, lane, (EXTRA & 1) != 0);
 }
 
 extern "C" int exp_launch(int variant, const uint64_t *rowptr, const uint32_t *col, const float *val,
@@ -283,14 +287,19 @@ extern "C" int exp_launch(int variant, const uint64_t *rowptr, const uint32_t *c
         case 10: hipLaunchKernelGGL((k_hot<8, false>), dim3(g4), dim3(256), 0, s, a); break;  // HOT rows nt (control)
         case 11: hipLaunchKernelGGL((k_hot<8, true>), dim3(g4), dim3(256), 0, s, a); break;   // COLD rows nt, hot default
         // k_hot<U, true, A, B>: COLD rows (bit 31 clear) get AUX_A, hot rows AUX_B
-        case 12: hipLaunchKernelGGL((k_hot<8, true, 2, 1>), dim3(g4), dim3(256), 0, s, a); break;    // hot nt, cold sc0
-        case 13: hipLaunchKernelGGL((k_hot<8, true, 2, 16>), dim3(g4), dim3(256), 0, s, a); break;   // hot nt, cold sc1
-        case 14: hipLaunchKernelGGL((k_hot<8, true, 18, 0>), dim3(g4), dim3(256), 0, s, a); break;   // hot nt+sc1
-        case 15: hipLaunchKernelGGL((k_hot<8, true, 16, 0>), dim3(g4), dim3(256), 0, s, a); break;   // hot sc1
-        case 16: hipLaunchKernelGGL((k_hot<8, true, 1, 0>), dim3(g4), dim3(256), 0, s, a); break;    // hot sc0
-        case 17: hipLaunchKernelGGL((k_hot<8, true, 3, 0>), dim3(g4), dim3(256), 0, s, a); break;    // hot nt+sc0
+        case 12: hipLaunchKernelGGL((k_hot<8, true, 2, 1>), dim3(g4), dim3(256), 0, s, a); break;    // cold nt, hot sc0
+        case 13: hipLaunchKernelGGL((k_hot<8, true, 2, 16>), dim3(g4), dim3(256), 0, s, a); break;   // cold nt, hot sc1
+        case 14: hipLaunchKernelGGL((k_hot<8, true, 18, 0>), dim3(g4), dim3(256), 0, s, a); break;   // cold nt+sc1
+        case 15: hipLaunchKernelGGL((k_hot<8, true, 16, 0>), dim3(g4), dim3(256), 0, s, a); break;   // cold sc1
+        case 16: hipLaunchKernelGGL((k_hot<8, true, 1, 0>), dim3(g4), dim3(256), 0, s, a); break;    // cold sc0
+        case 17: hipLaunchKernelGGL((k_hot<8, true, 3, 0>), dim3(g4), dim3(256), 0, s, a); break;    // cold nt+sc0
         case 18: hipLaunchKernelGGL((k_hot<8, true, 0, 0>), dim3(g4), dim3(256), 0, s, a); break;    // buffer loads, all default
-        case 19: hipLaunchKernelGGL((k_hot_global<8>), dim3(g4), dim3(256), 0, s, a); break;       // global loads, hot nt
+        case 19: hipLaunchKernelGGL((k_hot_global<8>), dim3(g4), dim3(256), 0, s, a); break;       // global loads, hot nt (control)
+        case 20: hipLaunchKernelGGL((k_hot<8, true, 2, 0, 1>), dim3(g4), dim3(256), 0, s, a); break;  // cold nt + nt stores
+        case 21: hipLaunchKernelGGL((k_hot<8, true, 2, 0, 2>), dim3(g4), dim3(256), 0, s, a); break;  // cold nt + nt CSR
+        case 22: hipLaunchKernelGGL((k_hot<8, true, 2, 0, 3>), dim3(g4), dim3(256), 0, s, a); break;  // cold nt + both
+        case 23: hipLaunchKernelGGL((k_hot<16, true, 2, 0, 0>), dim3(g4), dim3(256), 0, s, a); break; // cold nt, 16 in flight
+        case 24: hipLaunchKernelGGL((k_hot<4, true, 2, 0, 0>), dim3(g4), dim3(256), 0, s, a); break;  // cold nt, 4 in flight
         default: return -1;
     }
     return (int)hipGetLastError();

@@ -16,7 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--nodes", type=int, default=10_000_000)
 ap.add_argument("--pairs", type=int, default=95_000_000)
 ap.add_argument("--dim", type=int, default=256)
-ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--iters", type=int, default=7)   # the automatic gather cache policy arms on the third launch
+ap.add_argument("--hot", type=int, default=-1, help="cleora_graph_set_hot_cache: -1 automatic, 0 off, >0 bytes")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 L = _hip.lib()
@@ -24,6 +25,7 @@ g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)
 n, nnz, d = g["n"], g["nnz"], args.dim
 graph = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(),
                                g["val_left"].data_ptr(), None, 0, 0, 0, keepalive=g)
+graph.set_hot_cache(args.hot)
 hashes = synth.entity_hashes(n, 0, dev)
 x = torch.empty((n, d), dtype=torch.float32, device=dev)
 y = torch.empty_like(x)

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Profiling recipe for one round (run on the GPU box through gpurun):
+#   scripts/profile_round.sh r01   ->  gpurun_out/prof_r01/{stats,wstats,fetch,write,fetch_nohot,hit,hit_nohot}
+# then, back in the container, scripts/summarize_profile.py r01 condenses it into profiles/.
+# Counters are collected in passes of their own with nothing but --pmc (no trace domains).
+tag=${1:-r01}
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python "$root/bench.py" --no-cpu-baseline > "$out/bench_stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wstats" -o whiten -- python "$root/scripts/whiten_probe.py" > "$out/whiten_stats.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/write.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/fetch_nohot.log" 2>&1
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/hit.log" 2>&1
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/hit_nohot.log" 2>&1
+timeout 600 python "$root/bench.py" > "$out/bench_plain.log" 2>&1
+tail -1 "$out/bench_plain.log"
+for f in fetch write fetch_nohot hit hit_nohot; do tail -1 "$out/$f.log"; done
+# keep the merge under the gpurun_out size limit: only the summaries that summarize_profile.py reads
+find "$out" -type f ! -name "*_kernel_stats.csv" ! -name "pmc_counter_collection.csv" ! -name "*.log" -delete
+find "$out" -type f -size +8M -exec sh -c 'grep cleora "$1" > "$1.tmp"; head -1 "$1" | cat - "$1.tmp" > "$1.f"; mv "$1.f" "$1"; rm "$1.tmp"' _ {} \;
+du -sh "$out"

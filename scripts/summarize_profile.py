@@ -37,7 +37,7 @@ rows = list(csv.DictReader(open(os.path.join(src, "stats", "bench_kernel_stats.c
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for r in rows[:12]:
+    for r in [r for i, r in enumerate(rows) if i < 10 or "cleora" in r["Name"]]:
         name = r["Name"] if "cleora" in r["Name"] else r["Name"][:90]
         w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                     r["MinNs"], r["MaxNs"], r["StdDev"]])
@@ -76,8 +76,31 @@ for k, c in counters.items():
     w_ = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
     out["kernels"][k] = {"launches": len(c["FETCH_SIZE"]), "FETCH_SIZE_KiB_avg": f, "WRITE_SIZE_KiB_avg": w_,
                          "hbm_bytes_per_launch": f * 1024 * fetch_corr + w_ * 1024 * write_corr}
+
+# 2b. optional comparison passes: the gather cache policy switched off (--hot 0), and L2 hit rates
+def spmm_counters(sub):
+    path = os.path.join(src, sub, "pmc_counter_collection.csv")
+    acc = collections.defaultdict(list)
+    if os.path.exists(path):
+        for r in csv.DictReader(open(path)):
+            if "spmm_rows_kernel" in r["Kernel_Name"] and (sub.endswith("nohot") or "true, true>" in r["Kernel_Name"]):
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+policy = {}
+nohot = spmm_counters("fetch_nohot")
+if nohot:
+    policy["fetch_bytes_per_launch_policy_off"] = nohot["FETCH_SIZE"] * 1024 * fetch_corr
+    policy["fetch_bytes_per_launch_policy_on"] = out["kernels"]["spmm_rows_kernel<64, 1, 4, true, true>"]["FETCH_SIZE_KiB_avg"] * 1024 * fetch_corr
+for sub, key in (("hit", "policy_on"), ("hit_nohot", "policy_off")):
+    c = spmm_counters(sub)
+    if c:
+        policy[f"l2_hit_rate_{key}"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+        policy[f"l2_requests_{key}"] = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
+if policy:
+    out["gather_cache_policy"] = policy
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-dom = [k for k in out["kernels"] if k.startswith("spmm_rows_kernel")][0]
+dom = sorted((k for k in out["kernels"] if k.startswith("spmm_rows_kernel")), key=lambda k: out["kernels"][k]["launches"])[-1]
 json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"profiles/{tag}_pmc.json",
            "bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"]},
           open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)

@@ -190,8 +190,9 @@ def test_embed_loop_bit_exact():
 
 @pytest.mark.parametrize("d", [256, 512, 1024, 2048, 128, 64, 32, 8, 100, 260, 1000])
 def test_hot_column_policy_changes_no_bit(d):
-    """The gather cache policy (hot rows = most referenced columns, loaded `nt` through a buffer
-    descriptor) must not change any result bit; forced on with a small byte budget."""
+    """The gather cache policy (the most referenced rows keep the default cache policy, all others are
+    loaded `nt` through a buffer descriptor) must not change any result bit; forced on with a small
+    byte budget."""
     n = 3000 if d <= 512 else 700
     rng = np.random.default_rng(900 + d)
     deg = rng.poisson(10, n).astype(np.int64)
@@ -204,11 +205,21 @@ def test_hot_column_policy_changes_no_bit(d):
     x = rng.standard_normal((n, d)).astype(np.float32)
     g = _hip.Graph.from_host(rowptr, col, val)
     base = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
-    for budget in (d * 4 * 50, d * 4 * 1000):
-        g.set_hot_cache(budget)
+    assert g.info().hot_rows == 0                                    # automatic mode: X is far below 1 GiB
+    indeg = np.bincount(col, minlength=n)
+    for rows in (50, 1000):
+        g.set_hot_cache(d * 4 * rows)
         np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM), base)
+        marked = g.info().hot_rows
+        if d % 4 == 0:                                               # the policy lives in the float4 path
+            assert marked > 0                                        # whole in-degree classes from the top
+            thr = np.sort(indeg)[::-1][marked - 1]
+            assert marked == int((indeg >= thr).sum())
+        else:
+            assert marked == 0
     g.set_hot_cache(0)
     np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM), base)
+    assert g.info().hot_rows == 0
     mask = np.ones(n, bool)
     mask[5] = False
     np.testing.assert_array_equal(base[mask], oracle.l2_normalize(oracle.spmm(rowptr, col, val, x))[mask])

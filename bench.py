@@ -90,6 +90,10 @@ def main():
                          "and keep the fastest ping-pong pair (1 = no tuning).  The same kernel runs 34.4-39.9 ms "
                          "depending on WHICH two allocations hold X and Y (DESIGN.md §3.1, placement sensitivity).")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # developer switches for exercising the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo
+    # instead of RCCL, which refuses two ranks on one device); numbers from such a run mean nothing
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -100,10 +104,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; cleora_amd has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
     partition = args.partition
     if partition == "auto":
         partition = "column" if world > 1 else "row"

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcleora_hip.so")
 
 OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4
 LEFT, SYMMETRIC = 0, 1
-F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE = 1, 2, 4, 8, 16, 32
+F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
 
 c_u64, c_u32, c_i64, c_int, c_f32 = (ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_float)
@@ -59,6 +59,12 @@ SIGNATURES = {
     "cleora_gram_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_centered_gram_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp, vp]),
     "cleora_project_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp]),
+    "cleora_mean_dev": (c_int, [vp, c_u64, c_u32, vp, vp, vp]),
+    "cleora_eigh_workspace": (c_u64, [c_u32]),
+    "cleora_whiten_transform_dev": (c_int, [vp, c_u64, c_u32, c_u32, vp, vp, vp, vp]),
+    "cleora_whiten_workspace": (c_u64, [c_u64, c_u32]),
+    "cleora_whiten_dev": (c_int, [vp, c_u64, c_u64, c_u32, c_u32, vp, c_u64, vp, vp, vp]),
+    "cleora_whiten": (c_int, [vp, c_u64, c_u32, c_u32, vp]),
     "cleora_cosine_scores_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp]),
     "cleora_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),
     "cleora_l2_normalize": (c_int, [vp, c_u64, c_u32, vp]),
@@ -83,12 +89,18 @@ def _preload_hip_runtime():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    cand = os.path.join(libdir, "libamdhip64.so")
     if os.path.exists(cand):
         try:
             ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             pass
+    # the whitening eigensolver is dlopen'ed by the library on first use (csrc/eigh.hip): point it at the
+    # rocSOLVER that belongs to the same ROCm build as that runtime (nothing is loaded here)
+    solver = os.path.join(libdir, "librocsolver.so")
+    if os.path.exists(solver):
+        os.environ.setdefault("CLEORA_ROCSOLVER", solver)
 
 
 def lib():

@@ -415,6 +415,26 @@ int cleora_project_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
     return launch_project(x, ldx, n, d, mean_f32_dev, transform_dev, k, out, ldo, S(stream));
 }
 
+int cleora_mean_dev(const double *colsum_dev, uint64_t n, uint32_t d, double *mean64_dev,
+                    float *mean32_dev, void *stream) {
+    return launch_mean(colsum_dev, n, d, mean64_dev, mean32_dev, S(stream));
+}
+
+uint64_t cleora_eigh_workspace(uint32_t d) { return eigh_workspace(d); }
+
+int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, uint32_t k,
+                                float *transform_dev, double *eigenvalues_dev, void *workspace,
+                                void *stream) {
+    return launch_whiten_transform(gram_dev, n, d, k, transform_dev, eigenvalues_dev, workspace, S(stream));
+}
+
+uint64_t cleora_whiten_workspace(uint64_t n, uint32_t d) { return whiten_workspace(n, d); }
+
+int cleora_whiten_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t n_components,
+                      float *y, uint64_t ldy, void *workspace, double *eigenvalues_dev, void *stream) {
+    return launch_whiten(x, ldx, n, d, n_components, y, ldy, workspace, eigenvalues_dev, S(stream));
+}
+
 // ---- host-pointer entry points ----------------------------------------------------------------
 
 int cleora_propagate(const cleora_graph *g, int markov_type, const float *x_host, uint32_t d,
@@ -467,6 +487,67 @@ int cleora_init(const uint64_t *entity_hash_host, uint64_t n, uint32_t d, int64_
     return CLEORA_OK;
 }
 
+int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_components, float *y_host) {
+    CL_REQUIRE(d > 0, "d must be positive");
+    if (n == 0) return CLEORA_OK;
+    CL_REQUIRE(x_host != nullptr && y_host != nullptr, "x / y is NULL");
+    int rc = require_device();
+    if (rc != CLEORA_OK) return rc;
+    const uint32_t k = (n == 1 || n_components == 0 || n_components > d) ? d : n_components;
+    DevBuf x, y, ws;
+    if ((rc = x.alloc(n * (uint64_t)d * sizeof(float))) != CLEORA_OK ||
+        (rc = y.alloc(n * (uint64_t)k * sizeof(float))) != CLEORA_OK ||
+        (rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK)
+        return rc;
+    CL_HIP(hipMemcpy(x.p, x_host, n * (uint64_t)d * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = launch_whiten(x.as<float>(), d, n, d, k, y.as<float>(), k, ws.p, nullptr, nullptr)) != CLEORA_OK) return rc;
+    CL_HIP(hipMemcpy(y_host, y.p, n * (uint64_t)k * sizeof(float), hipMemcpyDeviceToHost));
+    return CLEORA_OK;
+}
+
+namespace {
+// The default path of pycleora.embed() (pycleora/__init__.py:97-127): propagate, residual, _normalize,
+// whiten_embeddings, f64 RMSE between whitened iterates.  Three buffers rotate: prev -> (SpMM + L2) -> mid
+// -> (whiten) -> next.
+int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int markov_type, uint32_t d,
+                   uint64_t max_iterations, float rw, float threshold, uint32_t flags, float **result,
+                   uint64_t *iterations_run) {
+    const uint64_t n = g->n_rows;
+    const bool check = threshold > 0.0f;
+    DevBuf ws, sq, rws, total;
+    int rc;
+    if ((rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK) return rc;
+    if (check && ((rc = sq.alloc(n * sizeof(double))) != CLEORA_OK ||
+                  (rc = rws.alloc(reduce_workspace(n) * sizeof(double))) != CLEORA_OK ||
+                  (rc = total.alloc(sizeof(double))) != CLEORA_OK))
+        return rc;
+    float *prev = a, *mid = b, *next = c;
+    uint64_t actual = max_iterations;
+    const uint32_t base = CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | (flags & CLEORA_F_FASTNORM);
+    for (uint64_t it = 0; it < max_iterations; ++it) {
+        if ((rc = launch_propagate(g, markov_type, prev, d, d, mid, d, base, rw, prev, nullptr, nullptr, nullptr)) != CLEORA_OK)
+            return rc;
+        if ((rc = launch_whiten(mid, d, n, d, d, next, d, ws.p, nullptr, nullptr)) != CLEORA_OK) return rc;
+        if (check && it > 0) {                                            // :122-125
+            if ((rc = launch_rowops(next, d, n, d, next, d, CLEORA_F_SQDIFF, 0.f, prev, sq.as<double>(), nullptr, nullptr)) != CLEORA_OK ||
+                (rc = launch_reduce_sum(sq.as<double>(), n, rws.as<double>(), total.as<double>(), nullptr)) != CLEORA_OK)
+                return rc;
+            double sum = 0.0;
+            CL_HIP(hipMemcpy(&sum, total.p, sizeof(double), hipMemcpyDeviceToHost));
+            if (sqrt(sum / (double)(n * (uint64_t)d)) < (double)threshold) {   // _compute_rmse, :974-976
+                std::swap(prev, next);
+                actual = it + 1;
+                break;
+            }
+        }
+        std::swap(prev, next);
+    }
+    *result = prev;
+    if (iterations_run) *iterations_run = actual;
+    return CLEORA_OK;
+}
+}  // namespace
+
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,
@@ -476,6 +557,8 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
     CL_REQUIRE(out_host != nullptr, "out is NULL");
     CL_REQUIRE(entity_hash_host != nullptr || x0_host != nullptr, "need entity hashes or x0");
     CL_REQUIRE(d > 0, "d must be positive");
+    CL_REQUIRE(!(flags & CLEORA_F_WHITEN) || residual_weight < 1.0f,
+               "residual_weight >= 1 is not supported together with CLEORA_F_WHITEN");
     CL_HIP(hipSetDevice(g->device));
     const uint64_t n = g->n_rows;
     const uint64_t bytes = n * (uint64_t)d * sizeof(float);
@@ -489,6 +572,16 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
         if ((rc = h.alloc(n * sizeof(uint64_t))) != CLEORA_OK) return rc;
         CL_HIP(hipMemcpy(h.p, entity_hash_host, n * sizeof(uint64_t), hipMemcpyHostToDevice));
         if ((rc = launch_init(h.as<uint64_t>(), n, d, seed, a.as<float>(), d, nullptr)) != CLEORA_OK) return rc;
+    }
+    if (flags & CLEORA_F_WHITEN) {
+        DevBuf c;
+        float *result = nullptr;
+        if ((rc = c.alloc(bytes)) != CLEORA_OK) return rc;
+        rc = embed_whitened(g, a.as<float>(), b.as<float>(), c.as<float>(), markov_type, d, max_iterations,
+                            residual_weight, convergence_threshold, flags, &result, iterations_run);
+        if (rc != CLEORA_OK) return rc;
+        CL_HIP(hipMemcpy(out_host, result, bytes, hipMemcpyDeviceToHost));
+        return CLEORA_OK;
     }
     if (check) {
         if ((rc = sq.alloc(n * sizeof(double))) != CLEORA_OK ||

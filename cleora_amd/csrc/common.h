@@ -112,4 +112,13 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
 
+// eigh.hip
+uint64_t eigh_workspace(uint32_t d);
+int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, float *mean32, hipStream_t stream);
+int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t k, float *transform,
+                            double *eigenvalues, void *workspace, hipStream_t stream);
+uint64_t whiten_workspace(uint64_t n, uint32_t d);
+int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
+                  void *workspace, double *eigenvalues, hipStream_t stream);
+
 }  // namespace cleora

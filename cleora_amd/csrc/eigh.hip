@@ -1,0 +1,227 @@
+// eigh.hip — from the Gram matrix to the whitening transform, without leaving the device.
+//
+//   cov = G / (n-1); lambda, V = eigh(cov); descending; T = V * 1/sqrt(max(lambda, 1e-10)) as f32
+//   (pycleora/__init__.py:143-156)
+//
+// The d x d symmetric eigenproblem is a library call, not a kernel of ours: rocSOLVER's dsyevd (the
+// device counterpart of the LAPACK routine behind the reference's np.linalg.eigh).  rocSOLVER is
+// bound lazily with dlopen on the first whitening call, so the propagation path has no dependency
+// on it and hosts that never whiten never load it.  CLEORA_ROCSOLVER=<path> overrides the name.
+#include <dlfcn.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cstdlib>
+#include <map>
+
+#include "common.h"
+
+namespace cleora {
+namespace {
+
+struct Solver {
+    void *lib = nullptr;
+    decltype(&rocblas_create_handle) create = nullptr;
+    decltype(&rocblas_destroy_handle) destroy = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocsolver_dsyevd) dsyevd = nullptr;
+    std::string error;
+    std::mutex mu;                               // one eigenproblem at a time per process
+    std::map<int, rocblas_handle> handles;       // one rocBLAS handle per device, created on demand
+};
+
+Solver &solver() {
+    static Solver s;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *env = std::getenv("CLEORA_ROCSOLVER");
+        const char *names[] = {env, "librocsolver.so.0", "librocsolver.so"};
+        for (const char *name : names) {
+            if (!name || !*name) continue;
+            s.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (s.lib) break;
+            s.error = dlerror();
+        }
+        if (!s.lib) return;
+        // dlsym on a handle also searches the library's dependencies (rocBLAS)
+        s.create = reinterpret_cast<decltype(s.create)>(dlsym(s.lib, "rocblas_create_handle"));
+        s.destroy = reinterpret_cast<decltype(s.destroy)>(dlsym(s.lib, "rocblas_destroy_handle"));
+        s.set_stream = reinterpret_cast<decltype(s.set_stream)>(dlsym(s.lib, "rocblas_set_stream"));
+        s.dsyevd = reinterpret_cast<decltype(s.dsyevd)>(dlsym(s.lib, "rocsolver_dsyevd"));
+        if (!s.create || !s.destroy || !s.set_stream || !s.dsyevd) {
+            s.error = "rocSOLVER / rocBLAS entry points not found in the loaded library";
+            s.lib = nullptr;
+        }
+    });
+    return s;
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const double *__restrict__ colsum, uint64_t n, uint32_t d,
+                                                   double *__restrict__ mean64, float *__restrict__ mean32) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const double m = colsum[c] / (double)n;      // np.mean(axis=0, dtype=float64)   (:136)
+    mean64[c] = m;
+    mean32[c] = (float)m;                        // mean.astype(np.float32)          (:159)
+}
+
+__global__ __launch_bounds__(256) void cov_kernel(const double *__restrict__ gram, uint64_t elems, double inv,
+                                                  double *__restrict__ cov) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < elems) cov[i] = gram[i] * inv;       // cov /= (n - 1)                   (:143)
+}
+
+// dsyevd leaves ascending eigenvalues in w and eigenvector j in column j (column-major: v[i + j*d]).
+// Output column j of the transform is eigenvector d-1-j (descending order, :147-149) scaled by
+// 1/sqrt(max(lambda, 1e-10)) in f64, then cast to f32 (:155-156).
+__global__ __launch_bounds__(256) void transform_kernel(const double *__restrict__ v, const double *__restrict__ w,
+                                                        uint32_t d, uint32_t k, float *__restrict__ t,
+                                                        double *__restrict__ w_desc) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < d && w_desc) w_desc[idx] = w[d - 1 - idx];
+    if (idx >= (uint64_t)d * k) return;
+    const uint32_t i = (uint32_t)(idx / k), j = (uint32_t)(idx % k);
+    const uint32_t src = d - 1 - j;
+    const double lam = w[src];
+    const double scale = 1.0 / sqrt(lam > 1e-10 ? lam : 1e-10);
+    t[idx] = (float)(v[(uint64_t)i + (uint64_t)src * d] * scale);
+}
+
+inline uint64_t align256(uint64_t b) { return (b + 255) / 256 * 256; }
+
+struct TransformWs {      // carved out of the caller's workspace
+    double *cov, *w, *e;
+    int *info;
+};
+inline uint64_t transform_ws_bytes(uint32_t d) {
+    return align256((uint64_t)d * d * 8) + 2 * align256((uint64_t)d * 8) + 256;
+}
+inline TransformWs carve_transform(void *ws, uint32_t d) {
+    char *p = static_cast<char *>(ws);
+    TransformWs t;
+    t.cov = reinterpret_cast<double *>(p); p += align256((uint64_t)d * d * 8);
+    t.w = reinterpret_cast<double *>(p); p += align256((uint64_t)d * 8);
+    t.e = reinterpret_cast<double *>(p); p += align256((uint64_t)d * 8);
+    t.info = reinterpret_cast<int *>(p);
+    return t;
+}
+
+}  // namespace
+
+uint64_t eigh_workspace(uint32_t d) { return transform_ws_bytes(d); }
+
+int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, float *mean32, hipStream_t stream) {
+    CL_REQUIRE(colsum != nullptr && mean64 != nullptr && mean32 != nullptr, "colsum / mean is NULL");
+    CL_REQUIRE(n > 0 && d > 0, "n and d must be positive");
+    hipLaunchKernelGGL(mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, colsum, n, d, mean64, mean32);
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t k, float *transform,
+                            double *eigenvalues, void *workspace, hipStream_t stream) {
+    CL_REQUIRE(gram != nullptr && transform != nullptr && workspace != nullptr, "gram / transform / workspace is NULL");
+    CL_REQUIRE(n >= 2, "whitening needs at least two rows");
+    CL_REQUIRE(d > 0 && k > 0 && k <= d, "need 0 < k <= d");
+    CL_REQUIRE(d <= (1u << 15), "d too large for the eigensolver");
+    Solver &s = solver();
+    if (!s.lib) {
+        set_error("whitening needs rocSOLVER (dlopen failed: " + s.error + "); set CLEORA_ROCSOLVER to its path");
+        return CLEORA_E_HIP;
+    }
+    int device = 0;
+    CL_HIP(hipGetDevice(&device));
+    const TransformWs w = carve_transform(workspace, d);
+    const uint64_t elems = (uint64_t)d * d;
+    hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, gram, elems,
+                       1.0 / (double)(n - 1), w.cov);
+    CL_HIP(hipGetLastError());
+    {
+        std::lock_guard<std::mutex> lock(s.mu);
+        rocblas_handle &h = s.handles[device];
+        if (!h && s.create(&h) != rocblas_status_success) {
+            h = nullptr;
+            set_error("rocblas_create_handle failed");
+            return CLEORA_E_HIP;
+        }
+        if (s.set_stream(h, stream) != rocblas_status_success) {
+            set_error("rocblas_set_stream failed");
+            return CLEORA_E_HIP;
+        }
+        // symmetric input: row-major and column-major coincide; eigenvectors come back column-major
+        const rocblas_status st = s.dsyevd(h, rocblas_evect_original, rocblas_fill_upper, (rocblas_int)d, w.cov,
+                                           (rocblas_int)d, w.w, w.e, w.info);
+        if (st != rocblas_status_success) {
+            set_error("rocsolver_dsyevd failed with status " + std::to_string((int)st));
+            return CLEORA_E_HIP;
+        }
+    }
+    const uint64_t cells = (uint64_t)d * k > d ? (uint64_t)d * k : d;
+    hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, w.cov, w.w, d, k,
+                       transform, eigenvalues);
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+// ---- the whole of whiten_embeddings on device buffers ------------------------------------------
+namespace {
+struct WhitenWs {
+    double *colsum_ws, *colsum, *mean64, *gram_ws, *gram;
+    float *mean32, *transform;
+    void *eigh;
+};
+inline uint64_t whiten_ws_layout(uint64_t n, uint32_t d, void *base, WhitenWs *out) {
+    uint64_t off = 0;
+    auto take = [&](uint64_t bytes) {
+        char *p = base ? static_cast<char *>(base) + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    char *a = take(colsum_workspace(n, d) * 8);
+    char *b = take((uint64_t)d * 8);
+    char *c = take((uint64_t)d * 8);
+    char *e = take(gram_workspace(n, d) * 8);
+    char *f = take((uint64_t)d * d * 8);
+    char *g = take((uint64_t)d * 4);
+    char *h = take((uint64_t)d * d * 4);
+    char *i = take(transform_ws_bytes(d));
+    if (out) {
+        out->colsum_ws = reinterpret_cast<double *>(a);
+        out->colsum = reinterpret_cast<double *>(b);
+        out->mean64 = reinterpret_cast<double *>(c);
+        out->gram_ws = reinterpret_cast<double *>(e);
+        out->gram = reinterpret_cast<double *>(f);
+        out->mean32 = reinterpret_cast<float *>(g);
+        out->transform = reinterpret_cast<float *>(h);
+        out->eigh = i;
+    }
+    return off;
+}
+}  // namespace
+
+uint64_t whiten_workspace(uint64_t n, uint32_t d) { return whiten_ws_layout(n, d, nullptr, nullptr); }
+
+int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
+                  void *workspace, double *eigenvalues, hipStream_t stream) {
+    CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
+    if (n == 0) return CLEORA_OK;
+    CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
+    CL_REQUIRE((const void *)x != (const void *)y, "x and y must not alias");
+    if (n == 1) {                                 // `if n <= 1: return embeddings.copy()`   (:132-133)
+        CL_REQUIRE(ldy >= d, "one row is returned unchanged: y needs d columns");
+        CL_HIP(hipMemcpyAsync(y, x, (uint64_t)d * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        return CLEORA_OK;
+    }
+    if (k == 0 || k > d) k = d;                   // n_components=None, or >= d             (:151)
+    CL_REQUIRE(ldy >= k, "bad output leading dimension");
+    CL_REQUIRE(workspace != nullptr, "workspace is NULL");
+    WhitenWs w;
+    whiten_ws_layout(n, d, workspace, &w);
+    int rc;
+    if ((rc = launch_colsum(x, ldx, n, d, w.colsum_ws, w.colsum, stream)) != CLEORA_OK) return rc;
+    if ((rc = launch_mean(w.colsum, n, d, w.mean64, w.mean32, stream)) != CLEORA_OK) return rc;
+    if ((rc = launch_gram(x, ldx, n, d, w.mean64, w.gram_ws, w.gram, stream)) != CLEORA_OK) return rc;
+    if ((rc = launch_whiten_transform(w.gram, n, d, k, w.transform, eigenvalues, w.eigh, stream)) != CLEORA_OK) return rc;
+    return launch_project(x, ldx, n, d, w.mean32, w.transform, k, y, ldy, stream);
+}
+
+}  // namespace cleora

@@ -24,8 +24,10 @@ DEFAULT_NUM_ITERATIONS = 40     # pycleora/__init__.py:13
 
 
 def eigh_descending(cov, backend="auto"):
-    """Eigen-decomposition of the covariance, eigenvalues descending (pycleora/__init__.py:145-149).
-    backend "host": numpy/LAPACK, the routine the reference itself calls.  "device":
+    """Eigen-decomposition of the covariance on host arrays, eigenvalues descending
+    (pycleora/__init__.py:145-149).  Used by the host-statistics routes (DeviceWhitener(eigh="host" |
+    "device"), the partitioned whitening in sharded.py); the default single-GPU route never leaves the
+    device (cleora_whiten_dev).  backend "host": numpy/LAPACK, the routine the reference itself calls.  "device":
     torch.linalg.eigh on the GPU (rocSOLVER).  "auto": device when torch sees a GPU, else host.
     Measured on the MI355X box: d = 256: host 5.1 ms / device 6.4 ms; d = 1024: host 322 ms /
     device 23 ms.  The device route is the default because the host route is fragile inside a
@@ -51,67 +53,91 @@ def eigh_descending(cov, backend="auto"):
 
 
 class DeviceWhitener:
-    """whiten_embeddings on device buffers.  Workspaces are sized once per (n, d)."""
+    """whiten_embeddings on device buffers.  Workspaces are sized once per (n, d).
+
+    eigh = "library" (what "auto" means): the whole chain — column sums, mean, centred Gram, rocSOLVER
+    dsyevd, transform, projection — is enqueued on one stream by cleora_whiten_dev with no host round
+    trip.  "host" / "device" keep the statistics on the host between the kernels and call
+    np.linalg.eigh / torch.linalg.eigh (see eigh_descending); they exist for A/B comparison with the
+    LAPACK routine the reference itself calls."""
 
     def __init__(self, n, d, eigh="auto"):
         L = _hip.lib()
-        self.n, self.d, self.L, self.eigh = n, d, L, eigh
-        self.colsum_ws = _hip.DevArray((L.cleora_colsum_workspace(n, d),), np.float64)
-        self.colsum = _hip.DevArray((d,), np.float64)
-        self.mean64 = _hip.DevArray((d,), np.float64)
-        self.mean32 = _hip.DevArray((d,), np.float32)
-        self.gram_ws = _hip.DevArray((L.cleora_gram_workspace(n, d),), np.float64)
-        self.gram = _hip.DevArray((d, d), np.float64)
+        self.n, self.d, self.L = n, d, L
+        self.eigh = "library" if eigh == "auto" else eigh
         self.transform = None
-        self.last_eigenvalues = None
+        self._eigenvalues = None
+        self._split = None          # buffers of the host-statistics route, allocated on first use
+        if self.eigh == "library":
+            self.ws = _hip.DevArray((L.cleora_whiten_workspace(n, d),), np.uint8)
+            self.eig_dev = _hip.DevArray((d,), np.float64)
+
+    def _split_buffers(self):
+        if self._split is None:
+            L, n, d = self.L, self.n, self.d
+            self._split = dict(
+                colsum_ws=_hip.DevArray((L.cleora_colsum_workspace(n, d),), np.float64),
+                colsum=_hip.DevArray((d,), np.float64), mean64=_hip.DevArray((d,), np.float64),
+                mean32=_hip.DevArray((d,), np.float32),
+                gram_ws=_hip.DevArray((L.cleora_gram_workspace(n, d),), np.float64),
+                gram=_hip.DevArray((d, d), np.float64))
+        return self._split
+
+    @property
+    def last_eigenvalues(self):
+        """Eigenvalues of the last covariance, descending (downloaded on demand)."""
+        if self.eigh == "library" and self._eigenvalues is None:
+            _hip.check(self.L.cleora_stream_sync(None))
+            self._eigenvalues = self.eig_dev.to_host()
+        return self._eigenvalues
 
     def stats(self, x_ptr, ldx, stream=None):
         """(mean f64[d], cov f64[d,d]) as pycleora/__init__.py:136-143."""
-        L, n, d = self.L, self.n, self.d
-        _hip.check(L.cleora_colsum_dev(x_ptr, ldx, n, d, self.colsum_ws.ptr, self.colsum.ptr, stream))
+        L, n, d, b = self.L, self.n, self.d, self._split_buffers()
+        _hip.check(L.cleora_colsum_dev(x_ptr, ldx, n, d, b["colsum_ws"].ptr, b["colsum"].ptr, stream))
+        _hip.check(L.cleora_mean_dev(b["colsum"].ptr, n, d, b["mean64"].ptr, b["mean32"].ptr, stream))
+        _hip.check(L.cleora_centered_gram_dev(x_ptr, ldx, n, d, b["mean64"].ptr, b["gram_ws"].ptr,
+                                              b["gram"].ptr, stream))
         _hip.check(L.cleora_stream_sync(stream))
-        mean = self.colsum.to_host() / float(n)
-        _hip.check(L.cleora_memcpy_h2d(self.mean64.ptr, _hip.ptr(mean), mean.nbytes, stream))
-        _hip.check(L.cleora_centered_gram_dev(x_ptr, ldx, n, d, self.mean64.ptr, self.gram_ws.ptr,
-                                              self.gram.ptr, stream))
-        _hip.check(L.cleora_stream_sync(stream))
-        cov = self.gram.to_host()
+        cov = b["gram"].to_host()
         cov *= 1.0 / (n - 1)
-        return mean, cov
+        return b["mean64"].to_host(), cov
 
     def whiten(self, x_ptr, ldx, out_ptr, ldo, n_components=None, stream=None):
         """out = whiten_embeddings(x).  Returns k (columns written)."""
         L, n, d = self.L, self.n, self.d
+        if self.eigh == "library":
+            k = d if n_components is None else min(int(n_components), d)
+            _hip.check(L.cleora_whiten_dev(x_ptr, ldx, n, d, k, out_ptr, ldo, self.ws.ptr, self.eig_dev.ptr,
+                                           stream))
+            self._eigenvalues = None
+            return k
         mean, cov = self.stats(x_ptr, ldx, stream)
         w, v = eigh_descending(cov, self.eigh)           # :145-149
         if n_components is not None:                     # :151-153
             w, v = w[:n_components], v[:, :n_components]
         scale = 1.0 / np.sqrt(np.maximum(w, 1e-10))      # :155
         transform = np.ascontiguousarray((v * scale).astype(np.float32))
-        mean32 = mean.astype(np.float32)
         k = transform.shape[1]
         if self.transform is None or self.transform.shape != transform.shape:
             self.transform = _hip.DevArray(transform.shape, np.float32)
         _hip.check(L.cleora_memcpy_h2d(self.transform.ptr, _hip.ptr(transform), transform.nbytes, stream))
-        _hip.check(L.cleora_memcpy_h2d(self.mean32.ptr, _hip.ptr(mean32), mean32.nbytes, stream))
-        _hip.check(L.cleora_project_dev(x_ptr, ldx, n, d, self.mean32.ptr, self.transform.ptr, k,
+        _hip.check(L.cleora_project_dev(x_ptr, ldx, n, d, self._split["mean32"].ptr, self.transform.ptr, k,
                                         out_ptr, ldo, stream))
-        self.last_eigenvalues = w
+        self._eigenvalues = w
         return k
 
 
 def whiten_embeddings(embeddings, n_components=None):
-    """Drop-in for pycleora.whiten_embeddings on host arrays (one upload, one download)."""
+    """Drop-in for pycleora.whiten_embeddings on host arrays: cleora_whiten (one upload, one download)."""
     x = np.ascontiguousarray(embeddings, dtype=np.float32)
     n, d = x.shape
     if n <= 1:
         return x.copy()                                   # :132-133
-    dx = _hip.DevArray.from_host(x)
     k = d if n_components is None else min(int(n_components), d)
-    out = _hip.DevArray((n, k), np.float32)
-    DeviceWhitener(n, d).whiten(dx.ptr, d, out.ptr, k, n_components)
-    _hip.check(_hip.lib().cleora_stream_sync(None))
-    return out.to_host()
+    out = np.empty((n, k), np.float32)
+    _hip.check(_hip.lib().cleora_whiten(_hip.ptr(x), n, d, k, _hip.ptr(out)))
+    return out
 
 
 def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITERATIONS,

@@ -76,11 +76,32 @@ class HipBackend:
                                                      ws.data_ptr(), out.data_ptr(), self._stream()))
         return out
 
+    def whiten_transform(self, gram, n, kdim):
+        d = gram.shape[0]
+        ws = torch.empty(self.lib.cleora_eigh_workspace(d), dtype=torch.uint8, device=gram.device)
+        out = torch.empty((d, kdim), dtype=torch.float32, device=gram.device)
+        _hip.check(self.lib.cleora_whiten_transform_dev(gram.data_ptr(), n, d, kdim, out.data_ptr(), None,
+                                                        ws.data_ptr(), self._stream()))
+        return out
+
     def project(self, x, mean32, transform, out):
         n, d = x.shape
         _hip.check(self.lib.cleora_project_dev(x.data_ptr(), x.stride(0), n, d, mean32.data_ptr(),
                                                transform.data_ptr(), transform.shape[1], out.data_ptr(),
                                                out.stride(0), self._stream()))
+
+
+def transform_from_gram(backend, gram, n, kdim):
+    """cov = gram/(n-1) -> eigh -> descending -> V / sqrt(max(lambda, 1e-10)) as f32, d x kdim
+    (pycleora/__init__.py:143-156).  On the HIP backend this stays on the device
+    (cleora_whiten_transform_dev: rocSOLVER dsyevd); injected CPU backends use numpy's LAPACK."""
+    if hasattr(backend, "whiten_transform"):
+        return backend.whiten_transform(gram, n, kdim)
+    import numpy as np
+    w, v = np.linalg.eigh(gram.cpu().numpy() * (1.0 / (n - 1)))
+    idx = np.argsort(w)[::-1][:kdim]                                       # :147-153
+    scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))                       # :155
+    return torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32))).to(gram.device)
 
 
 def block_size(n, world, steps):
@@ -169,21 +190,9 @@ class ShardedGraph:
         if self.world > 1:
             dist.all_reduce(gram, group=self.group)
         kdim = d if n_components is None else min(int(n_components), d)
-        transform = torch.empty((d, kdim), dtype=torch.float32, device=y.device)
-        if self.rank == 0:
-            if y.is_cuda:
-                # eigh on the device (rocSOLVER through torch): no D2H of the covariance and no host
-                # BLAS thread pool inside the loop (see embed.eigh_descending)
-                w, v = torch.linalg.eigh(gram * (1.0 / (self.n - 1)))
-                w, v = torch.flip(w, [0])[:kdim], torch.flip(v, [1])[:, :kdim]   # descending (:147-149)
-                scale = 1.0 / torch.sqrt(torch.clamp(w, min=1e-10))                 # :155
-                transform.copy_((v * scale).to(torch.float32))
-            else:
-                cov = gram.numpy() * (1.0 / (self.n - 1))
-                w, v = np.linalg.eigh(cov)
-                idx = np.argsort(w)[::-1][:kdim]
-                scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))
-                transform.copy_(torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32))))
+        # every rank holds the same all-reduced Gram, so the (deterministic) eigensolver is replicated;
+        # the transform is still broadcast from rank 0 so that the ranks cannot drift apart
+        transform = transform_from_gram(self.backend, gram, self.n, kdim)
         if self.world > 1:
             dist.broadcast(transform, src=0, group=self.group)
         mean32 = mean.to(torch.float32)
@@ -333,15 +342,7 @@ class ColumnShardedGraph:
             dist.all_reduce(gram, group=self.group)
         # every rank holds the same all-reduced Gram: eigh is replicated (deterministic routine),
         # but the transform is still broadcast from rank 0 so the ranks cannot drift apart
-        cov = gram * (1.0 / (self.n - 1))
-        if cov.is_cuda:
-            w, v = torch.linalg.eigh(cov)
-        else:
-            import numpy as np
-            wn, vn = np.linalg.eigh(cov.numpy())
-            w, v = torch.from_numpy(wn), torch.from_numpy(vn)
-        w, v = torch.flip(w, [0]), torch.flip(v, [1])
-        transform = (v * (1.0 / torch.sqrt(torch.clamp(w, min=1e-10)))).to(torch.float32).contiguous()
+        transform = transform_from_gram(self.backend, gram, self.n, d)
         if P > 1:
             dist.broadcast(transform, src=0, group=self.group)
         proj = torch.zeros((rp, d), dtype=torch.float32, device=rows.device)

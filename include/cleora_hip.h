@@ -53,6 +53,7 @@ extern "C" {
                                  several GPUs and the sums must be all-reduced before the scale */
 #define CLEORA_F_SCALE 32u    /* IN: row_sumsq[r] is the complete sum of squares; y[r] *= 1/max(sqrt(.),1e-10)
                                  (src/embedding.rs:98-102) without recomputing it */
+#define CLEORA_F_WHITEN 64u   /* cleora_embed only: whiten_embeddings after the L2 norm of every iteration (pycleora/__init__.py:963-971) */
 
 typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct SparseMatrix, src/sparse_matrix.rs:56-78) */
 
@@ -175,6 +176,30 @@ int cleora_project_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                        const float *mean_f32_dev, const float *transform_dev, uint32_t k,
                        float *out, uint64_t ldo, void *stream);
 
+/* mean64[c] = colsum[c] / n (f64, :136) and mean32[c] = (float)mean64[c] (:159), on the device. */
+int cleora_mean_dev(const double *colsum_dev, uint64_t n, uint32_t d, double *mean64_dev,
+                    float *mean32_dev, void *stream);
+
+/* From the centred Gram matrix to the whitening transform, on the device (:143-156):
+ *   cov = gram / (n-1);  lambda, V = eigh(cov);  descending order;
+ *   transform[:, j] = (float)(V[:, j] / sqrt(max(lambda_j, 1e-10)))   for the k leading components.
+ * gram: d x d f64 (read only); transform: d x k row-major f32; eigenvalues_dev: f64[d] descending, may be
+ * NULL.  workspace: cleora_eigh_workspace(d) BYTES.  The eigenproblem is rocSOLVER's dsyevd (the device
+ * counterpart of the LAPACK call behind np.linalg.eigh), bound with dlopen on first use; eigenvector
+ * signs are the solver's (the reference's are LAPACK's: whitening is defined up to them). */
+uint64_t cleora_eigh_workspace(uint32_t d);
+int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, uint32_t k,
+                                float *transform_dev, double *eigenvalues_dev, void *workspace,
+                                void *stream);
+
+/* whiten_embeddings (pycleora/__init__.py:130-164) on device buffers, one stream, no host round trip:
+ * column sums -> mean -> centred Gram -> transform -> projection.  y: n x k (ldy), must not alias x.
+ * n_components = 0 (or >= d) keeps all d components.  n == 1 copies the row unchanged (:132-133).
+ * workspace: cleora_whiten_workspace(n, d) BYTES.  eigenvalues_dev: f64[d] descending or NULL. */
+uint64_t cleora_whiten_workspace(uint64_t n, uint32_t d);
+int cleora_whiten_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t n_components,
+                      float *y, uint64_t ldy, void *workspace, double *eigenvalues_dev, void *stream);
+
 /* ---- similarity ---------------------------------------------------- */
 
 /* scores[r] = (x[r] . query) / max(||x[r]||, 1e-10): the row-normalise + GEMV of find_most_similar /
@@ -197,11 +222,19 @@ int cleora_l2_normalize(const float *x_host, uint64_t n, uint32_t d, float *y_ho
 int cleora_init(const uint64_t *entity_hash_host, uint64_t n, uint32_t d, int64_t seed,
                 float *x_host);
 
+/* whiten_embeddings(embeddings, n_components) on host arrays (pycleora/__init__.py:130-164).
+ * y_host: n x k with k = n_components, or d when n_components is 0 or >= d (n <= 1: n x d copy). */
+int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_components, float *y_host);
+
 /* SparseMatrix::embed_fast / embed_fast_convergence (src/lib.rs:320-412) →
  * NdArrayMatrix::embed_full / embed_full_with_convergence (src/embedding.rs:106-188).
  * Device-resident loop: init (or x0_host if non-NULL), `max_iterations` x (SpMM, residual for
  * 0 < rw < 1, L2), optional RMSE early stop (threshold > 0, from iteration 1).
- * The graph must be square (n_rows == n_cols).  out_host: n x d.  iterations_run may be NULL. */
+ * The graph must be square (n_rows == n_cols).  out_host: n x d.  iterations_run may be NULL.
+ * With CLEORA_F_WHITEN in `flags` the loop is the default path of pycleora.embed() instead
+ * (pycleora/__init__.py:97-127 with _postprocess_iteration :963-971): every iteration is SpMM, residual
+ * (rw must be < 1), L2 normalise, THEN whiten_embeddings; the RMSE of the early stop is taken between
+ * whitened iterates in f64 (:122-125, :974-976). */
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,

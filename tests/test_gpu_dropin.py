@@ -1,12 +1,14 @@
 """GPU: the drop-in SparseMatrix and the device-resident embed() against the reference's outputs
 for BASELINE config 1 (karate club; tests/golden/karate_ref.npz was produced by the reference's
 own `pycleora.embed()` running over an oracle-backed stub, see tests/golden/make_golden.py)."""
+import ctypes
 import os
 
 import numpy as np
 import pytest
 
 import oracle
+from cleora_amd import _hip
 from cleora_amd import embed as dev_embed
 from cleora_amd.pycleora import SparseMatrix
 from oracle import whiten as ow
@@ -75,6 +77,34 @@ def test_embed_default_whiten_d16(karate):
     res = dev_embed.embed(g, 16, 10, residual_weight=0.3)
     want = k["embed_resid_d16"]
     assert np.abs(cosine_matrix(res) - cosine_matrix(want)).max() < 1e-4
+
+
+def test_c_abi_embed_with_whiten_flag(karate):
+    """cleora_embed(..., CLEORA_F_WHITEN): the default path of pycleora.embed() as ONE C-ABI call (what a
+    Rust host would bind), against the reference's own output for config 1 at d = 16."""
+    k, g = karate
+    L = _hip.lib()
+    n, d = g.num_entities, 16
+    hashes = np.ascontiguousarray(k["entity_hashes"], dtype=np.uint64)
+    out = np.empty((n, d), np.float32)
+    ran = ctypes.c_uint64(0)
+    _hip.check(L.cleora_embed(g._graph().handle, _hip.ptr(hashes), None, _hip.LEFT, d, 40, 0, 0.0, 0.0,
+                              _hip.F_WHITEN, _hip.ptr(out), ctypes.byref(ran)))
+    assert ran.value == 40
+    want = k["embed_whiten_d16"]
+    s = np.sign((out * want).sum(axis=0))
+    assert np.abs(out * s - want).max() <= 5e-3 * np.abs(want).max()
+    assert np.abs(cosine_matrix(out) - cosine_matrix(want)).max() < 1e-4
+    # residual + early stop: same loop through the Python driver
+    x0 = oracle.init(k["entity_hashes"], 12, 1)
+    want = dev_embed.embed(g, 12, 40, initial_embeddings=x0, residual_weight=0.3, convergence_threshold=2e-2)
+    out = np.empty((n, 12), np.float32)
+    _hip.check(L.cleora_embed(g._graph().handle, None, _hip.ptr(x0), _hip.LEFT, 12, 40, 0, 0.3, 2e-2,
+                              _hip.F_WHITEN, _hip.ptr(out), ctypes.byref(ran)))
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-6 * np.abs(want).max())
+    with pytest.raises(ValueError, match="residual_weight"):
+        _hip.check(L.cleora_embed(g._graph().handle, None, _hip.ptr(x0), _hip.LEFT, 12, 2, 0, 1.0, 0.0,
+                                  _hip.F_WHITEN, _hip.ptr(out), None))
 
 
 def test_embed_default_whiten_d128_rank_deficient(karate):

@@ -99,3 +99,74 @@ def test_whiten_property_identity_covariance_at_scale():
     cov = (out.astype(np.float64) - mean).T @ (out.astype(np.float64) - mean) / (n - 1)
     assert np.abs(mean).max() < 2e-4
     assert np.abs(cov - np.eye(d)).max() < 2e-3
+
+
+@pytest.mark.parametrize("d,k", [(16, 16), (64, 10), (256, 256), (130, 130), (513, 40)])
+def test_whiten_transform_dev_vs_lapack(d, k):
+    """cleora_whiten_transform_dev (rocSOLVER dsyevd + scaling on the device) vs np.linalg.eigh, the routine
+    the reference calls: eigenvalues rel 1e-11 of the largest; transform columns after sign alignment
+    |delta| <= 1e-4 * max|column| for well-separated eigenvalues (columns of close eigenvalues rotate)."""
+    rng = np.random.default_rng(d * 7 + k)
+    n = 5000
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    lam = np.geomspace(1.0, 1e-3, d) * (1 + 0.3 * rng.random(d))
+    lam[::7] *= 3.0                                        # spread, keep gaps
+    cov = (q * lam) @ q.T
+    cov = (cov + cov.T) / 2
+    gram = np.ascontiguousarray(cov * (n - 1))
+    L = _hip.lib()
+    dg = _hip.DevArray.from_host(gram)
+    dt = _hip.DevArray((d, k), np.float32)
+    de = _hip.DevArray((d,), np.float64)
+    ws = _hip.DevArray((L.cleora_eigh_workspace(d),), np.uint8)
+    _hip.check(L.cleora_whiten_transform_dev(dg.ptr, n, d, k, dt.ptr, de.ptr, ws.ptr, None))
+    _hip.check(L.cleora_stream_sync(None))
+    np.testing.assert_array_equal(dg.to_host(), gram)      # input is not modified
+    w, v = np.linalg.eigh(cov)
+    w, v = w[::-1], v[:, ::-1]
+    got_w, got_t = de.to_host(), dt.to_host()
+    assert np.abs(got_w - w).max() <= 1e-11 * w[0]
+    want_t = (v * (1.0 / np.sqrt(np.maximum(w, 1e-10))))[:, :k].astype(np.float32)
+    gaps = np.minimum(np.abs(np.diff(w, prepend=np.inf)), np.abs(np.diff(w, append=-np.inf)))[:k] / w[:k]
+    ok = gaps > 1e-3
+    got_a = sign_align(got_t, want_t)
+    assert ok.sum() >= k // 2
+    assert np.all(np.abs(got_a - want_t)[:, ok].max(axis=0) <= 1e-4 * np.abs(want_t)[:, ok].max(axis=0))
+    # the transform whitens cov whatever the rotation inside close eigenvalue groups: T^T cov T = I
+    t64 = got_t.astype(np.float64)
+    assert np.abs(t64.T @ cov @ t64 - np.eye(k)).max() < 5e-6
+
+
+@pytest.mark.parametrize("n,d,k", [(3000, 32, None), (2000, 100, 17), (5000, 256, None), (2, 8, None), (700, 130, 130)])
+def test_whiten_dev_matches_host_statistics_route(n, d, k):
+    """The device-only chain (cleora_whiten_dev) vs the route with numpy's LAPACK eigh between the kernels."""
+    x = case_input(3 * n + d, n, d)
+    dx = _hip.DevArray.from_host(x)
+    kk = d if k is None else k
+    outs = []
+    for route in ("library", "host"):
+        w = dev_embed.DeviceWhitener(n, d, eigh=route)
+        out = _hip.DevArray((n, kk), np.float32)
+        assert w.whiten(dx.ptr, d, out.ptr, kk, k) == kk
+        _hip.check(_hip.lib().cleora_stream_sync(None))
+        outs.append((out.to_host(), w.last_eigenvalues))
+    (a, wa), (b, wb) = outs
+    assert np.abs(wa[:kk] - wb[:kk]).max() <= 1e-10 * max(wb[0], 1e-300)
+    if n > d:        # full-rank covariance: columns are defined up to sign
+        a = sign_align(a, b)
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max()
+
+
+def test_cleora_whiten_errors_and_single_row():
+    L = _hip.lib()
+    x = np.arange(6, dtype=np.float32).reshape(1, 6)
+    y = np.zeros_like(x)
+    _hip.check(L.cleora_whiten(_hip.ptr(x), 1, 6, 3, _hip.ptr(y)))       # n <= 1: the row comes back unchanged
+    np.testing.assert_array_equal(y, x)
+    _hip.check(L.cleora_whiten(None, 0, 6, 0, None))                     # empty input is a no-op
+    with pytest.raises(ValueError):
+        _hip.check(L.cleora_whiten(_hip.ptr(x), 1, 0, 0, _hip.ptr(y)))
+    dx = _hip.DevArray.from_host(np.ones((4, 8), np.float32))
+    ws = _hip.DevArray((L.cleora_whiten_workspace(4, 8),), np.uint8)
+    with pytest.raises(ValueError, match="alias"):
+        _hip.check(L.cleora_whiten_dev(dx.ptr, 8, 4, 8, 0, dx.ptr, 8, ws.ptr, None, None))

@@ -64,10 +64,25 @@ def cpu_baseline(g, x_dev, n, d, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s or count >= 5:
             break
-    return {"value": g["nnz"] * d * count / el, "unit": "edge*dim/s", "cores": threads,
-            "kind": "port", "iterations_per_sec": count / el,
-            "sample": f"{count} full iteration(s) of the same graph and X (SpMM, reference AoS edge "
-                      f"layout, dynamic row schedule + separate L2 pass), {el:.1f} s"}
+    out = {"value": g["nnz"] * d * count / el, "unit": "edge*dim/s", "cores": threads,
+           "kind": "port", "iterations_per_sec": count / el,
+           "sample": f"{count} full iteration(s) of the same graph and X (SpMM, reference AoS edge "
+                     f"layout, dynamic row schedule + separate L2 pass), {el:.1f} s"}
+    # independent line: single-thread scipy CSR @ dense on a contiguous block of rows
+    try:
+        import scipy.sparse as sp
+        r0, rows = n // 3, min(n - n // 3, 400_000)
+        e0, e1 = int(rowptr[r0]), int(rowptr[r0 + rows])
+        a = sp.csr_matrix((edges["left"][e0:e1], edges["col"][e0:e1].astype(np.int64),
+                           (rowptr[r0:r0 + rows + 1] - rowptr[r0]).astype(np.int64)), shape=(rows, n))
+        t0 = time.perf_counter()
+        a @ x
+        el = time.perf_counter() - t0
+        out["scipy_single_thread"] = {"value": (e1 - e0) * d / el, "unit": "edge*dim/s", "cores": 1,
+                                      "sample": f"scipy.sparse CSR @ dense, rows [{r0}, {r0 + rows}) = {e1 - e0} edges, {el:.1f} s"}
+    except Exception as ex:  # scipy is optional; the port above is the baseline
+        out["scipy_single_thread"] = {"error": str(ex)}
+    return out
 
 
 def main():

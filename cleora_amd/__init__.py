@@ -2,7 +2,8 @@
 
   cleora_amd.pycleora.SparseMatrix   drop-in for pycleora.pycleora.SparseMatrix (src/lib.rs)
   cleora_amd.embed                   device-resident embed()/whitening loop (pycleora/__init__.py:51-164)
-  cleora_amd.sharded                 row-partitioned multi-GPU propagation (one process per GPU)
+  cleora_amd.variants                device-resident embed variants + predict_links (pycleora/__init__.py:206-410, 636-681, 784-852)
+  cleora_amd.sharded                 column- / row-partitioned multi-GPU propagation (one process per GPU)
   cleora_amd._hip                    ctypes binding of libcleora_hip.so (include/cleora_hip.h)
 """
 __version__ = "0.1.0"
@@ -31,6 +32,8 @@ def accelerate(package=None):
     crossing PCIe twice per iteration and whitening in numpy:
         pycleora.embed              -> cleora_amd.embed.embed           (same signature)
         pycleora.whiten_embeddings  -> cleora_amd.embed.whiten_embeddings
+        pycleora.embed_multiscale / embed_weighted / embed_directed / embed_with_attention /
+        embed_edge_features / predict_links -> cleora_amd.variants.* (same signatures)
     Normalisations the device path does not run ('l1', 'spectral') are forwarded to the original."""
     import importlib
 
@@ -47,4 +50,35 @@ def accelerate(package=None):
     embed.__wrapped__ = original_embed
     pkg.embed = embed
     pkg.whiten_embeddings = _dev.whiten_embeddings
+
+    # the embed variants and link prediction: same signatures, device-resident loop
+    import inspect
+
+    from . import variants as _var
+
+    def rebind(name):
+        original = getattr(pkg, name, None)
+        device_fn = getattr(_var, name)
+        if original is None:
+            return
+        sig = inspect.signature(device_fn)
+
+        def wrapper(*args, **kwargs):
+            try:
+                bound = sig.bind(*args, **kwargs).arguments
+            except TypeError:
+                return original(*args, **kwargs)
+            graph = bound.get("graph")
+            if bound.get("normalization", "l2") not in ("l2", "none") or \
+                    (graph is not None and not isinstance(graph, _dev.SparseMatrix)):
+                return original(*args, **kwargs)
+            return device_fn(*args, **kwargs)
+
+        wrapper.__wrapped__ = original
+        wrapper.__name__ = name
+        setattr(pkg, name, wrapper)
+
+    for name in ("embed_multiscale", "embed_weighted", "embed_directed", "embed_with_attention",
+                 "embed_edge_features", "predict_links"):
+        rebind(name)
     return pkg

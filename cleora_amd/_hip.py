@@ -50,6 +50,8 @@ SIGNATURES = {
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
     "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
+    "cleora_propagate_vals_dev": (c_int, [vp, vp, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
+    "cleora_edge_attention_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, c_f32, vp, vp]),
     "cleora_rowops_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_init_dev": (c_int, [vp, c_u64, c_u32, c_i64, vp, c_u64, vp]),
     "cleora_reduce_workspace": (c_u64, [c_u64]),

@@ -370,6 +370,19 @@ int cleora_propagate_dev(const cleora_graph *g, int markov_type, const float *x,
                             row_sqdiff, row_sumsq, S(stream));
 }
 
+int cleora_propagate_vals_dev(const cleora_graph *g, const float *edge_vals_dev, const float *x, uint64_t ldx,
+                              uint32_t d, float *y, uint64_t ldy, uint32_t flags, float residual_weight,
+                              const float *x_self, double *row_sqdiff, float *row_sumsq, void *stream) {
+    CL_REQUIRE(edge_vals_dev != nullptr, "edge_vals is NULL");
+    return launch_propagate(g, CLEORA_LEFT, x, ldx, d, y, ldy, flags, residual_weight, x_self, row_sqdiff,
+                            row_sumsq, S(stream), edge_vals_dev);
+}
+
+int cleora_edge_attention_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx, uint32_t d,
+                              float temperature, float *edge_vals_out_dev, void *stream) {
+    return launch_edge_attention(g, markov_type, x, ldx, d, temperature, edge_vals_out_dev, S(stream));
+}
+
 int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                       uint32_t flags, float residual_weight, const float *x_self,
                       double *row_sqdiff, float *row_sumsq, void *stream) {

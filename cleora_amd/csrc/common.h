@@ -89,7 +89,8 @@ namespace cleora {
 // spmm.hip
 int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                      float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
-                     double *row_sqdiff, float *row_sumsq, hipStream_t stream);
+                     double *row_sqdiff, float *row_sumsq, hipStream_t stream,
+                     const float *val_override = nullptr);   // per-edge values replacing g->val[kind]
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
                   float *row_sumsq, hipStream_t stream);
@@ -112,6 +113,9 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
 
+// attention.hip
+int launch_edge_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
+                          float temperature, float *vals_out, hipStream_t stream);
 // eigh.hip
 uint64_t eigh_workspace(uint32_t d);
 int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, float *mean32, hipStream_t stream);

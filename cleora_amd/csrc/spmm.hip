@@ -575,10 +575,12 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
 
 int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                      float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
-                     double *row_sqdiff, float *row_sumsq, hipStream_t stream) {
+                     double *row_sqdiff, float *row_sumsq, hipStream_t stream, const float *val_override) {
     CL_REQUIRE(g != nullptr, "graph handle is NULL");
-    CL_REQUIRE(kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC, "unknown markov_type");
-    CL_REQUIRE(g->val[kind] != nullptr, "graph has no values for this markov_type");
+    if (!val_override) {
+        CL_REQUIRE(kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC, "unknown markov_type");
+        CL_REQUIRE(g->val[kind] != nullptr, "graph has no values for this markov_type");
+    }
     CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
     CL_REQUIRE(x != y, "x and y must not alias");
@@ -602,7 +604,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
     SpmmArgs a{};
     a.rowptr = g->rowptr;
     a.col = g->col;
-    a.val = g->val[kind];
+    a.val = val_override ? val_override : g->val[kind];
     a.x = x;
     a.ldx = ldx;
     a.x_bytes = g->n_cols * ldx * sizeof(float);

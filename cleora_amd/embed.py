@@ -209,7 +209,11 @@ def embed_csr(rowptr, col, val, initial_embeddings, num_iterations=DEFAULT_NUM_I
 
 
 def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residual_weight,
-                 convergence_threshold, whiten):
+                 convergence_threshold, whiten, snapshots=None, attention_temperature=None):
+    """The device-resident iteration shared by embed(), embed_csr() and cleora_amd.variants.
+    snapshots: iteration counts after which a host copy is also kept (embed_multiscale) — the return
+    value is then the list of those copies.  attention_temperature: from iteration 1 on, the edge
+    values are recomputed from the current iterate (embed_with_attention)."""
     L = _hip.lib()
     d = x0.shape[1]
     cur = _hip.DevArray.from_host(x0)
@@ -220,6 +224,7 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
     sq = _hip.DevArray((n,), np.float64) if check else None
     ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None
     tot = _hip.DevArray((1,), np.float64) if check else None
+    attn = _hip.DevArray((max(int(g.info().nnz), 1),), np.float32) if attention_temperature is not None else None
     flags = (_hip.F_L2NORM if normalization == "l2" else 0)
     # the reference's slow path blends for any rw > 0 (:114); the kernel gates on 0 < rw < 1
     # like the Rust loop (src/embedding.rs:116).  rw >= 1 is rejected rather than guessed.
@@ -227,9 +232,16 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
         raise ValueError("residual_weight must be < 1 on the device path")
     if residual_weight > 0:
         flags |= _hip.F_RESIDUAL
+    taken = []
     for i in range(int(num_iterations)):
-        _hip.check(L.cleora_propagate_dev(g.handle, kind, cur.ptr, d, d, nxt.ptr, d, flags,
-                                          float(residual_weight), cur.ptr, None, None, None))
+        if attn is not None and i > 0:                # pycleora/__init__.py:241-269
+            _hip.check(L.cleora_edge_attention_dev(g.handle, kind, cur.ptr, d, d, float(attention_temperature),
+                                                   attn.ptr, None))
+            _hip.check(L.cleora_propagate_vals_dev(g.handle, attn.ptr, cur.ptr, d, d, nxt.ptr, d, flags,
+                                                   float(residual_weight), cur.ptr, None, None, None))
+        else:
+            _hip.check(L.cleora_propagate_dev(g.handle, kind, cur.ptr, d, d, nxt.ptr, d, flags,
+                                              float(residual_weight), cur.ptr, None, None, None))
         result = nxt
         if whitener is not None:
             whitener.whiten(nxt.ptr, d, wht.ptr, d)
@@ -237,6 +249,9 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
         if callback is not None:
             _hip.check(L.cleora_stream_sync(None))
             callback(i, result.to_host())
+        if snapshots is not None and (i + 1) in snapshots:
+            _hip.check(L.cleora_stream_sync(None))
+            taken.append(result.to_host())
         stop = False
         if check and i > 0:                           # :122-125, f64 RMSE vs the previous iterate
             _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF, 0.0,
@@ -253,6 +268,8 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
         if stop:
             break
     _hip.check(L.cleora_stream_sync(None))
+    if snapshots is not None:
+        return taken
     return cur.to_host()
 
 

@@ -1,0 +1,217 @@
+"""Device-resident forms of the reference's embed variants and link prediction.
+
+Each of these reference functions builds a scipy CSR on the host and then iterates
+`adj @ X` + `_postprocess_iteration` in numpy (pycleora/__init__.py:206-410, 784-852); here the host part
+(who is connected to whom, with which weight) is done once with vectorised numpy and the iteration runs
+in HBM through the same kernels as embed().  Signatures, defaults, return values and error messages are
+the reference's.  Arithmetic differences, stated once: the reference multiplies with f64 scipy matrices
+and rounds to f32 after every iteration; the device accumulates in f32 in edge order (the Rust kernel's
+order) — a relative difference of ~1e-6 per iteration, which the parity tests carry as their tolerance.
+
+    embed_multiscale      (:279-309)    embed_weighted        (:312-359)
+    embed_directed        (:362-410)    embed_with_attention  (:206-276)
+    embed_edge_features   (:784-852)    predict_links         (:636-681)
+"""
+import numpy as np
+
+from . import _hip
+from .embed import (DEFAULT_FEATURE_DIM, DEFAULT_NUM_ITERATIONS, _device_loop, embed, embed_csr)
+from .pycleora import SparseMatrix
+
+
+def _validate_propagation(propagation):
+    if propagation not in ("left", "symmetric"):                         # :24-26
+        raise ValueError(f"Unknown propagation type: '{propagation}'. Use 'left' or 'symmetric'.")
+
+
+def _check_device_normalization(normalization):
+    if normalization not in ("l2", "none"):
+        raise ValueError(f"the device path runs normalization 'l2' or 'none'; got '{normalization}'")
+
+
+def _row_normalised(rowptr, vals64):
+    """diags(1 / max(row_sums, 1e-10)) @ adj on CSR values, in f64 (:351-353, :400-402)."""
+    n = rowptr.shape[0] - 1
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    sums = np.bincount(rows, weights=vals64, minlength=n)
+    return vals64 / np.maximum(sums, 1e-10)[rows]
+
+
+def embed_multiscale(graph, feature_dim=DEFAULT_FEATURE_DIM, scales=None, propagation="left",
+                     normalization="l2", seed=0, num_workers=None, whiten=True):
+    """Snapshots of ONE propagation run after `scales` iterations, concatenated column-wise (:279-309)."""
+    _validate_propagation(propagation)
+    _check_device_normalization(normalization)
+    if scales is None:
+        scales = [10, 20, 30, 40]
+    if not scales or not all(isinstance(s, int) and s > 0 for s in scales):
+        raise ValueError("scales must be a non-empty list of positive integers")
+    x0 = graph.initialize_deterministically(feature_dim, seed)
+    ordered = sorted(scales)
+    kind = _hip.LEFT if propagation == "left" else _hip.SYMMETRIC
+    if graph.num_entities == 0:
+        return np.concatenate([x0.copy() for _ in ordered], axis=1)
+    with graph._lock:
+        taken = _device_loop(graph._graph(), graph.num_entities, x0, kind, ordered[-1], normalization, None,
+                             0.0, 0.0, whiten, snapshots=set(ordered))
+    by_count = dict(zip(sorted(set(ordered)), taken))
+    return np.concatenate([by_count[s] for s in ordered], axis=1)
+
+
+def embed_weighted(edges_with_weights, columns, feature_dim=DEFAULT_FEATURE_DIM,
+                   num_iterations=DEFAULT_NUM_ITERATIONS, propagation="left", normalization="l2", seed=0,
+                   hyperedge_trim_n=16, num_workers=None, whiten=True):
+    """(:312-359).  Every entity takes the largest weight (at least 1) of the lines it occurs in, the rows of
+    the Markov matrix are scaled by it and renormalised."""
+    _check_device_normalization(normalization)
+    edge_strs = [e for e, w in edges_with_weights]
+    graph = SparseMatrix.from_iterator(iter(edge_strs), columns, hyperedge_trim_n, num_workers)
+    x0 = graph.initialize_deterministically(feature_dim, seed)
+    rows, cols, vals, n, _ = graph.to_sparse_csr(propagation)
+    weight_diag = np.ones(n, dtype=np.float64)
+    index_map = {eid: i for i, eid in enumerate(graph.entity_ids)}
+    for edge_str, w in edges_with_weights:                                # :338-343
+        for ent in edge_str.strip().split():
+            idx = index_map.get(ent)
+            if idx is not None:
+                weight_diag[idx] = max(weight_diag[idx], w)
+    rowptr = graph._arr["rowptr"].astype(np.int64)
+    weighted = _row_normalised(rowptr, weight_diag[rows.astype(np.int64)] * vals.astype(np.float64))
+    emb = embed_csr(rowptr.astype(np.uint64), cols, weighted.astype(np.float32), x0, num_iterations, normalization,
+                    whiten=whiten)
+    return graph, emb
+
+
+def embed_directed(edges, columns, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITERATIONS,
+                   normalization="l2", seed=0, hyperedge_trim_n=16, num_workers=None, whiten=True):
+    """(:362-410).  Keeps the stored edge (r, c) only if some line lists r's token before c's, then
+    renormalises the rows of the left Markov matrix."""
+    _check_device_normalization(normalization)
+    edges = list(edges)
+    graph = SparseMatrix.from_iterator(iter(edges), columns, hyperedge_trim_n, num_workers)
+    n = graph.num_entities
+    index_map = {eid: i for i, eid in enumerate(graph.entity_ids)}
+    keys = set()
+    for edge_str in edges:                                                # :376-382
+        parts = [index_map.get(p) for p in edge_str.strip().split()]
+        for i in range(len(parts)):
+            if parts[i] is None:
+                continue
+            for j in range(i + 1, len(parts)):
+                if parts[j] is not None:
+                    keys.add(parts[i] * n + parts[j])
+    rows, cols, vals, _, _ = graph.to_sparse_csr("left")
+    edge_keys = rows.astype(np.int64) * n + cols.astype(np.int64)
+    keep = np.isin(edge_keys, np.fromiter(keys, dtype=np.int64, count=len(keys)))
+    kept_rows = rows[keep].astype(np.int64)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(kept_rows, minlength=n), out=rowptr[1:])
+    vals64 = _row_normalised(rowptr, vals[keep].astype(np.float64))
+    x0 = graph.initialize_deterministically(feature_dim, seed)
+    emb = embed_csr(rowptr.astype(np.uint64), cols[keep], vals64.astype(np.float32), x0, num_iterations,
+                    normalization, whiten=whiten)
+    return graph, emb
+
+
+def embed_with_attention(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITERATIONS,
+                         propagation="left", normalization="l2", attention_temperature=1.0, seed=0,
+                         num_workers=None, callback=None, whiten=True):
+    """(:206-276).  Iteration 0 is a plain propagation; from iteration 1 on every edge is re-weighted by a
+    softmax over its row of cosine(x_r, x_c) / temperature (cleora_edge_attention_dev) before the SpMM."""
+    _validate_propagation(propagation)
+    _check_device_normalization(normalization)
+    if attention_temperature <= 0:
+        raise ValueError(f"attention_temperature must be positive, got {attention_temperature}")
+    if num_iterations <= 0:
+        raise ValueError(f"num_iterations must be positive, got {num_iterations}")
+    x0 = graph.initialize_deterministically(feature_dim, seed)
+    if graph.num_entities == 0:
+        return x0
+    kind = _hip.LEFT if propagation == "left" else _hip.SYMMETRIC
+    with graph._lock:
+        return _device_loop(graph._graph(), graph.num_entities, x0, kind, int(num_iterations), normalization,
+                            callback, 0.0, 0.0, whiten, attention_temperature=float(attention_temperature))
+
+
+def embed_edge_features(graph, edge_features, feature_dim=DEFAULT_FEATURE_DIM,
+                        num_iterations=DEFAULT_NUM_ITERATIONS, propagation="left", normalization="l2",
+                        combine="concat", num_workers=None, whiten=True):
+    """(:784-852).  Structural embedding + the propagation of per-node means of the edge feature vectors."""
+    _validate_propagation(propagation)
+    struct_emb = embed(graph, feature_dim=feature_dim, num_iterations=num_iterations, propagation=propagation,
+                       normalization=normalization, num_workers=num_workers, whiten=whiten)
+    if not edge_features:
+        return struct_emb
+    edge_feat_dim = len(next(iter(edge_features.values())))
+    n = graph.num_entities
+    index_map = {eid: i for i, eid in enumerate(graph.entity_ids)}
+    node_feats = np.zeros((n, edge_feat_dim), dtype=np.float64)
+    node_counts = np.zeros(n, dtype=np.float64)
+    for edge_key, feat in edge_features.items():                          # :815-825
+        parts = edge_key.strip().split()
+        if len(parts) == 2:
+            ia, ib = index_map.get(parts[0]), index_map.get(parts[1])
+            if ia is not None and ib is not None:
+                feat_arr = np.array(feat, dtype=np.float64)
+                node_feats[ia] += feat_arr
+                node_feats[ib] += feat_arr
+                node_counts[ia] += 1
+                node_counts[ib] += 1
+    node_feats /= np.maximum(node_counts, 1.0)[:, None]
+    kind = _hip.LEFT if propagation == "left" else _hip.SYMMETRIC
+    # H is rounded to f32 by _postprocess_iteration after every iteration in the reference too (:839); only its
+    # very first SpMM sees the f64 means, which the f32 start rounds (relative 6e-8)
+    with graph._lock:
+        edge_emb = _device_loop(graph._graph(), n, np.ascontiguousarray(node_feats.astype(np.float32)), kind,
+                                int(num_iterations), "l2", None, 0.0, 0.0, whiten) if num_iterations > 0 \
+            else node_feats.astype(np.float32)
+    if combine == "concat":
+        return np.concatenate([struct_emb, edge_emb], axis=1)
+    if combine == "mean":
+        min_dim = min(struct_emb.shape[1], edge_emb.shape[1])
+        return (struct_emb[:, :min_dim] + edge_emb[:, :min_dim]) / 2.0
+    if combine == "edge_only":
+        return edge_emb
+    raise ValueError(f"Unknown combine mode: '{combine}'. Use 'concat', 'mean', or 'edge_only'.")
+
+
+def predict_links(graph, embeddings, top_k=10, exclude_existing=True, source_entities=None):
+    """(:636-681).  For every source entity: cosine similarity to all entities (one pass over the resident X
+    per source, cleora_cosine_scores_dev), the source itself and — optionally — its stored neighbours in either
+    direction masked with -2, the top_k of the rest; finally the top_k of all candidates by score."""
+    x = np.ascontiguousarray(embeddings, dtype=np.float32)
+    n, d = x.shape
+    if source_entities is not None:
+        source_indices = [graph.get_entity_index(eid) for eid in source_entities]
+    else:
+        source_indices = list(range(graph.num_entities))
+    ids = graph.entity_ids
+    rowptr = graph._arr["rowptr"].astype(np.int64)
+    col = graph._arr["col"].astype(np.int64)
+    reverse = None
+    if exclude_existing:                                                  # (other, src) edges: a CSC view
+        order = np.argsort(col, kind="stable")
+        rows = np.repeat(np.arange(graph.num_entities), np.diff(rowptr))
+        reverse = (np.concatenate([[0], np.cumsum(np.bincount(col, minlength=graph.num_entities))]), rows[order])
+    L = _hip.lib()
+    normed = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)          # :643-645
+    dx = _hip.DevArray.from_host(np.ascontiguousarray(normed))
+    dq = _hip.DevArray((d,), np.float32)
+    ds = _hip.DevArray((n,), np.float32)
+    predictions = []
+    for src in source_indices:
+        _hip.check(L.cleora_memcpy_h2d(dq.ptr, _hip.ptr(np.ascontiguousarray(normed[src])), d * 4, None))
+        _hip.check(L.cleora_cosine_scores_dev(dx.ptr, d, n, d, dq.ptr, ds.ptr, None))
+        _hip.check(L.cleora_stream_sync(None))
+        sims = ds.to_host()
+        sims[src] = -2.0
+        if exclude_existing:
+            sims[col[rowptr[src]:rowptr[src + 1]]] = -2.0
+            cptr, crow = reverse
+            sims[crow[cptr[src]:cptr[src + 1]]] = -2.0
+        for tgt in np.argsort(sims)[::-1][:top_k]:
+            if sims[tgt] <= -2.0:
+                continue
+            predictions.append({"source": ids[src], "target": ids[int(tgt)], "score": float(sims[int(tgt)])})
+    predictions.sort(key=lambda p: p["score"], reverse=True)
+    return predictions[:top_k]

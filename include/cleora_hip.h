@@ -137,6 +137,20 @@ int cleora_propagate_dev(const cleora_graph *g, int markov_type, const float *x,
                          float residual_weight, const float *x_self, double *row_sqdiff,
                          float *row_sumsq, void *stream);
 
+/* The same SpMM with CALLER-SUPPLIED per-edge values (f32[nnz], the graph's edge order) in place of the stored
+ * Markov values: the `weighted_adj @ embeddings` step of the reference's re-weighted variants
+ * (embed_with_attention, pycleora/__init__.py:269; any host that rescales edges between iterations). */
+int cleora_propagate_vals_dev(const cleora_graph *g, const float *edge_vals_dev, const float *x, uint64_t ldx,
+                              uint32_t d, float *y, uint64_t ldy, uint32_t flags, float residual_weight,
+                              const float *x_self, double *row_sqdiff, float *row_sumsq, void *stream);
+
+/* Attention weights of embed_with_attention (pycleora/__init__.py:241-268) for every stored edge (r, c):
+ * score = cos(x_r, x_c) / temperature; softmax over the row's edges; multiplied by the stored Markov value of
+ * `markov_type` and renormalised so each row sums to 1 (each denominator clamped at 1e-10 like the reference).
+ * edge_vals_out_dev: f32[nnz] in edge order, ready for cleora_propagate_vals_dev.  Square graphs only. */
+int cleora_edge_attention_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx, uint32_t d,
+                              float temperature, float *edge_vals_out_dev, void *stream);
+
 /* Row-wise epilogue alone: NdArrayMatrix::l2_normalize_inplace (src/embedding.rs:88-104) when
  * flags = CLEORA_F_L2NORM; same flags as above.  x may equal y (in place). */
 int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,

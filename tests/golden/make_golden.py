@@ -15,6 +15,8 @@ What it writes
                         _normalize(…,"l2") (:942-946), whiten_embeddings (:130-164),
                         _postprocess_iteration (:963-971), _compute_rmse (:974-976)
                         on seeded inputs (the seeds are stored with the outputs).
+  variants_ref.npz      embed_multiscale / embed_weighted / embed_directed / embed_with_attention /
+                        embed_edge_features / predict_links of the reference, on karate club.
   karate_ref.npz        config 1: karate_club lines + labels (datasets.py:283-331,
                         data only) and the result of the reference's embed()
                         (:51-127, whiten=True and whiten=False) run UNMODIFIED over
@@ -75,6 +77,9 @@ class StubSparseMatrix:
         val = self.g.val_left if propagation == "left" else self.g.val_sym
         x0 = oracle.init(self.g.entity_hashes, feature_dim, seed)
         return oracle.embed(self.g.rowptr, self.g.col, val, x0, num_iterations, residual_weight)[0]
+
+    def get_entity_index(self, entity_id):
+        return self.entity_ids.index(entity_id)
 
     def to_sparse_csr(self, markov_type=None):
         g = self.g
@@ -146,6 +151,33 @@ def main():
                                           callback=lambda i, e: None)        # slow path, no whiten
     kar["embed_resid_d16"] = pc.embed(g, 16, 10, residual_weight=0.3, whiten=True)
     np.savez_compressed(os.path.join(HERE, "karate_ref.npz"), **kar)
+
+    # 4. the embed variants and predict_links (pycleora/__init__.py:206-410, 636-681, 784-852), reference
+    #    functions run unmodified over the stub, on karate club
+    edges = [str(e) for e in ds["edges"]]
+    columns = str(ds["columns"])
+    rng = np.random.default_rng(77)
+    weights = rng.uniform(0.5, 3.0, len(edges))
+    feat_keys = edges[::2]
+    feats = rng.standard_normal((len(feat_keys), 3))
+    var = {"weights": weights, "feat_keys": np.array(feat_keys), "feats": feats}
+    for tag, wh in (("w", True), ("n", False)):
+        var[f"multiscale_{tag}"] = pc.embed_multiscale(g, 8, scales=[2, 5, 3], whiten=wh)
+        var[f"weighted_{tag}"] = pc.embed_weighted(list(zip(edges, weights.tolist())), columns, 8, 5,
+                                                   propagation="symmetric", whiten=wh)[1]
+        var[f"directed_{tag}"] = pc.embed_directed(edges, columns, 8, 5, whiten=wh)[1]
+        var[f"attention_{tag}"] = pc.embed_with_attention(g, 8, 4, attention_temperature=0.7, whiten=wh)
+        var[f"attention_sym_{tag}"] = pc.embed_with_attention(g, 8, 3, propagation="symmetric",
+                                                              attention_temperature=2.0, whiten=wh)
+        var[f"edgefeat_{tag}"] = pc.embed_edge_features(g, dict(zip(feat_keys, feats)), 8, 3, whiten=wh)
+    emb = kar["embed_whiten_d16"]
+    for tag, kw in (("all", dict(top_k=12)), ("some", dict(top_k=7, source_entities=["0", "33", "5"])),
+                    ("keep", dict(top_k=9, exclude_existing=False, source_entities=["1", "2"]))):
+        pred = pc.predict_links(g, emb, **kw)
+        var[f"pred_{tag}_source"] = np.array([p["source"] for p in pred])
+        var[f"pred_{tag}_target"] = np.array([p["target"] for p in pred])
+        var[f"pred_{tag}_score"] = np.array([p["score"] for p in pred])
+    np.savez_compressed(os.path.join(HERE, "variants_ref.npz"), **var)
     print("golden fixtures written to", HERE)
 
 

@@ -1,0 +1,159 @@
+"""GPU: the device-resident embed variants and predict_links (cleora_amd/variants.py) against the outputs of
+the reference's own functions (tests/golden/variants_ref.npz, produced by tests/golden/make_golden.py from
+/root/reference/pycleora/__init__.py:206-410, 636-681, 784-852 on karate club).
+
+Tolerances (floating point, stated):
+  whiten=False runs: the reference accumulates `adj @ X` in f64 and rounds to f32 once per iteration, the
+      device accumulates in f32 in edge order: |delta| <= 2e-5 on unit-norm rows after <= 5 iterations.
+  whiten=True runs (d = 8 < rank 33, well conditioned): columns compared after sign alignment (eigh's sign
+      is arbitrary), |delta| <= 5e-3 * max|ref|, and the pairwise-cosine matrices agree to 1e-4.
+  predict_links: same (source, target) pairs in the same order, scores to 2e-6.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from cleora_amd import _hip, variants
+from cleora_amd.pycleora import SparseMatrix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    k = np.load(os.path.join(golden_dir, "karate_ref.npz"))
+    v = np.load(os.path.join(golden_dir, "variants_ref.npz"))
+    edges = [str(s) for s in k["edges"]]
+    g = SparseMatrix.from_iterator(iter(edges), str(k["columns"]))
+    return k, v, edges, str(k["columns"]), g
+
+
+def cosine_matrix(e):
+    e = e.astype(np.float64)
+    e = e / np.maximum(np.linalg.norm(e, axis=1, keepdims=True), 1e-300)
+    return e @ e.T
+
+
+def assert_close(got, want, whitened, blocks=1, lead=None):
+    """lead: compare only the `lead` leading whitened components (the trailing ones of a nearly singular
+    covariance are amplified rounding noise in the reference itself)."""
+    assert got.shape == want.shape and got.dtype == np.float32
+    if not whitened:
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-5)
+        return
+    w = want.shape[1] // blocks
+    for b in range(blocks):                                 # concatenated outputs: every block is whitened separately
+        a, r = got[:, b * w:(b + 1) * w][:, :lead], want[:, b * w:(b + 1) * w][:, :lead]
+        s = np.sign((a * r).sum(axis=0))
+        assert np.abs(a * s - r).max() <= 5e-3 * np.abs(r).max()
+        assert np.abs(cosine_matrix(a) - cosine_matrix(r)).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag,wh", [("w", True), ("n", False)])
+def test_embed_multiscale(ref, tag, wh):
+    k, v, edges, columns, g = ref
+    got = variants.embed_multiscale(g, 8, scales=[2, 5, 3], whiten=wh)
+    assert_close(got, v[f"multiscale_{tag}"], wh, blocks=3)
+    with pytest.raises(ValueError, match="scales must be"):
+        variants.embed_multiscale(g, 8, scales=[])
+
+
+@pytest.mark.parametrize("tag,wh", [("w", True), ("n", False)])
+def test_embed_weighted(ref, tag, wh):
+    k, v, edges, columns, g = ref
+    graph, got = variants.embed_weighted(list(zip(edges, v["weights"].tolist())), columns, 8, 5,
+                                         propagation="symmetric", whiten=wh)
+    assert graph.entity_ids == g.entity_ids
+    assert_close(got, v[f"weighted_{tag}"], wh)
+
+
+@pytest.mark.parametrize("tag,wh", [("w", True), ("n", False)])
+def test_embed_directed(ref, tag, wh):
+    k, v, edges, columns, g = ref
+    graph, got = variants.embed_directed(edges, columns, 8, 5, whiten=wh)
+    assert graph.num_entities == g.num_entities
+    # 15 of the 34 karate nodes have no outgoing edge in the directed graph (zero rows): the covariance is nearly
+    # singular and the last two whitened components are noise; the first six are compared
+    assert_close(got, v[f"directed_{tag}"], wh, lead=6)
+
+
+@pytest.mark.parametrize("tag,wh", [("w", True), ("n", False)])
+def test_embed_with_attention(ref, tag, wh):
+    k, v, edges, columns, g = ref
+    seen = []
+    got = variants.embed_with_attention(g, 8, 4, attention_temperature=0.7, whiten=wh,
+                                        callback=lambda i, e: seen.append(i))
+    assert seen == [0, 1, 2, 3]
+    assert_close(got, v[f"attention_{tag}"], wh)
+    got = variants.embed_with_attention(g, 8, 3, propagation="symmetric", attention_temperature=2.0, whiten=wh)
+    assert_close(got, v[f"attention_sym_{tag}"], wh)
+    with pytest.raises(ValueError, match="attention_temperature must be positive"):
+        variants.embed_with_attention(g, 8, 3, attention_temperature=0.0)
+    with pytest.raises(ValueError, match="num_iterations must be positive"):
+        variants.embed_with_attention(g, 8, 0)
+
+
+def test_edge_attention_weights_vs_numpy(ref):
+    """cleora_edge_attention_dev alone against a numpy restatement of pycleora/__init__.py:241-268 on a random
+    iterate: rows sum to 1, weights to 1e-6 relative."""
+    k, v, edges, columns, g = ref
+    rowptr, col, adj = k["rowptr"].astype(np.int64), k["col"].astype(np.int64), k["val_left"].astype(np.float64)
+    n, d, temp = g.num_entities, 24, 0.5
+    x = np.random.default_rng(3).standard_normal((n, d)).astype(np.float32)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    xn = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)
+    score = np.sum(xn[rows] * xn[col], axis=1) / temp
+    mx = np.full(n, -np.inf)
+    np.maximum.at(mx, rows, score)
+    ex = np.exp(score - mx[rows])
+    a = ex / np.maximum(np.bincount(rows, weights=ex, minlength=n), 1e-10)[rows] * adj
+    want = a / np.maximum(np.bincount(rows, weights=a, minlength=n), 1e-10)[rows]
+    L = _hip.lib()
+    dx = _hip.DevArray.from_host(x)
+    dv = _hip.DevArray((col.shape[0],), np.float32)
+    _hip.check(L.cleora_edge_attention_dev(g._graph().handle, _hip.LEFT, dx.ptr, d, d, temp, dv.ptr, None))
+    _hip.check(L.cleora_stream_sync(None))
+    got = dv.to_host()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(np.bincount(rows, weights=got, minlength=n), 1.0, atol=1e-6)
+    # and the SpMM with caller-supplied values
+    dy = _hip.DevArray((n, d), np.float32)
+    _hip.check(L.cleora_propagate_vals_dev(g._graph().handle, dv.ptr, dx.ptr, d, d, dy.ptr, d, 0, 0.0, None, None,
+                                           None, None))
+    _hip.check(L.cleora_stream_sync(None))
+    import oracle
+    np.testing.assert_array_equal(dy.to_host(), oracle.spmm(k["rowptr"], k["col"], got, x))
+
+
+@pytest.mark.parametrize("tag,wh", [("w", True), ("n", False)])
+def test_embed_edge_features(ref, tag, wh):
+    k, v, edges, columns, g = ref
+    feats = dict(zip([str(s) for s in v["feat_keys"]], v["feats"]))
+    got = variants.embed_edge_features(g, feats, 8, 3, whiten=wh)
+    want = v[f"edgefeat_{tag}"]
+    assert got.shape == want.shape == (g.num_entities, 11)
+    assert_close(got[:, :8], want[:, :8], wh)
+    assert_close(got[:, 8:], want[:, 8:], wh)
+    only = variants.embed_edge_features(g, feats, 8, 3, combine="edge_only", whiten=wh)
+    np.testing.assert_array_equal(only, got[:, 8:])
+    with pytest.raises(ValueError, match="Unknown combine mode"):
+        variants.embed_edge_features(g, feats, 8, 1, combine="sum")
+
+
+@pytest.mark.parametrize("tag,kw", [("all", dict(top_k=12)),
+                                    ("some", dict(top_k=7, source_entities=["0", "33", "5"])),
+                                    ("keep", dict(top_k=9, exclude_existing=False, source_entities=["1", "2"]))])
+def test_predict_links(ref, tag, kw):
+    k, v, edges, columns, g = ref
+    got = variants.predict_links(g, k["embed_whiten_d16"], **kw)
+    want_s, want_t, want_sc = v[f"pred_{tag}_source"], v[f"pred_{tag}_target"], v[f"pred_{tag}_score"]
+    assert len(got) == len(want_sc)
+    np.testing.assert_allclose([p["score"] for p in got], want_sc, rtol=0, atol=2e-6)
+    # candidates whose scores tie within the tolerance may swap places; everything else is in order
+    for i, p in enumerate(got):
+        if (p["source"], p["target"]) != (str(want_s[i]), str(want_t[i])):
+            close = np.abs(want_sc - p["score"]) <= 2e-6
+            assert (p["source"], p["target"]) in {(str(a), str(b)) for a, b in zip(want_s[close], want_t[close])}
+    with pytest.raises(ValueError, match="not found"):
+        variants.predict_links(g, k["embed_whiten_d16"], source_entities=["no-such-entity"])

@@ -192,6 +192,16 @@ def test_accelerate_rebinds_reference_entry_points():
     g = SparseMatrix.from_iterator(iter(["a b", "b c"]), "complex::reflexive::n")
     assert pkg.embed(g, 8, 2, normalization="l1") == "orig"
     assert calls == [("orig", None), ("orig", "l1")]
+    # the variants are rebound when the package has them; foreign graphs / normalisations are forwarded
+    pkg2 = types.SimpleNamespace(embed=pkg.embed.__wrapped__, whiten_embeddings=None,
+                                 embed_multiscale=lambda *a, **k: "orig-ms", predict_links=lambda *a, **k: "orig-pl")
+    cleora_amd.accelerate(pkg2)
+    assert pkg2.embed_multiscale(object(), 8) == "orig-ms"
+    assert pkg2.embed_multiscale(g, 8, normalization="spectral") == "orig-ms"
+    assert pkg2.predict_links(object(), np.zeros((2, 2), np.float32)) == "orig-pl"
+    assert not hasattr(pkg2, "embed_weighted")
+    with pytest.raises(ValueError, match="scales must be"):
+        pkg2.embed_multiscale(g, 8, scales=[0])                                 # our implementation validates first
     with pytest.raises(RuntimeError):          # l2 goes to the device path: no GPU here, and no fallback
         if __import__("cleora_amd._hip", fromlist=["x"]).device_count() == 0:
             pkg.embed(g, 8, 2, whiten=False)

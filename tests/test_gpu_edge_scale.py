@@ -122,6 +122,15 @@ def test_properties_at_baseline_sizes(config):
     x = torch.randn((n, d), dtype=torch.float32, device=dev)
     y1, y2 = prop(graph, x), prop(graph, x)
     assert torch.equal(y1, y2)
+    # 2b. the automatic gather cache policy (hot.hip) arms on the third launch when X >= 1 GiB and d >= 256:
+    #     y1 ran without it, y2 with it (C3), and switching it off again changes no bit either
+    armed = graph.info().hot_rows
+    assert (armed > 0) == config.startswith("C3")
+    graph.set_hot_cache(0)
+    assert torch.equal(prop(graph, x), y1) and graph.info().hot_rows == 0
+    graph.set_hot_cache(256 << 20)
+    assert torch.equal(prop(graph, x), y1) and 0 < graph.info().hot_rows <= (256 << 20) // (d * 4)
+    graph.set_hot_cache(-1)
     # 3. linearity: A(2x) = 2 A x exactly (power-of-two scaling commutes with every rounding)
     assert torch.equal(prop(graph, x * 2.0), y1 * 2.0)
     # 4. hub split changes only the split rows, and only within summation-order tolerance

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double *__restrict__ 
 
 // ---- cosine scores against one query (find_most_similar, pycleora/__init__.py:753-781) --------------
 // scores[r] = (x[r] . q) / max(||x[r]||, 1e-10); one wavefront per row, one pass over X (HBM-bound).
+template <bool W4>
 __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ x, uint64_t ldx, uint64_t n,
                                                      uint32_t d, const float *__restrict__ q,
                                                      float *__restrict__ scores) {
@@ -145,10 +146,19 @@ __global__ __launch_bounds__(256) void cosine_kernel(const float *__restrict__ x
     if (row >= n) return;
     const float *xr = x + row * ldx;
     float dot = 0.f, sq = 0.f;
-    for (uint32_t c = lane; c < d; c += 64) {
-        const float v = xr[c];
-        dot += v * q[c];
-        sq += v * v;
+    if constexpr (W4) {                       // 16 B per lane: one wavefront load covers a whole 1 KiB row
+        for (uint32_t c = lane * 4; c < d; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(xr + c);
+            const float4 w = *reinterpret_cast<const float4 *>(q + c);
+            dot += v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+            sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (uint32_t c = lane; c < d; c += 64) {
+            const float v = xr[c];
+            dot += v * q[c];
+            sq += v * v;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -167,7 +177,10 @@ int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const fl
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && q != nullptr && scores != nullptr, "x / q / scores is NULL");
     if (n == 0) return CLEORA_OK;
-    hipLaunchKernelGGL(cosine_kernel, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, x, ldx, n, d, q, scores);
+    if ((d % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && aligned16(q))
+        hipLaunchKernelGGL(cosine_kernel<true>, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, x, ldx, n, d, q, scores);
+    else
+        hipLaunchKernelGGL(cosine_kernel<false>, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, x, ldx, n, d, q, scores);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

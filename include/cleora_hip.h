@@ -18,6 +18,10 @@
  *     the default stream) and only enqueue work.  The others take HOST pointers,
  *     borrow them for the duration of the call and return with results on the host.
  *   - matrices are row-major f32 with a leading dimension in ELEMENTS (ld >= d).
+ *   - threads: every entry point may be called from any thread; calls on one graph handle are
+ *     serialised by a mutex inside the handle while they enqueue.  A handle owns device scratch
+ *     (hub-row partial sums, timing events), so launches on the SAME handle must be ordered on the
+ *     device too — use one stream per handle (or the default stream); different handles are independent.
  *   - there is no CPU fallback: without a gfx950 device every compute entry point
  *     fails with CLEORA_E_NODEVICE / CLEORA_E_HIP.
  */

@@ -206,3 +206,36 @@ def test_find_most_similar(karate):
     assert 0 not in [r["index"] for r in got]
     with pytest.raises(ValueError, match="not found"):
         dev_embed.find_most_similar(g, emb, "nope")
+
+
+def test_concurrent_calls_from_several_threads(karate):
+    """The reference's methods take &self and may be called from several Python threads (SURVEY.md §8b);
+    the drop-in guards its device state: results under contention equal the serial ones bit for bit."""
+    import threading
+    k, g = karate
+    rng = np.random.default_rng(77)
+    xs = [rng.standard_normal((g.num_entities, 24)).astype(np.float32) for _ in range(6)]
+    serial = [(g.left_markov_propagate(x), g.symmetric_markov_propagate(x), g.embed_fast(16, 5, seed=i))
+              for i, x in enumerate(xs)]
+    lines = [str(s) for s in k["edges"]]
+    results, errors = [None] * len(xs), []
+
+    def worker(i):
+        try:
+            for _ in range(5):
+                own = SparseMatrix.from_iterator(iter(lines), str(k["columns"]))      # a second handle per thread
+                results[i] = (g.left_markov_propagate(xs[i]), g.symmetric_markov_propagate(xs[i]),
+                              g.embed_fast(16, 5, seed=i))
+                np.testing.assert_array_equal(own.left_markov_propagate(xs[i]), results[i][0])
+        except Exception as ex:  # surfaced below: an assertion inside a thread would otherwise be lost
+            errors.append(ex)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)

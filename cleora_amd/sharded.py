@@ -170,8 +170,8 @@ class ShardedGraph:
     def whiten(self, y, out, n_components=None):
         """whiten_embeddings (pycleora/__init__.py:130-164) over the row partition: `y` holds this
         rank's blocks of the matrix to whiten; `out` receives the whitened matrix, replicated.
-        Local f64 column sums and centred Gram -> all-reduce (d and d*d doubles) -> eigh on rank 0,
-        transform broadcast -> row-local projection -> in-place all-gather per block."""
+        Local f64 column sums and centred Gram -> all-reduce (d and d*d doubles) -> transform
+        (cleora_whiten_transform_dev, replicated; rank 0's copy is broadcast) -> row-local projection -> in-place all-gather per block."""
         import numpy as np
         d = y.shape[1]
         cs = torch.zeros(d, dtype=torch.float64, device=y.device)

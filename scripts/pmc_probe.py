@@ -17,11 +17,12 @@ ap.add_argument("--nodes", type=int, default=10_000_000)
 ap.add_argument("--pairs", type=int, default=95_000_000)
 ap.add_argument("--dim", type=int, default=256)
 ap.add_argument("--iters", type=int, default=7)   # the automatic gather cache policy arms on the third launch
+ap.add_argument("--graph", default="c3", choices=["c3", "c2"], help="c3: power-law generator; c2: BASELINE config 2, bipartite 500k x 500k, 10M pairs")
 ap.add_argument("--hot", type=int, default=-1, help="cleora_graph_set_hot_cache: -1 automatic, 0 off, >0 bytes")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 L = _hip.lib()
-g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)
+g = synth.bipartite_graph(500_000, 500_000, 10_000_000, 1, dev) if args.graph == "c2" else synth.power_law_graph(args.nodes, args.pairs, 2, dev)
 n, nnz, d = g["n"], g["nnz"], args.dim
 graph = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(),
                                g["val_left"].data_ptr(), None, 0, 0, 0, keepalive=g)

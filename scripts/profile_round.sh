@@ -15,9 +15,15 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pm
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/fetch_nohot.log" 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/hit.log" 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/hit_nohot.log" 2>&1
+# whitening kernels: MFMA pipe occupancy (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, GRBM_GUI_ACTIVE per XCD)
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/wpmc" -o pmc -- python "$root/scripts/whiten_probe.py" > "$out/wpmc.log" 2>&1
+# BASELINE config 2 (bipartite 1M / 20M, d = 256): kernel time and HBM bytes of the same kernel
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c2_stats" -o c2 -- python "$root/scripts/pmc_probe.py" --graph c2 --iters 40 > "$out/c2_stats.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/c2_fetch" -o pmc -- python "$root/scripts/pmc_probe.py" --graph c2 > "$out/c2_fetch.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/c2_write" -o pmc -- python "$root/scripts/pmc_probe.py" --graph c2 > "$out/c2_write.log" 2>&1
 timeout 600 python "$root/bench.py" > "$out/bench_plain.log" 2>&1
 tail -1 "$out/bench_plain.log"
-for f in fetch write fetch_nohot hit hit_nohot; do tail -1 "$out/$f.log"; done
+for f in fetch write fetch_nohot hit hit_nohot wpmc c2_stats c2_fetch c2_write; do tail -1 "$out/$f.log" | cut -c1-200; done
 # keep the merge under the gpurun_out size limit: only the summaries that summarize_profile.py reads
 find "$out" -type f ! -name "*_kernel_stats.csv" ! -name "pmc_counter_collection.csv" ! -name "*.log" -delete
 find "$out" -type f -size +8M -exec sh -c 'grep cleora "$1" > "$1.tmp"; head -1 "$1" | cat - "$1.tmp" > "$1.f"; mv "$1.f" "$1"; rm "$1.tmp"' _ {} \;

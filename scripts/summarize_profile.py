@@ -105,3 +105,42 @@ json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"profiles/{tag}
            "bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"]},
           open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+
+# 3. whitening kernels: MFMA pipe occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)
+wp = os.path.join(src, "wpmc", "pmc_counter_collection.csv")
+if os.path.exists(wp):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(wp)):
+        if "cleora" in r["Kernel_Name"] and ("gram_kernel" in r["Kernel_Name"] or "project_kernel" in r["Kernel_Name"]):
+            acc[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    wout = {"formula": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)  [8 XCDs, 1024 SIMDs]", "kernels": []}
+    for (name, grid), c in sorted(acc.items()):
+        busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+        act = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+        wout["kernels"].append({"kernel": name, "grid_size": int(grid), "launches": len(c["GRBM_GUI_ACTIVE"]),
+                                "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": act,
+                                "mfma_busy": busy / (act / 8 * 1024)})
+    json.dump(wout, open(os.path.join(dst, f"{tag}_whiten_pmc.json"), "w"), indent=1)
+
+# 4. BASELINE config 2 on one GPU: kernel time (rocprofv3 stats) and HBM bytes (PMC) of the same SpMM kernel
+c2s = os.path.join(src, "c2_stats", "c2_kernel_stats.csv")
+if os.path.exists(c2s):
+    m2 = re.search(r"PMC_PROBE n=(\d+) nnz=(\d+) d=(\d+)", open(os.path.join(src, "c2_stats.log")).read())
+    n2, nnz2, d2 = (int(v) for v in m2.groups())
+    st = [r for r in csv.DictReader(open(c2s)) if "spmm_rows_kernel" in r["Name"]][0]
+    byt = {}
+    for kind, counter in (("c2_fetch", "FETCH_SIZE"), ("c2_write", "WRITE_SIZE")):
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(src, kind, "pmc_counter_collection.csv")))
+                if "spmm_rows_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        byt[counter] = sum(vals) / len(vals)
+    alg = nnz2 * 8 + (n2 + 1) * 8 + nnz2 * d2 * 4 + n2 * d2 * 4
+    pmc_bytes = byt["FETCH_SIZE"] * 1024 * fetch_corr + byt["WRITE_SIZE"] * 1024 * write_corr
+    avg_ms = float(st["AverageNs"]) / 1e6
+    json.dump({"config": "BASELINE config 2: bipartite 500k x 500k, 10M pairs, d=256, left Markov, SpMM + fused L2",
+               "n": n2, "nnz": nnz2, "d": d2, "kernel": short(st["Name"]), "launches": int(st["Calls"]), "avg_launch_ms": avg_ms,
+               "algorithmic_bytes_per_launch": alg, "algorithmic_GBps": alg / avg_ms / 1e6,
+               "pmc_bytes_per_launch": pmc_bytes, "pmc_GBps": pmc_bytes / avg_ms / 1e6,
+               "note": "X is 1.0 GB: part of it stays in L2 / Infinity Cache, so the fabric-side PMC bytes are below the gather model; "
+                       "the PMC counters include Infinity-Cache hits"},
+              open(os.path.join(dst, f"{tag}_c2.json"), "w"), indent=1)

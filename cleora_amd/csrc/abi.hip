@@ -515,6 +515,14 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
     CL_HIP(hipMemcpy(x.p, x_host, n * (uint64_t)d * sizeof(float), hipMemcpyHostToDevice));
     if ((rc = launch_whiten(x.as<float>(), d, n, d, k, y.as<float>(), k, ws.p, nullptr, nullptr)) != CLEORA_OK) return rc;
     CL_HIP(hipMemcpy(y_host, y.p, n * (uint64_t)k * sizeof(float), hipMemcpyDeviceToHost));
+    if (n > 1) {
+        int info = 0;
+        CL_HIP(hipMemcpy(&info, whiten_info(ws.p, n, d), sizeof(int), hipMemcpyDeviceToHost));
+        if (info != 0) {
+            set_error("the eigensolver did not converge (dsyevd info = " + std::to_string(info) + ")");
+            return CLEORA_E_HIP;
+        }
+    }
     return CLEORA_OK;
 }
 
@@ -554,6 +562,14 @@ int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int mark
             }
         }
         std::swap(prev, next);
+    }
+    if (n > 1 && max_iterations > 0) {
+        int info = 0;
+        CL_HIP(hipMemcpy(&info, whiten_info(ws.p, n, d), sizeof(int), hipMemcpyDeviceToHost));
+        if (info != 0) {
+            set_error("the eigensolver did not converge (dsyevd info = " + std::to_string(info) + ")");
+            return CLEORA_E_HIP;
+        }
     }
     *result = prev;
     if (iterations_run) *iterations_run = actual;

@@ -122,6 +122,7 @@ int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, fl
 int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t k, float *transform,
                             double *eigenvalues, void *workspace, hipStream_t stream);
 uint64_t whiten_workspace(uint64_t n, uint32_t d);
+const int *whiten_info(void *workspace, uint64_t n, uint32_t d);
 int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
                   void *workspace, double *eigenvalues, hipStream_t stream);
 

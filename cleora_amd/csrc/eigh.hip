@@ -200,6 +200,13 @@ inline uint64_t whiten_ws_layout(uint64_t n, uint32_t d, void *base, WhitenWs *o
 
 uint64_t whiten_workspace(uint64_t n, uint32_t d) { return whiten_ws_layout(n, d, nullptr, nullptr); }
 
+// dsyevd's convergence flag of the last launch_whiten on this workspace (0 = converged), on the device
+const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
+    WhitenWs w;
+    whiten_ws_layout(n, d, workspace, &w);
+    return carve_transform(w.eigh, d).info;
+}
+
 int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
                   void *workspace, double *eigenvalues, hipStream_t stream) {
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");

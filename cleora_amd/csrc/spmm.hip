@@ -412,6 +412,50 @@ __global__ __launch_bounds__(256) void rowops_kernel(const float *x, uint64_t ld
     finish_row<G, V, W, false>(ra, row, gl, gbase, acc);
 }
 
+// ---- stand-alone exact-order L2 normalise: 16 lanes per row, E4 float4 per lane --------------------
+// NdArrayMatrix::l2_normalize_inplace (src/embedding.rs:88-104) sums the squares of a row strictly in index
+// order.  With one wavefront per row that chain is 256 dependent full-wave adds (the fused SpMM hides them
+// behind its gathers; alone they made this pass ALU-bound at 1.5 TB/s).  Here a row lives in ONE 16-lane DPP
+// row, lane l holding the 4*E4 consecutive elements [l*4*E4, (l+1)*4*E4): the running sum walks the lane's
+// elements, then moves one lane to the right with `row_shr:1` (lane 0 receives 0).  Every round recomputes all
+// lanes from their left neighbour, so after round r lanes 0..r hold the exact prefix sums; 16 rounds of
+// (1 + 4*E4) instructions serve FOUR rows: 17 instead of 320 wave instructions per row at d = 256, same bits.
+template <int E4>
+__global__ __launch_bounds__(256) void l2_exact16_kernel(const float *__restrict__ x, uint64_t ldx, uint64_t n,
+                                                         float *__restrict__ y, uint64_t ldy) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const uint64_t row = (CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < n;
+    float4 v[E4];
+    const float *xr = x + (live ? row : 0) * ldx + (uint32_t)sub * (4 * E4);
+#pragma unroll
+    for (int i = 0; i < E4; ++i) v[i] = live ? *reinterpret_cast<const float4 *>(xr + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float sq[4 * E4];
+#pragma unroll
+    for (int i = 0; i < E4; ++i) {
+        sq[4 * i + 0] = fmul(v[i].x, v[i].x);
+        sq[4 * i + 1] = fmul(v[i].y, v[i].y);
+        sq[4 * i + 2] = fmul(v[i].z, v[i].z);
+        sq[4 * i + 3] = fmul(v[i].w, v[i].w);
+    }
+    float s = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < 16; ++r) {
+        // previous lane's running sum; row_shr:1 with bound_ctrl: lane 0 of each 16-lane row reads 0
+        s = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x111, 0xF, 0xF, true));
+#pragma unroll
+        for (int e = 0; e < 4 * E4; ++e) s = fadd(s, sq[e]);
+    }
+    s = __shfl(s, lane | 15, 64);                       // the row's total sits in its last lane
+    const float norm = fmaxf(sqrtf(s), 1e-10f);        // src/embedding.rs:98-102
+    const float inv = (1.0f / norm);
+    if (!live) return;
+    float *yr = y + row * ldy + (uint32_t)sub * (4 * E4);
+#pragma unroll
+    for (int i = 0; i < E4; ++i)
+        *reinterpret_cast<float4 *>(yr + 4 * i) = make_float4(fmul(v[i].x, inv), fmul(v[i].y, inv), fmul(v[i].z, inv), fmul(v[i].w, inv));
+}
+
 // ---- rows wider than the register-resident shapes: wave per row, two passes -----------------
 __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64_t ldx, uint64_t n,
                                                           const RowArgs ra) {
@@ -670,6 +714,21 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
     ra.d = d;
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
                     (!x_self || aligned16(x_self));
+    if (flags == CLEORA_F_L2NORM && w4 && d % 64 == 0) {   // plain exact-order normalise: 16 lanes per row
+        const dim3 grid = grid_for(n, 16);
+        bool done = true;
+        switch (d / 64) {
+            case 1: hipLaunchKernelGGL(l2_exact16_kernel<1>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
+            case 2: hipLaunchKernelGGL(l2_exact16_kernel<2>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
+            case 4: hipLaunchKernelGGL(l2_exact16_kernel<4>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
+            case 8: hipLaunchKernelGGL(l2_exact16_kernel<8>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
+            default: done = false;
+        }
+        if (done) {
+            CL_HIP(hipGetLastError());
+            return CLEORA_OK;
+        }
+    }
     const bool ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
         hipLaunchKernelGGL((rowops_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
                            grid_for(n, 256 / decltype(G)::value), dim3(256), 0, stream, x, ldx, n, ra);

@@ -223,3 +223,23 @@ def test_hot_column_policy_changes_no_bit(d):
     mask = np.ones(n, bool)
     mask[5] = False
     np.testing.assert_array_equal(base[mask], oracle.l2_normalize(oracle.spmm(rowptr, col, val, x))[mask])
+
+
+@pytest.mark.parametrize("d", [64, 128, 256, 512, 192, 320])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1001])
+def test_standalone_l2_normalize_bit_exact(n, d):
+    """cleora_l2_normalize / cleora_rowops_dev(L2NORM): the 16-lanes-per-row exact-order kernel (d = 64, 128, 256,
+    512) and the general path (192, 320) against the oracle's sequential sum, bit for bit; zero rows stay zero;
+    also in place."""
+    rng = np.random.default_rng(n * 1000 + d)
+    x = (rng.standard_normal((n, d)) * rng.uniform(1e-3, 1e3, (n, 1))).astype(np.float32)
+    if n > 2:
+        x[2] = 0.0
+    want = oracle.l2_normalize(x)
+    y = np.full_like(x, np.nan)
+    _hip.check(L.cleora_l2_normalize(_hip.ptr(x), n, d, _hip.ptr(y)))
+    np.testing.assert_array_equal(y, want)
+    dx = _hip.DevArray.from_host(x)
+    _hip.check(L.cleora_rowops_dev(dx.ptr, d, n, d, dx.ptr, d, _hip.F_L2NORM, 0.0, None, None, None, None))
+    _hip.check(L.cleora_stream_sync(None))
+    np.testing.assert_array_equal(dx.to_host(), want)

@@ -329,6 +329,7 @@ int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes) {
     CL_REQUIRE(g != nullptr, "graph handle is NULL");
     std::lock_guard<std::mutex> lock(g->mu);
     g->hot_bytes = hot_bytes;
+    g->hot_failed = false;
     g->hot_rows_target = 0;   // rebuild (or drop) the marks on the next launch
     if (hot_bytes == 0 && g->col_hot) {
         (void)hipFree(g->col_hot);

@@ -75,6 +75,7 @@ struct cleora_graph {
     mutable uint32_t *col_hot = nullptr;
     mutable uint64_t hot_rows_target = 0;
     mutable uint64_t hot_rows_marked = 0;
+    mutable bool hot_failed = false;        // building the marks failed once (e.g. out of memory): policy stays off
     mutable uint32_t auto_launches = 0;     // automatic mode arms itself on the third eligible launch
 
     // optional per-kernel timing (cleora_graph_set_timing): 4 events per propagate call,

@@ -54,17 +54,23 @@ __global__ __launch_bounds__(256) void mark_kernel(const uint32_t *__restrict__ 
 
 }  // namespace
 
+namespace {
+const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want);
+}
+
 // Returns the marked column array for rows of `d` floats (building or rebuilding it if needed), or
 // nullptr when the policy does not apply.  Called with g->mu held.
+
 const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx) {
-    if (g->hot_bytes == 0 || g->nnz == 0 || g->n_cols >= (1ull << 31)) return nullptr;
+    if (g->hot_bytes == 0 || g->hot_failed || g->nnz == 0 || g->n_cols >= (1ull << 31)) return nullptr;
     const uint64_t row_bytes = (uint64_t)d * sizeof(float);
     const uint64_t x_bytes = g->n_cols * ldx * sizeof(float);
     uint64_t budget;
     if (g->hot_bytes < 0) {                           // auto: only when X is far larger than the caches ...
         if (x_bytes < (1ull << 30)) return nullptr;
-        // ... and a row fills a whole wavefront's load: on 128 / 64 / 32-column panels (the column
-        // partition at P = 2 / 4 / 8) the policy measured +0 / +2 / +7 % (scripts/column_probe.py).
+        // ... and a row fills a whole wavefront's load: on the 64 / 32-column slices of the column partition
+        // (P = 4 / 8) the policy measured +2 / +7 % (scripts/column_probe.py); sub-wave groups also need X to
+        // fit one 4 GiB buffer descriptor, which the 128-column slice of C3 does not.
         if (d < 256) return nullptr;
         // ... and the graph is evidently being iterated: the marks cost ~13 ms to build at C3 scale
         // (one pass of random atomics over col) and return ~3 ms per launch.
@@ -77,7 +83,18 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
     if (want > g->n_cols / 2) want = g->n_cols / 2;
     if (want == 0) return nullptr;
     if (g->col_hot && g->hot_rows_target == want) return g->col_hot;
+    const uint32_t *marked = build_hot_cols(g, want);
+    if (!marked) {
+        // the policy is an optimisation: a failure here (typically out of memory for the marked copy) must not
+        // fail the launch or be retried on every call — clear the sticky HIP error and switch the policy off
+        (void)hipGetLastError();
+        g->hot_failed = true;
+    }
+    return marked;
+}
 
+namespace {
+const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want) {
     if (hipSetDevice(g->device) != hipSuccess) return nullptr;
     uint32_t *indeg = nullptr, *bins = nullptr;
     if (hipMalloc(&indeg, g->n_cols * sizeof(uint32_t)) != hipSuccess) return nullptr;
@@ -111,5 +128,6 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
     g->hot_rows_marked = cum;
     return g->col_hot;
 }
+}  // namespace
 
 }  // namespace cleora

@@ -10,7 +10,7 @@
 Counter handling follows MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in
 separate passes (TCC slots), both are in KiB, and on gfx950 FETCH_SIZE reports half of the
 bytes of a 16-byte-per-lane coalesced read.  The factor is not assumed: the probe runs
-rowops_kernel (reads exactly n*d*4 B with the same dwordx4 row accesses as the SpMM gathers) and
+the stand-alone L2 pass (reads exactly n*d*4 B with the same dwordx4 accesses as the SpMM gathers) and
 init_kernel (writes exactly n*d*4 B), and the corrections are the ratios measured on those.
 """
 import collections
@@ -63,12 +63,15 @@ for kind in ("fetch", "write"):
         if "cleora" in r["Kernel_Name"]:
             counters[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 known = n * d * 4
-fetch_corr = known / (counters["rowops_kernel<64, 1, 4>"]["FETCH_SIZE"][0] * 1024)
-write_corr = known / (counters["init_kernel"]["WRITE_SIZE"][0] * 1024)
+# the stand-alone L2 pass (l2_exact16_kernel, formerly rowops_kernel) reads exactly n*d*4 B; init_kernel writes exactly that
+l2_key = [k for k in counters if k.startswith("l2_exact16_kernel") or k.startswith("rowops_kernel")][0]
+init_key = [k for k in counters if k.startswith("init_kernel")][0]
+fetch_corr = known / (counters[l2_key]["FETCH_SIZE"][0] * 1024)
+write_corr = known / (counters[init_key]["WRITE_SIZE"][0] * 1024)
 out = {"tag": tag, "n": n, "nnz": nnz, "d": d,
-       "calibration": {"known_bytes": known,
-                       "rowops_FETCH_SIZE_KiB": counters["rowops_kernel<64, 1, 4>"]["FETCH_SIZE"][0],
-                       "init_WRITE_SIZE_KiB": counters["init_kernel"]["WRITE_SIZE"][0],
+       "calibration": {"known_bytes": known, "read_kernel": l2_key, "write_kernel": init_key,
+                       "rowops_FETCH_SIZE_KiB": counters[l2_key]["FETCH_SIZE"][0],
+                       "init_WRITE_SIZE_KiB": counters[init_key]["WRITE_SIZE"][0],
                        "fetch_correction": fetch_corr, "write_correction": write_corr},
        "kernels": {}}
 for k, c in counters.items():

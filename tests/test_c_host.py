@@ -1,0 +1,76 @@
+"""The C ABI from plain C: both headers compile as strict C99 and C++11, and examples/embed_file.c (no Python,
+no torch, system HIP runtime) builds against the in-tree libraries.  Without a GPU the program must fail loudly
+(exit code 3, "no CPU fallback"); on a GPU its output equals the drop-in's embed_fast bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXAMPLE = os.path.join(ROOT, "examples", "embed_file")
+LINES = ["a b", "b c", "c a d", "d e", "e a", "f a b c"]
+
+
+def build_example():
+    subprocess.check_call(["bash", os.path.join(ROOT, "examples", "build.sh")], stdout=subprocess.DEVNULL)
+
+
+def read_tsv(path):
+    ids, rows = [], []
+    for line in open(path):
+        eid, vals = line.rstrip("\n").split("\t")
+        ids.append(eid)
+        rows.append(np.array(vals.split(" "), dtype=np.float32))
+    return ids, np.stack(rows)
+
+
+def test_headers_are_plain_c(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "cleora_hip.h"\n#include "cleora_host.h"\n'
+                   "int main(void) { cleora_graph_info i; (void)i; return CLEORA_ABI_VERSION == 1 ? 0 : 1; }\n")
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src),
+                           "-o", str(tmp_path / "t.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-x", "c++", "-c",
+                           str(src), "-o", str(tmp_path / "t2.o")])
+
+
+def test_c_host_fails_loudly_without_a_gpu(tmp_path):
+    from cleora_amd import _hip
+    build_example()
+    edges = tmp_path / "edges.tsv"
+    edges.write_text("\n".join(LINES) + "\n")
+    r = subprocess.run([EXAMPLE, "complex::bad::n", "8", "3", str(tmp_path / "o.tsv"), str(edges)], capture_output=True, text=True)
+    assert r.returncode == 2 and "Unrecognized column field modifier" in r.stderr     # src/configuration.rs:51-56
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is present: the no-device behaviour cannot be observed")
+    r = subprocess.run([EXAMPLE, "complex::reflexive::n", "8", "3", str(tmp_path / "o.tsv"), str(edges)], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stderr and "6 entities" in r.stderr
+    assert not (tmp_path / "o.tsv").exists()
+
+
+@pytest.mark.gpu
+def test_c_host_matches_the_drop_in(tmp_path):
+    from cleora_amd import embed as dev_embed
+    from cleora_amd.pycleora import SparseMatrix
+    build_example()
+    edges = tmp_path / "edges.tsv"
+    rng = np.random.default_rng(8)
+    lines = LINES + [" ".join(f"n{int(v)}" for v in rng.integers(0, 60, rng.integers(2, 6))) for _ in range(300)]
+    edges.write_text("\n".join(lines) + "\n")
+    g = SparseMatrix.from_files([str(edges)], "complex::reflexive::n")
+    env = {k: v for k, v in os.environ.items() if k != "CLEORA_ROCSOLVER"}      # the C host finds rocSOLVER by itself
+    out = tmp_path / "o.tsv"
+    subprocess.check_call([EXAMPLE, "complex::reflexive::n", "32", "5", str(out), str(edges)], env=env)
+    ids, got = read_tsv(out)
+    assert ids == g.entity_ids
+    np.testing.assert_array_equal(got, g.embed_fast(32, 5))
+    subprocess.check_call([EXAMPLE, "--symmetric", "complex::reflexive::n", "16", "3", str(out), str(edges)], env=env)
+    np.testing.assert_array_equal(read_tsv(out)[1], g.embed_fast(16, 3, propagation="symmetric"))
+    # the default (whitened) path of pycleora.embed() as one C call; eigenvector signs are the solver's
+    subprocess.check_call([EXAMPLE, "--whiten", "complex::reflexive::n", "8", "4", str(out), str(edges)], env=env)
+    got, want = read_tsv(out)[1], dev_embed.embed(g, 8, 4)
+    got = got * np.sign((got * want).sum(axis=0))
+    assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()

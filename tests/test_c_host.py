@@ -53,7 +53,6 @@ def test_c_host_fails_loudly_without_a_gpu(tmp_path):
 
 @pytest.mark.gpu
 def test_c_host_matches_the_drop_in(tmp_path):
-    from cleora_amd import embed as dev_embed
     from cleora_amd.pycleora import SparseMatrix
     build_example()
     edges = tmp_path / "edges.tsv"
@@ -69,7 +68,23 @@ def test_c_host_matches_the_drop_in(tmp_path):
     np.testing.assert_array_equal(got, g.embed_fast(32, 5))
     subprocess.check_call([EXAMPLE, "--symmetric", "complex::reflexive::n", "16", "3", str(out), str(edges)], env=env)
     np.testing.assert_array_equal(read_tsv(out)[1], g.embed_fast(16, 3, propagation="symmetric"))
-    # the default (whitened) path of pycleora.embed() as one C call; eigenvector signs are the solver's
+
+
+@pytest.mark.gpu
+def test_c_host_whitened_loop(tmp_path):
+    """The default (whitened) path of pycleora.embed() as ONE C call from a process that never loads Python's
+    ROCm libraries: rocSOLVER comes from the system ROCm through the library's own dlopen.  Eigenvector signs are
+    the solver's, so columns are sign-aligned; 1e-4 relative."""
+    from cleora_amd import embed as dev_embed
+    from cleora_amd.pycleora import SparseMatrix
+    build_example()
+    edges = tmp_path / "edges.tsv"
+    rng = np.random.default_rng(9)
+    lines = LINES + [" ".join(f"n{int(v)}" for v in rng.integers(0, 60, rng.integers(2, 6))) for _ in range(300)]
+    edges.write_text("\n".join(lines) + "\n")
+    g = SparseMatrix.from_files([str(edges)], "complex::reflexive::n")
+    env = {k: v for k, v in os.environ.items() if k != "CLEORA_ROCSOLVER"}
+    out = tmp_path / "o.tsv"
     subprocess.check_call([EXAMPLE, "--whiten", "complex::reflexive::n", "8", "4", str(out), str(edges)], env=env)
     got, want = read_tsv(out)[1], dev_embed.embed(g, 8, 4)
     got = got * np.sign((got * want).sum(axis=0))

@@ -39,7 +39,7 @@ def _as_f32_matrix(x, name="x"):
 
 
 class SparseMatrix:
-    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_lock", "_bufs", "__weakref__")
+    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_lock", "_bufs", "_lookup", "__weakref__")
 
     # ---- construction -------------------------------------------------------------------------
     def __new__(cls, *args):
@@ -57,6 +57,7 @@ class SparseMatrix:
         self._dev_graph = None
         self._lock = threading.Lock()
         self._bufs = {}
+        self._lookup = {}       # id -> index tables, built on first use
 
     @classmethod
     def _wrap(cls, host):
@@ -209,6 +210,7 @@ class SparseMatrix:
         ids = [str(s) for s in ids]
         self._host.set_entity_ids(ids)
         self._ids = ids
+        self._lookup = {}
         self._arr["hashes"] = self._host.arrays()["hashes"]
 
     @property
@@ -223,14 +225,31 @@ class SparseMatrix:
     def num_edges(self):
         return int(self._arr["col"].shape[0])
 
+    def _ids_list(self):
+        if self._ids is None:
+            self._ids = self._host.entity_ids()
+        return self._ids
+
     def get_entity_index(self, entity_id):
+        """Position of the FIRST entity with this id (`iter().position`, src/lib.rs:216-224); the lookup table is
+        built once per id list instead of scanning n strings per call."""
+        first = self._lookup.get("first")
+        if first is None:
+            first = {}
+            for i, e in enumerate(self._ids_list()):
+                first.setdefault(e, i)
+            self._lookup["first"] = first
         try:
-            return self.entity_ids.index(entity_id)
-        except ValueError:
+            return first[entity_id]
+        except (KeyError, TypeError):
             raise ValueError(f"Entity '{entity_id}' not found")
 
     def get_entity_indices(self, entity_ids):
-        index = {e: i for i, e in enumerate(self.entity_ids)}
+        """HashMap collected from (id, index) pairs: with duplicate ids the LAST index wins (src/lib.rs:226-240)."""
+        index = self._lookup.get("last")
+        if index is None:
+            index = {e: i for i, e in enumerate(self._ids_list())}
+            self._lookup["last"] = index
         out = []
         for e in entity_ids:
             if e not in index:

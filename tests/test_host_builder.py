@@ -116,6 +116,16 @@ def test_drop_in_host_surface(tmp_path, golden_dir):
         g.get_entity_index("zz")
     nb = dict(g.get_neighbors("0"))
     assert nb["0"] == 0.5 and len(nb) == 17
+    with pytest.raises(ValueError, match="not found"):
+        g.get_entity_indices(["0", "zz"])
+    # duplicate ids after the setter: position() finds the first, the collected HashMap keeps the last
+    # (src/lib.rs:216-240); the cached lookup tables are rebuilt when the ids change
+    dup = SparseMatrix.from_iterator(iter(["a b", "b c"]), "complex::reflexive::n")
+    assert dup.get_entity_index("c") == 2
+    dup.entity_ids = ["x", "y", "x"]
+    assert dup.get_entity_index("x") == 0 and dup.get_entity_indices(["x", "y"]) == [2, 1]
+    with pytest.raises(ValueError, match="Entity 'c' not found"):
+        dup.get_entity_index("c")
     # reference quirk kept: for a reflexive column both descriptor names are equal and
     # HashMap::from keeps the LAST pair (col_b_id = 1), while every column_id is 0 (src/lib.rs:180-196)
     assert not g.get_entity_column_mask("member").any()

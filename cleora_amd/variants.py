@@ -12,6 +12,8 @@ order) — a relative difference of ~1e-6 per iteration, which the parity tests 
     embed_directed        (:362-410)    embed_with_attention  (:206-276)
     embed_edge_features   (:784-852)    predict_links         (:636-681)
 """
+from itertools import combinations
+
 import numpy as np
 
 from . import _hip
@@ -68,13 +70,17 @@ def embed_weighted(edges_with_weights, columns, feature_dim=DEFAULT_FEATURE_DIM,
     graph = SparseMatrix.from_iterator(iter(edge_strs), columns, hyperedge_trim_n, num_workers)
     x0 = graph.initialize_deterministically(feature_dim, seed)
     rows, cols, vals, n, _ = graph.to_sparse_csr(propagation)
-    weight_diag = np.ones(n, dtype=np.float64)
+    # every entity takes the largest weight of the lines it occurs in, never less than 1 (:335-343):
+    # one (entity, weight) pair per token occurrence, reduced with a scatter-max
     index_map = {eid: i for i, eid in enumerate(graph.entity_ids)}
-    for edge_str, w in edges_with_weights:                                # :338-343
-        for ent in edge_str.strip().split():
-            idx = index_map.get(ent)
-            if idx is not None:
-                weight_diag[idx] = max(weight_diag[idx], w)
+    occ_idx, occ_w = [], []
+    for line, w in edges_with_weights:
+        hits = [index_map[t] for t in line.split() if t in index_map]
+        occ_idx.extend(hits)
+        occ_w.extend([w] * len(hits))
+    weight_diag = np.ones(n, dtype=np.float64)
+    if occ_idx:
+        np.maximum.at(weight_diag, np.asarray(occ_idx, dtype=np.int64), np.asarray(occ_w, dtype=np.float64))
     rowptr = graph._arr["rowptr"].astype(np.int64)
     weighted = _row_normalised(rowptr, weight_diag[rows.astype(np.int64)] * vals.astype(np.float64))
     emb = embed_csr(rowptr.astype(np.uint64), cols, weighted.astype(np.float32), x0, num_iterations, normalization,
@@ -91,15 +97,12 @@ def embed_directed(edges, columns, feature_dim=DEFAULT_FEATURE_DIM, num_iteratio
     graph = SparseMatrix.from_iterator(iter(edges), columns, hyperedge_trim_n, num_workers)
     n = graph.num_entities
     index_map = {eid: i for i, eid in enumerate(graph.entity_ids)}
+    # (earlier token, later token) of every line as one integer key per ordered entity pair (:376-382);
+    # tokens that are not entities cannot match a stored edge and are dropped here
     keys = set()
-    for edge_str in edges:                                                # :376-382
-        parts = [index_map.get(p) for p in edge_str.strip().split()]
-        for i in range(len(parts)):
-            if parts[i] is None:
-                continue
-            for j in range(i + 1, len(parts)):
-                if parts[j] is not None:
-                    keys.add(parts[i] * n + parts[j])
+    for line in edges:
+        seq = [index_map[t] for t in line.split() if t in index_map]
+        keys.update(a * n + b for a, b in combinations(seq, 2))
     rows, cols, vals, _, _ = graph.to_sparse_csr("left")
     edge_keys = rows.astype(np.int64) * n + cols.astype(np.int64)
     keep = np.isin(edge_keys, np.fromiter(keys, dtype=np.int64, count=len(keys)))
@@ -145,18 +148,22 @@ def embed_edge_features(graph, edge_features, feature_dim=DEFAULT_FEATURE_DIM,
     edge_feat_dim = len(next(iter(edge_features.values())))
     n = graph.num_entities
     index_map = {eid: i for i, eid in enumerate(graph.entity_ids)}
+    # per-node mean of the feature vectors of the two-entity keys it takes part in (:812-828): the usable keys
+    # become an endpoint list and a feature matrix, scattered with np.add.at (a key "a a" counts twice for a)
+    ends, rows = [], []
+    for key, feat in edge_features.items():
+        tokens = key.split()
+        if len(tokens) == 2 and tokens[0] in index_map and tokens[1] in index_map:
+            ends.append((index_map[tokens[0]], index_map[tokens[1]]))
+            rows.append(np.asarray(feat, dtype=np.float64))
     node_feats = np.zeros((n, edge_feat_dim), dtype=np.float64)
     node_counts = np.zeros(n, dtype=np.float64)
-    for edge_key, feat in edge_features.items():                          # :815-825
-        parts = edge_key.strip().split()
-        if len(parts) == 2:
-            ia, ib = index_map.get(parts[0]), index_map.get(parts[1])
-            if ia is not None and ib is not None:
-                feat_arr = np.array(feat, dtype=np.float64)
-                node_feats[ia] += feat_arr
-                node_feats[ib] += feat_arr
-                node_counts[ia] += 1
-                node_counts[ib] += 1
+    if ends:
+        ends = np.asarray(ends, dtype=np.int64)
+        feats = np.stack(rows)
+        for side in (0, 1):
+            np.add.at(node_feats, ends[:, side], feats)
+            np.add.at(node_counts, ends[:, side], 1.0)
     node_feats /= np.maximum(node_counts, 1.0)[:, None]
     kind = _hip.LEFT if propagation == "left" else _hip.SYMMETRIC
     # H is rounded to f32 by _postprocess_iteration after every iteration in the reference too (:839); only its

@@ -10,15 +10,6 @@ namespace {
 // division by 2^23 are exact: the result is bit-identical to the CPU's.
 constexpr uint64_t kFxK = 0x517cc1b727220a95ULL;
 
-__device__ __forceinline__ float init_value(uint64_t h, uint32_t c, int64_t seed) {
-    const uint64_t s = h + (uint64_t)c + (uint64_t)seed;  // wrapping i64 add
-    const int64_t hv = (int64_t)(s * kFxK);
-    const int64_t r = hv % (int64_t)(8 * 1024 * 1024);
-    return (float)r / 8388608.0f;
-}
-
-// W4: four consecutive columns per lane, one 16-byte store (a wavefront writes a whole 1 KiB row at d = 256)
-template <bool W4>
 __global__ __launch_bounds__(256) void init_kernel(const uint64_t *__restrict__ hash, uint64_t n,
                                                    uint32_t d, int64_t seed, float *__restrict__ x,
                                                    uint64_t ldx) {
@@ -27,12 +18,11 @@ __global__ __launch_bounds__(256) void init_kernel(const uint64_t *__restrict__ 
     if (row >= n) return;
     const uint64_t h = hash[row];
     float *xr = x + row * ldx;
-    if constexpr (W4) {
-        for (uint32_t c = lane * 4; c < d; c += 256)
-            *reinterpret_cast<float4 *>(xr + c) = make_float4(init_value(h, c, seed), init_value(h, c + 1, seed),
-                                                              init_value(h, c + 2, seed), init_value(h, c + 3, seed));
-    } else {
-        for (uint32_t c = lane; c < d; c += 64) xr[c] = init_value(h, c, seed);
+    for (uint32_t c = lane; c < d; c += 64) {
+        const uint64_t s = h + (uint64_t)c + (uint64_t)seed;  // wrapping i64 add
+        const int64_t hv = (int64_t)(s * kFxK);
+        const int64_t r = hv % (int64_t)(8 * 1024 * 1024);
+        xr[c] = (float)r / 8388608.0f;
     }
 }
 
@@ -200,10 +190,8 @@ int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, floa
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(hash != nullptr && x != nullptr, "hash / x is NULL");
     if (n == 0) return CLEORA_OK;
-    if ((d % 4 == 0) && (ldx % 4 == 0) && aligned16(x))
-        hipLaunchKernelGGL(init_kernel<true>, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, hash, n, d, seed, x, ldx);
-    else
-        hipLaunchKernelGGL(init_kernel<false>, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, hash, n, d, seed, x, ldx);
+    hipLaunchKernelGGL(init_kernel, grid_1d_as_2d((n + 3) / 4), dim3(256), 0, stream, hash, n, d,
+                       seed, x, ldx);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

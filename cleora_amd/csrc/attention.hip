@@ -63,14 +63,17 @@ __global__ __launch_bounds__(256) void edge_attention_kernel(const uint64_t *__r
         mx = fmax(mx, (double)s);
     }
     __threadfence();                               // lane 0's scores are read by every lane below
+    // ... through device-scope loads: the per-CU vector L1 is not coherent, and a cache line of `out` also holds
+    // the entries of neighbouring rows, so another wavefront of this CU may have pulled a stale copy of it
+    auto score = [&](uint64_t e) { return (double)__hip_atomic_load(out + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     double se = 0.0;
-    for (uint64_t e = beg + lane; e < end; e += 64) se += exp((double)out[e] - mx);
+    for (uint64_t e = beg + lane; e < end; e += 64) se += exp(score(e) - mx);
     se = fmax(wave_sum(se), 1e-10);
     double sw = 0.0;
-    for (uint64_t e = beg + lane; e < end; e += 64) sw += exp((double)out[e] - mx) / se * (double)adj[e];
+    for (uint64_t e = beg + lane; e < end; e += 64) sw += exp(score(e) - mx) / se * (double)adj[e];
     sw = fmax(wave_sum(sw), 1e-10);
     for (uint64_t e = beg + lane; e < end; e += 64)
-        out[e] = (float)(exp((double)out[e] - mx) / se * (double)adj[e] / sw);
+        out[e] = (float)(exp(score(e) - mx) / se * (double)adj[e] / sw);
 }
 
 }  // namespace

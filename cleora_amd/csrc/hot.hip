@@ -96,6 +96,8 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
 namespace {
 const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want) {
     if (hipSetDevice(g->device) != hipSuccess) return nullptr;
+    // a rebuild overwrites col_hot in place: launches still reading the previous marks (any stream) finish first
+    if (g->col_hot && hipDeviceSynchronize() != hipSuccess) return nullptr;
     uint32_t *indeg = nullptr, *bins = nullptr;
     if (hipMalloc(&indeg, g->n_cols * sizeof(uint32_t)) != hipSuccess) return nullptr;
     if (hipMalloc(&bins, kDegBins * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(indeg); return nullptr; }

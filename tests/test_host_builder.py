@@ -217,3 +217,43 @@ def test_accelerate_rebinds_reference_entry_points():
             pkg.embed(g, 8, 2, whiten=False)
         else:
             raise RuntimeError("gpu present")
+
+
+def test_parallel_builder_is_thread_count_invariant_and_matches_the_oracle():
+    """Inputs of >= 20 000 lines take the 4-phase parallel pipeline (cleora_host.cpp).  Its result must be the
+    single-consumer result for ANY thread count (identical pickle bytes), and equal the Python restatement of the
+    reference builder (oracle/refgraph.py) — including lines longer than hyperedge_trim_n, skipped lines,
+    duplicate tokens inside a line, and unicode ids."""
+    from cleora_amd import _host
+    from oracle import refgraph
+    rng = np.random.default_rng(321)
+    n_lines = 24_000
+    arity = np.minimum(22, 2 + rng.poisson(4, n_lines))
+    arity[rng.integers(0, n_lines, 300)] = rng.integers(17, 23, 300)        # > hyperedge_trim_n = 16: trimmed
+    members = np.minimum(rng.zipf(1.3, int(arity.sum())) - 1, 4000)
+    lines, pos = [], 0
+    for k in arity:
+        lines.append(" ".join(f"e{m}" if m % 7 else f"é{m}" for m in members[pos:pos + k]))
+        pos += k
+    lines[100] = "a\tb"            # wrong column count for a one-column spec: skipped
+    lines[101] = ""                # empty
+    lines[102] = "  x7   x7  x8 "  # duplicate token, surrounding and repeated blanks
+    L = _host.lib()
+    blobs = []
+    try:
+        for t in (1, 2, 5, 8):
+            L.cleora_host_set_threads(t)
+            g = SparseMatrix.from_iterator(iter(lines), "complex::reflexive::e")
+            blobs.append(g.__getstate__())
+    finally:
+        L.cleora_host_set_threads(0)
+    assert all(b == blobs[0] for b in blobs[1:])
+    want = refgraph.build_graph(lines, "complex::reflexive::e", 16)
+    assert g.entity_ids == list(want.entity_ids)
+    a = g._arr
+    np.testing.assert_array_equal(a["rowptr"], want.rowptr)
+    np.testing.assert_array_equal(a["col"], want.col)
+    np.testing.assert_array_equal(a["val_left"], want.val_left)
+    np.testing.assert_array_equal(a["val_sym"], want.val_sym)
+    np.testing.assert_array_equal(a["row_sum"], want.row_sum)
+    np.testing.assert_array_equal(a["hashes"], want.entity_hashes)

@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a run takes 1-3 minutes; if a collective ever deadlocks, leave a traceback of every thread and exit
+    # instead of hanging the launcher
+    import faulthandler
+    faulthandler.dump_traceback_later(1500, exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -330,6 +334,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

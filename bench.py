@@ -7,20 +7,31 @@
 
 One "step" = one propagate iteration of BASELINE.json's metric workload: CSR x dense SpMM with
 the L2 normalisation fused into its epilogue (src/embedding.rs:106-136, one loop body of
-embed_full) on the synthetic power-law graph |V| = 10M, |E| = nnz ~ 200M, d = 256.  For N > 1
-(cleora_amd/sharded.py) the default is the COLUMN partition — each rank owns d/N columns of X
-and the whole CSR, and the only collective per iteration is an all-reduce of the n row
-sums-of-squares; `--partition row` selects north_star's literal layout (row blocks + in-place
-all-gather of the 10 GB iterate), which is xGMI-bound.  The graph, X and the CSR
-are resident in HBM before the timed region.  Total work is fixed as N grows ("strong" scaling,
-as BASELINE.json quotes the same graph at 1/2/4/8 GPUs).
+embed_full) on the synthetic power-law graph |V| = 10M, |E| = nnz ~ 200M, d = 256 (BASELINE
+config 3).  The graph, X and the CSR are resident in HBM before the timed region.  Total work is
+fixed as N grows ("strong" scaling: BASELINE.json quotes the same graph at 1/2/4/8 GPUs).
+
+N > 1 (cleora_amd/sharded.py; kernels AND collectives go through the C ABI — RCCL is bound directly in
+csrc/comm.hip; torch.distributed/gloo is only the launcher: it distributes the RCCL id and reduces the
+timings).  BOTH partitions are measured, W + K iterations each, and reported in `partitions`:
+  row     north_star's layout: row blocks of the CSR, full replicas of X, in-place all-gather of the
+          10 GB iterate per iteration over xGMI (block k's gather overlaps block k+1's SpMM);
+  column  each rank owns d/N columns of X and the whole CSR; the only collective per iteration is an
+          all-reduce of the n row sums-of-squares.
+`value` is the faster of the two and `config.partition` names it.
+
+N = 1 additionally reports `whitened` — the default pycleora.embed() loop (SpMM + L2, then
+whiten_embeddings: pycleora/__init__.py:109-117,130-164) with per-kernel milliseconds from HIP events and
+MFMA roofline fractions for the Gram and projection kernels —, `checks` (one GPU iteration against one
+oracle iteration on the same graph and X: every row compared) and `cpu_baseline` (the oracle's
+reference-order CPU port timed on this box's host cores) — a reported baseline, not the target.
 
 Prints ONE JSON line on rank 0.  `value` = nnz * d * steps / seconds (edge*dim/s, whole job);
 `roofline` is for the dominant kernel (spmm_rows_kernel) from HIP events recorded inside the
-timed region on the launch stream; `cpu_baseline` is the oracle's reference-order CPU port timed
-on this box's host cores (N = 1, rank 0 only) — a reported baseline, not the target.
+timed region on the launch stream.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,9 +43,14 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from cleora_amd import _hip, sharded, synth  # noqa: E402
+from cleora_amd import _hip, comm as comm_mod, sharded, synth  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming ceiling)
+METRIC = "propagate iterations/sec & edges·dim/sec, |V|=10M |E|=200M d=256, 1/2/4/8 GPU"  # BASELINE.json, verbatim
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming ceiling)
+F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = the f32 vector rate
+F64_MFMA_PEAK_TF = 78.6     # AMD's MI355X datasheet figure for FP64 matrix (the guide lists none); the measured
+                            # ceiling of v_mfma_f64_16x16x4_f64 on this chip is in DESIGN.md §3.5 (scripts/mfma_peak.hip)
+KERNEL_SOURCES = ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h")
 
 
 def algorithmic_bytes(nnz, n_rows_written, n_rowptr, d):
@@ -43,9 +59,20 @@ def algorithmic_bytes(nnz, n_rows_written, n_rowptr, d):
     return nnz * 8 + (n_rowptr + 1) * 8 + nnz * d * 4 + n_rows_written * d * 4
 
 
-def cpu_baseline(g, x_dev, n, d, budget_s=12.0):
-    """Reference-order CPU port (oracle AoS SpMM + separate L2 pass, all host cores) on whole
-    iterations of the same graph and X; bounded to about `budget_s` seconds."""
+def kernel_source_stamp():
+    """Identifies the build the committed PMC traffic figure was measured on."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0):
+    """Reference-order CPU port (oracle AoS SpMM + separate L2 pass, all host cores) on whole iterations of the
+    same graph and X, bounded to about `budget_s` seconds; its FIRST iteration doubles as the parity check:
+    y_dev is the GPU's iteration from the same x_dev — every non-hub row must be bit-equal (hub rows are summed
+    in segment order on the GPU: tolerance)."""
     import oracle
     rowptr = g["rowptr"].cpu().numpy().astype(np.uint64)
     edges = np.empty(g["nnz"], dtype=oracle.EDGE_DTYPE)
@@ -55,7 +82,21 @@ def cpu_baseline(g, x_dev, n, d, budget_s=12.0):
     x = x_dev[:n].cpu().numpy()
     y = np.empty_like(x)
     threads = oracle.max_threads()
-    oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)  # page-touch + pool spin-up
+    oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)  # page-touch + pool spin-up; also the check
+    deg = np.diff(rowptr.astype(np.int64))
+    hub = deg > hub_threshold
+    equal_rows, hub_max, chunk = 0, 0.0, 1 << 20
+    for r0 in range(0, n, chunk):
+        r1 = min(n, r0 + chunk)
+        got = y_dev[r0:r1].cpu().numpy()
+        same = (got.view(np.uint32) == y[r0:r1].view(np.uint32)).all(axis=1)
+        h = hub[r0:r1]
+        equal_rows += int(same[~h].sum())
+        if h.any():
+            hub_max = max(hub_max, float(np.abs(got[h] - y[r0:r1][h]).max()))
+    checks = {"oracle_rows_compared": int(n), "oracle_nonhub_rows": int((~hub).sum()),
+              "oracle_rows_bit_equal": equal_rows, "hub_rows": int(hub.sum()),
+              "hub_max_abs_diff_unit_rows": hub_max}
     count, t0 = 0, time.perf_counter()
     while True:
         oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)
@@ -82,6 +123,243 @@ def cpu_baseline(g, x_dev, n, d, budget_s=12.0):
                                       "sample": f"scipy.sparse CSR @ dense, rows [{r0}, {r0 + rows}) = {e1 - e0} edges, {el:.1f} s"}
     except Exception as ex:  # scipy is optional; the port above is the baseline
         out["scipy_single_thread"] = {"error": str(ex)}
+    return out, checks
+
+
+class Launcher:
+    """torch.distributed as the launcher only: barrier and max-over-ranks of host timings (gloo, CPU tensors)."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def max(self, v):
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+
+def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, backend, L):
+    """W + K iterations of one partition; returns (result dict, x, x_next, iterate, blocks, n_pad)."""
+    n, nnz, d = g["n"], g["nnz"], args.dim
+    steps_per_iter = args.overlap_steps or (1 if world == 1 else 4)
+    launch_bytes = []
+    stream = torch.cuda.current_stream().cuda_stream
+    if part == "row":
+        sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world, steps_per_iter,
+                                  backend, comm=comm, balance=args.balance)
+        blocks = sg.blocks
+        for k in range(steps_per_iter):
+            b0, b1 = sg.my_rows[k]
+            r0, r1 = min(b0, n), min(b1, n)
+            dk = deg[r0:r1]
+            # the launch gathers for ALL edges of the block (hub segments are its first work items)
+            # and writes every row except the hub rows (hub_finish_kernel writes those)
+            n_hub = int((dk > blocks[k].info().hub_threshold).sum())
+            launch_bytes.append(algorithmic_bytes(int(dk.sum()), (b1 - b0) - n_hub, b1 - b0, d))
+        x = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
+        x_next = torch.zeros_like(x)
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
+        dl = d
+        par = (f"row-block-cyclic x{world} ({sg.balance}-balanced), {steps_per_iter} block(s)/rank/iter"
+               + (", in-place RCCL all-gather of X (C ABI) overlapped with the next block" if world > 1 else ""))
+
+        def iterate(a, b):
+            sg.propagate(_hip.LEFT, a, b)
+    else:
+        cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend,
+                                        comm=comm, steps=steps_per_iter)
+        blocks, dl = cg.blocks, cg.dl
+        for blk, (r0, r1) in zip(cg.blocks, cg.row_blocks):
+            dk = deg[r0:r1]
+            n_hub = int((dk > blk.info().hub_threshold).sum())
+            launch_bytes.append(algorithmic_bytes(int(dk.sum()), (r1 - r0) - n_hub, r1 - r0, dl))
+        x = torch.empty((n, dl), dtype=torch.float32, device=dev)
+        x_next = torch.empty_like(x)
+        rowsq = torch.zeros(n, dtype=torch.float32, device=dev)
+        # columns [c0, c0 + dl) of the deterministic init: init_value depends on hash + col + seed only
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, dl, cg.c0, x.data_ptr(), dl, stream))
+        par = (f"column partition x{world}: every rank owns {dl} of {d} columns and the whole CSR; "
+               f"RCCL all-reduce (C ABI) of the n f32 row sums-of-squares per iteration in {steps_per_iter} row "
+               f"block(s) (block k's reduce overlaps block k+1's SpMM), no exchange of X")
+
+        def iterate(a, b):
+            cg.propagate(_hip.LEFT, a, b, rowsq)
+
+    def sync():
+        torch.cuda.synchronize()
+        launcher.barrier()
+        torch.cuda.synchronize()
+
+    extra = {}
+    # all-gather algorithm (row partition, N > 1): RCCL's ring all-gather against the direct send/recv mesh
+    if part == "row" and world > 1 and isinstance(comm, comm_mod.RcclComm) and not os.environ.get("CLEORA_ALLGATHER"):
+        tried = {}
+        for name, algo in (("rccl_allgather", _hip.ALLGATHER_RING), ("p2p_mesh", _hip.ALLGATHER_P2P)):
+            comm.set_allgather(algo)
+            iterate(x, x_next)
+            sync()
+            t0 = time.perf_counter()
+            iterate(x_next, x)
+            iterate(x, x_next)
+            sync()
+            tried[name] = launcher.max(time.perf_counter() - t0) / 2 * 1e3
+        best = min(tried, key=tried.get)                      # every rank sees the same (max-reduced) times
+        comm.set_allgather(_hip.ALLGATHER_P2P if best == "p2p_mesh" else _hip.ALLGATHER_RING)
+        extra["allgather_ms_per_iter_tried"] = {k: round(v, 3) for k, v in tried.items()}
+        extra["allgather"] = best
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
+
+    # ---- placement (outside the timed region; one GPU only) ----------------------------------------
+    # The same launch runs up to 12 % slower when the two ping-pong allocations fall into the same placement
+    # class (DESIGN.md §3.1).  X stays where it is; candidate partners are tried until one is clearly faster.
+    placement = None
+    ncand = max(1, args.placement_candidates)
+    if world == 1 and ncand > 1:
+        src = x.clone()
+
+        def step_time(a, b):
+            a.copy_(src)
+            iterate(a, b)                      # warm
+            a.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            iterate(a, b)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+
+        tried, spacers = [], []
+        for k in range(ncand):
+            cand = x_next if k == 0 else torch.zeros_like(x)
+            tried.append((step_time(x, cand) + step_time(cand, x), cand))
+            lo, hi = min(t for t, _ in tried), max(t for t, _ in tried)
+            if k >= 1 and lo < 0.95 * hi:
+                break
+            spacers.append(torch.empty(int((0.6 + 0.83 * (k + 1)) * 2 ** 30), dtype=torch.uint8, device=dev))
+        best_t, best = min(tried, key=lambda p: p[0])
+        x_next = best
+        x.copy_(src)
+        placement = {"partners_tried": len(tried), "pair_ms_tried": [round(t / 2, 3) for t, _ in tried],
+                     "untuned_pair_ms": round(tried[0][0] / 2, 3), "chosen_pair_ms": round(best_t / 2, 3)}
+        del tried, spacers, src, best
+        torch.cuda.empty_cache()
+
+    a, b = x, x_next
+    for _ in range(args.warmup):
+        iterate(a, b)
+        a, b = b, a
+    for blk in blocks:
+        blk.set_timing(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iterate(a, b)
+        a, b = b, a
+    sync()
+    elapsed = launcher.max(time.perf_counter() - t0)
+
+    rows_ms, calls, other_ms = 0.0, 0, 0.0
+    for blk in blocks:
+        ms, c = blk.get_timing()
+        blk.set_timing(False)
+        rows_ms += ms[1]
+        other_ms += ms[0] + ms[2]
+        calls += c
+    avg_ms = rows_ms / max(calls, 1)
+    avg_bytes = sum(launch_bytes) / len(launch_bytes)
+    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    finite = bool(torch.isfinite(a[:n]).all())
+    sumsq = a[:n].double().pow(2).sum(1)
+    if part == "column" and world > 1:
+        comm.allreduce(sumsq)
+        torch.cuda.synchronize()
+    norm_err = float((sumsq.sqrt() - 1).abs().max())
+    hot_rows = int(blocks[0].info().hot_rows)      # gather cache policy (cleora_graph_set_hot_cache), 0 = inactive
+    g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
+    kernel_name = f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true,{'true' if hot_rows else 'false'}>"
+    res = {
+        "value": nnz * d * args.steps / elapsed, "iterations_per_sec": args.steps / elapsed,
+        "ms_per_step": elapsed / args.steps * 1e3, "parallelism": par,
+        "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches": calls,
+                     "gather_cache_policy_hot_rows": hot_rows,
+                     "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
+                     "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                     # SURVEY.md §8(d) secondary model: every operand once (lower bound on traffic)
+                     "compulsory_bytes_per_iteration": nnz * 8 + (n + 1) * 8 + 2 * n * d * 4},
+        "checks": {"finite": finite, "max_abs_row_norm_minus_1": norm_err},
+        "placement_tuning": placement,
+    }
+    res.update(extra)
+    return res, a, b, iterate, blocks
+
+
+def run_whitened(args, g, x, dev, L, iters):
+    """The default pycleora.embed() loop on one GPU (pycleora/__init__.py:109-117): SpMM + fused L2 norm, then
+    whiten_embeddings (cleora_whiten_dev: statistics, f64-MFMA Gram, eigensolver, f32-MFMA projection)."""
+    n, nnz, d = g["n"], g["nnz"], args.dim
+    gr = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(), g["val_left"].data_ptr(),
+                                None, dev.index or 0, keepalive=(g["rowptr"], g["col"], g["val_left"]))
+    prev = x[:n].clone()
+    mid, nxt = torch.empty_like(prev), torch.empty_like(prev)
+    ws = torch.empty(L.cleora_whiten_workspace(n, d), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def iterate():
+        nonlocal prev, nxt
+        _hip.check(L.cleora_propagate_dev(gr.handle, _hip.LEFT, prev.data_ptr(), d, d, mid.data_ptr(), d,
+                                          _hip.F_L2NORM, 0.0, None, None, None, stream))
+        _hip.check(L.cleora_whiten_dev(mid.data_ptr(), d, n, d, d, nxt.data_ptr(), d, ws.data_ptr(), None, stream))
+        prev, nxt = nxt, prev
+
+    for _ in range(3):          # the gather cache policy arms on the third launch
+        iterate()
+    torch.cuda.synchronize()
+    gr.set_timing(True)
+    _hip.check(L.cleora_whiten_set_timing(1))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iterate()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms, c = gr.get_timing()
+    gr.set_timing(False)
+    import ctypes
+    wms, wc = (ctypes.c_double * 4)(), ctypes.c_uint64(0)
+    _hip.check(L.cleora_whiten_get_timing(ctypes.byref(wms), ctypes.byref(wc)))
+    _hip.check(L.cleora_whiten_set_timing(0))
+    k = max(wc.value, 1)
+    stats_ms, gram_ms, eigh_ms, proj_ms = (wms[i] / k for i in range(4))
+    # executed MFMA work of the Gram: block tiles on/above the diagonal, and of a diagonal block tile only its
+    # 36 upper 16x16 MFMA tiles of 64 (csrc/whiten.hip)
+    tiles = -(-d // 128)
+    mfma_tiles = tiles * 36 + (tiles * (tiles - 1) // 2) * 64
+    gram_flops = 2.0 * n * mfma_tiles * 256
+    proj_flops = 2.0 * n * d * d
+    cov = torch.cov(prev[: min(n, 2_000_000)].double().T)
+    out = {
+        "ms_per_iter": el / iters * 1e3, "iterations": iters, "iterations_per_sec": iters / el,
+        "kernels_ms": {"spmm_l2": ms[1] / max(c, 1) + (ms[0] + ms[2]) / max(c, 1), "column_statistics": stats_ms,
+                       "gram_f64_mfma": gram_ms, "eigensolver_transform": eigh_ms, "project_f32_mfma": proj_ms},
+        "gram_roofline": {"bound": "mfma", "dtype": "f64", "achieved": gram_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else 0.0,
+                          "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": gram_flops / (gram_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TF if gram_ms else 0.0,
+                          "executed_flops": gram_flops, "full_flops_2nd2": 2.0 * n * d * d},
+        "project_roofline": {"bound": "mfma", "dtype": "f32", "achieved": proj_flops / (proj_ms * 1e-3) / 1e12 if proj_ms else 0.0,
+                             "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": proj_flops / (proj_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF if proj_ms else 0.0},
+        "checks": {"finite": bool(torch.isfinite(prev).all()),
+                   "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())},
+    }
+    gr.close()
     return out
 
 
@@ -94,27 +372,29 @@ def main():
     ap.add_argument("--pairs", type=int, default=95_000_000)
     ap.add_argument("--dim", type=int, default=256)
     ap.add_argument("--overlap-steps", type=int, default=0,
-                    help="row blocks per rank per iteration (gather of block k overlaps SpMM of k+1); "
+                    help="row blocks per rank per iteration (exchange of block k overlaps SpMM of k+1); "
                          "0 = 1 on one GPU, 4 otherwise")
-    ap.add_argument("--partition", default="auto", choices=["auto", "row", "column"],
-                    help="multi-GPU partition: 'column' = each rank owns d/N columns of X (one all-reduce of "
-                         "n floats per iteration); 'row' = row blocks + in-place all-gather of X (north_star's "
-                         "literal layout, 10 GB per iteration over xGMI); auto = column for N > 1")
+    ap.add_argument("--partition", default="both", choices=["both", "row", "column"],
+                    help="multi-GPU partition(s) to measure: 'row' = row blocks + in-place all-gather of X (north_star's "
+                         "layout); 'column' = each rank owns d/N columns of X (one all-reduce of n floats per "
+                         "iteration); both (default) measures the two and reports the faster as `value`")
+    ap.add_argument("--balance", default="auto", choices=["auto", "rows", "nnz"],
+                    help="row partition: equal row counts, or balanced on the rowptr prefix sum")
     ap.add_argument("--placement-candidates", type=int, default=8,
                     help="before the timed region, try up to this many allocations as the partner buffer of X "
-                         "and keep the fastest ping-pong pair (1 = no tuning).  The same kernel runs 34.4-39.9 ms "
-                         "depending on WHICH two allocations hold X and Y (DESIGN.md §3.1, placement sensitivity).")
+                         "and keep the fastest ping-pong pair (1 = no tuning); DESIGN.md §3.1")
+    ap.add_argument("--whiten-iters", type=int, default=8, help="iterations of the whitened default loop (N = 1); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    # developer switches for exercising the N > 1 code path on a ONE-GPU box (every rank on cuda:0, gloo
-    # instead of RCCL, which refuses two ranks on one device); numbers from such a run mean nothing
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--watchdog", type=int, default=1500, help="seconds before every thread's traceback is dumped and the run exits")
+    # developer switches for exercising the N > 1 code path on a ONE-GPU box (every rank on cuda:0, collectives
+    # through torch.distributed/gloo instead of RCCL, which refuses two ranks on one device); numbers mean nothing
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "gloo"], help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # a run takes 1-3 minutes; if a collective ever deadlocks, leave a traceback of every thread and exit
-    # instead of hanging the launcher
     import faulthandler
-    faulthandler.dump_traceback_later(1500, exit=True)
+    faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,210 +407,95 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    L = _hip.lib()
+    launcher = Launcher(world)
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
-    partition = args.partition
-    if partition == "auto":
-        partition = "column" if world > 1 else "row"
-    if partition == "column" and args.dim % (4 * world) != 0:
-        partition = "row"
+        dist.init_process_group("gloo")       # the launcher; the data path's collectives are the C ABI's (RCCL)
+        comm = (comm_mod.RcclComm.from_torch_distributed(local_rank) if args.backend == "rccl"
+                else comm_mod.TorchComm())
+    else:
+        comm = comm_mod.LocalComm()
 
     d = args.dim
-    steps_per_iter = args.overlap_steps or (1 if world == 1 else 4)
     g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)  # same seed on every rank
     n, nnz = g["n"], g["nnz"]
     deg = torch.diff(g["rowptr"])
     hashes = synth.entity_hashes(n, 0, dev)
-    L = _hip.lib()
     backend = sharded.HipBackend(dev)
-    launch_bytes = []
-    if partition == "row":
-        sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world,
-                                  steps_per_iter, backend)
-        blocks = sg.blocks
-        # algorithmic bytes of this rank's dominant-kernel launches (rows the rows-kernel owns)
-        for k in range(steps_per_iter):
-            r0 = min((k * world + rank) * sg.block, n)
-            r1 = min(r0 + sg.block, n)
-            dk = deg[r0:r1]
-            # the launch gathers for ALL edges of the block (hub segments are its first work items)
-            # and writes every row except the hub rows (hub_finish_kernel writes those)
-            n_hub = int((dk > sg.blocks[k].info().hub_threshold).sum())
-            launch_bytes.append(algorithmic_bytes(int(dk.sum()), sg.block - n_hub, sg.block, d))
-        x = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
-        x_next = torch.zeros_like(x)
-        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d,
-                                     torch.cuda.current_stream().cuda_stream))
-        kernel_name = "spmm_rows_kernel<64,1,4,true>"
-        par = (f"row-block-cyclic x{world}, {steps_per_iter} block(s)/rank/iter"
-               + (", in-place RCCL all-gather overlapped with the next block" if world > 1 else ""))
-
-        def iterate():
-            nonlocal x, x_next
-            sg.propagate(_hip.LEFT, x, x_next)
-            x, x_next = x_next, x
+    if world == 1:
+        parts = ["row"]
     else:
-        cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend,
-                                        steps=steps_per_iter)
-        blocks = cg.blocks
-        dl = cg.dl
-        for blk, (r0, r1) in zip(cg.blocks, cg.row_blocks):
-            dk = deg[r0:r1]
-            n_hub = int((dk > blk.info().hub_threshold).sum())
-            launch_bytes.append(algorithmic_bytes(int(dk.sum()), (r1 - r0) - n_hub, r1 - r0, dl))
-        x = torch.empty((n, dl), dtype=torch.float32, device=dev)
-        x_next = torch.empty_like(x)
-        rowsq = torch.zeros(n, dtype=torch.float32, device=dev)
-        # columns [c0, c0 + dl) of the deterministic init: init_value depends on hash + col + seed only
-        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, dl, cg.c0, x.data_ptr(), dl,
-                                     torch.cuda.current_stream().cuda_stream))
-        g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
-        kernel_name = f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true>"
-        par = (f"column partition x{world}: every rank owns {dl} of {d} columns and the whole CSR; "
-               f"RCCL all-reduce of the n f32 row sums-of-squares per iteration in {steps_per_iter} row block(s) "
-               f"(block k's reduce overlaps block k+1's SpMM), no exchange of X")
+        parts = ["column", "row"] if args.partition == "both" else [args.partition]
+        if d % (4 * world) != 0 and "column" in parts:
+            parts.remove("column")
+            parts = parts or ["row"]
 
-        def iterate():
-            nonlocal x, x_next
-            cg.propagate(_hip.LEFT, x, x_next, rowsq)
-            x, x_next = x_next, x
-    keep_full = g if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
-    del deg, hashes
-    if partition == "row":
-        del g
-    torch.cuda.empty_cache()
+    results, keep = {}, None
+    for part in parts:
+        res, a, b, iterate, blocks = run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher,
+                                                   backend, L)
+        results[part] = res
+        if world == 1:
+            keep = (a, b, iterate, blocks)
+        else:
+            del a, b, iterate, blocks
+            torch.cuda.empty_cache()
+    best = max(results, key=lambda p: results[p]["value"])
+    r = results[best]
 
-    # ---- placement tuning (outside the timed region) ---------------------------------------------
-    # The same launch runs 34.4-39.9 ms depending on WHICH two allocations hold X and Y: a pair is
-    # slow when both buffers fall into the same (unknown, physical) placement class — unaffected by
-    # offsets inside the allocations (scripts/alloc_probe*.py).  So X stays where it is
-    # and candidate partners are allocated one by one (with spacer allocations in between to move the
-    # allocator along) until one is clearly faster than the slowest seen, or the budget is used.
-    placement = None
-    ncand = max(1, args.placement_candidates)
-    if ncand > 1:
-        base, src = x, x.clone()
-
-        def step_time(a, b):
-            nonlocal x, x_next
-            a.copy_(src)
-            x, x_next = a, b
-            iterate()                       # warm (iterate swaps x / x_next)
-            x, x_next = a, b
-            a.copy_(src)
+    whitened = cpu = None
+    if world == 1:
+        a, b, iterate, blocks = keep
+        if not args.no_cpu_baseline:
+            iterate(a, b)                                     # the GPU iteration the oracle is compared with
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            iterate()
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1)
-
-        tried, spacers = [], []
-        # with several ranks every iterate() contains a collective, so all ranks must run the SAME
-        # number of trial steps: a fixed count and no data-dependent early exit
-        if world > 1:
-            ncand = min(ncand, 4)
-        for k in range(ncand):
-            cand = x_next if k == 0 else torch.zeros_like(base)
-            tried.append((step_time(base, cand) + step_time(cand, base), cand))
-            lo, hi = min(t for t, _ in tried), max(t for t, _ in tried)
-            if world == 1 and k >= 1 and lo < 0.95 * hi:
-                break
-            spacers.append(torch.empty(int((0.6 + 0.83 * (k + 1)) * 2 ** 30), dtype=torch.uint8, device=dev))
-        best_t, best = min(tried, key=lambda p: p[0])
-        x, x_next = base, best
-        x.copy_(src)
-        placement = {"partners_tried": len(tried), "pair_ms_tried": [round(t / 2, 3) for t, _ in tried],
-                     "chosen_pair_ms": round(best_t / 2, 3)}
-        del tried, spacers, src, best, base
+            cpu, checks = cpu_baseline_and_checks(g, a, b, n, d, blocks[0].info().hub_threshold)
+            r["checks"].update(checks)
+        x_w = a
+        del b, iterate, blocks, keep
         torch.cuda.empty_cache()
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        iterate()
-    for blk in blocks:
-        blk.set_timing(True)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iterate()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-
-    # dominant kernel: average launch duration from the HIP events recorded in the timed region
-    rows_ms, calls, other_ms = 0.0, 0, 0.0
-    for blk in blocks:
-        ms, c = blk.get_timing()
-        blk.set_timing(False)
-        rows_ms += ms[1]
-        other_ms += ms[0] + ms[2]
-        calls += c
-    avg_ms = rows_ms / max(calls, 1)
-    avg_bytes = sum(launch_bytes) / len(launch_bytes)
-    achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    finite = bool(torch.isfinite(x[:n]).all())
-    sumsq = x[:n].double().pow(2).sum(1)
-    if partition == "column" and world > 1:
-        dist.all_reduce(sumsq)
-    norm_err = float((sumsq.sqrt() - 1).abs().max())
+        if args.whiten_iters > 0:
+            whitened = run_whitened(args, g, x_w, dev, L, args.whiten_iters)
 
     if rank == 0:
-        traffic = None
+        # PMC traffic of the dominant kernel: a committed measurement, valid only for the kernel build it was taken on
+        traffic, tnote = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if world == 1 and os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                if rec.get("n") == n and rec.get("nnz") == nnz and rec.get("d") == d and world == 1:
+                if (rec.get("n"), rec.get("nnz"), rec.get("d")) != (n, nnz, d):
+                    tnote = "profiles/hbm_traffic.json is for another workload"
+                elif rec.get("kernel_source_sha16") != kernel_source_stamp():
+                    tnote = "profiles/hbm_traffic.json was measured on another build of the kernel (stale): re-profile"
+                else:
                     traffic = rec.get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        hot_rows = int(blocks[0].info().hot_rows)      # gather cache policy (cleora_graph_set_hot_cache), 0 = inactive
-        kernel_name = kernel_name[:-1] + (",true>" if hot_rows else ",false>")
+                    tnote = f"rocprofv3 PMC, profiles/{rec.get('source', 'r02_pmc.json')}"
+            except Exception as ex:
+                tnote = f"unreadable profiles/hbm_traffic.json: {ex}"
+        r["roofline"]["traffic"] = traffic
+        r["roofline"]["traffic_note"] = tnote
         out = {
-            "metric": "propagate edges*dim/sec (SpMM + fused L2 norm"
-                      + ("" if world == 1 else (" + all-gather of X" if partition == "row" else " + all-reduce of row norms"))
-                      + "), |V|=10M |E|=200M d=256",
-            "value": nnz * d * args.steps / elapsed,
-            "unit": "edge*dim/s",
-            "iterations_per_sec": args.steps / elapsed,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": METRIC, "value": r["value"], "unit": "edge*dim/s",
+            "iterations_per_sec": r["iterations_per_sec"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic power-law graph, reflexive column semantics "
-                                   f"(BASELINE config 3): n={n}, nnz={nnz}, d={d}, left Markov",
-                       "n": n, "nnz": nnz, "d": d,
-                       "parallelism": par, "partition": partition, "seed": 2},
-            "roofline": {"bound": "hbm", "kernel": kernel_name,
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms,
-                         "launches": calls, "gather_cache_policy_hot_rows": hot_rows,
-                         "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
-                         "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
-                         # SURVEY.md §8(d) secondary model: every operand once (lower bound on traffic)
-                         "compulsory_bytes_per_iteration": nnz * 8 + (n + 1) * 8 + 2 * n * d * 4},
-            "checks": {"finite": finite, "max_abs_row_norm_minus_1": norm_err},
-            "placement_tuning": placement,
+                                   f"(BASELINE config 3): n={n}, nnz={nnz}, d={d}, left Markov; one step = SpMM + fused L2 norm"
+                                   + ("" if world == 1 else " + the partition's exchange step"),
+                       "n": n, "nnz": nnz, "d": d, "parallelism": r["parallelism"], "partition": best, "seed": 2,
+                       "collectives": None if world == 1 else ("RCCL via the C ABI (csrc/comm.hip)" if args.backend == "rccl"
+                                                                else "torch.distributed/gloo (developer mode)")},
+            "roofline": r["roofline"], "checks": r["checks"], "placement_tuning": r["placement_tuning"],
+            "cpu_baseline": cpu,
         }
-        if keep_full is not None:
-            out["cpu_baseline"] = cpu_baseline(keep_full, x, n, d)
-        else:
-            out["cpu_baseline"] = None
+        if world > 1:
+            out["partitions"] = {p: {k: v for k, v in results[p].items() if k not in ("placement_tuning",)} for p in results}
+        if whitened is not None:
+            out["whitened"] = whitened
         print(json.dumps(out), flush=True)
+    comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -34,7 +34,8 @@ def accelerate(package=None):
         pycleora.whiten_embeddings  -> cleora_amd.embed.whiten_embeddings
         pycleora.embed_multiscale / embed_weighted / embed_directed / embed_with_attention /
         embed_edge_features / predict_links -> cleora_amd.variants.* (same signatures)
-    Normalisations the device path does not run ('l1', 'spectral') are forwarded to the original."""
+    The one normalisation the device path does not run — 'spectral', a full SVD per iteration
+    (pycleora/__init__.py:951-956) — is forwarded to the original."""
     import importlib
 
     from . import embed as _dev
@@ -43,7 +44,7 @@ def accelerate(package=None):
 
     def embed(graph, *args, **kwargs):
         norm = kwargs.get("normalization", args[3] if len(args) > 3 else "l2")
-        if norm not in ("l2", "none") or not isinstance(graph, _dev.SparseMatrix):
+        if norm not in ("l2", "l1", "none") or not isinstance(graph, _dev.SparseMatrix):
             return original_embed(graph, *args, **kwargs)
         return _dev.embed(graph, *args, **kwargs)
 
@@ -69,7 +70,7 @@ def accelerate(package=None):
             except TypeError:
                 return original(*args, **kwargs)
             graph = bound.get("graph")
-            if bound.get("normalization", "l2") not in ("l2", "none") or \
+            if bound.get("normalization", "l2") not in ("l2", "l1", "none") or \
                     (graph is not None and not isinstance(graph, _dev.SparseMatrix)):
                 return original(*args, **kwargs)
             return device_fn(*args, **kwargs)

@@ -12,9 +12,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcleora_hip.so")
 
-OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE = 0, -1, -2, -3, -4
+OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE, E_RCCL = 0, -1, -2, -3, -4, -5
 LEFT, SYMMETRIC = 0, 1
 F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
+F_L1NORM, F_BLEND_ANY, F_SQDIFF64 = 128, 256, 512
+ABI_VERSION = 2
+COMM_ID_BYTES = 128
+ALLGATHER_RING, ALLGATHER_P2P = 0, 1
 
 c_u64, c_u32, c_i64, c_int, c_f32 = (ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_float)
@@ -40,6 +44,20 @@ SIGNATURES = {
     "cleora_memcpy_d2d": (c_int, [vp, vp, c_u64, vp]),
     "cleora_memset": (c_int, [vp, c_int, c_u64, vp]),
     "cleora_stream_sync": (c_int, [vp]),
+    "cleora_stream_create": (c_int, [ctypes.POINTER(vp)]),
+    "cleora_stream_destroy": (c_int, [vp]),
+    "cleora_stream_wait_stream": (c_int, [vp, vp]),
+    "cleora_comm_unique_id": (c_int, [vp]),
+    "cleora_comm_create": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp)]),
+    "cleora_comm_destroy": (c_int, [vp]),
+    "cleora_comm_info": (c_int, [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "cleora_comm_set_allgather": (c_int, [vp, c_int]),
+    "cleora_allgatherv_f32_dev": (c_int, [vp, vp, vp, vp]),
+    "cleora_allgather_f32_dev": (c_int, [vp, vp, c_u64, vp]),
+    "cleora_allreduce_f32_dev": (c_int, [vp, vp, c_u64, vp]),
+    "cleora_allreduce_f64_dev": (c_int, [vp, vp, c_u64, vp]),
+    "cleora_broadcast_dev": (c_int, [vp, vp, c_u64, c_int, vp]),
+    "cleora_alltoall_f32_dev": (c_int, [vp, vp, vp, c_u64, vp]),
     "cleora_graph_create": (c_int, [c_int, c_u64, c_u64, c_u64, vp, vp, vp, vp, c_u32, c_u32,
                                     ctypes.POINTER(vp)]),
     "cleora_graph_create_dev": (c_int, [c_int, c_u64, c_u64, c_u64, vp, vp, vp, vp, c_u32, c_u32,
@@ -67,6 +85,8 @@ SIGNATURES = {
     "cleora_whiten_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_whiten_dev": (c_int, [vp, c_u64, c_u64, c_u32, c_u32, vp, c_u64, vp, vp, vp]),
     "cleora_whiten": (c_int, [vp, c_u64, c_u32, c_u32, vp]),
+    "cleora_whiten_set_timing": (c_int, [c_int]),
+    "cleora_whiten_get_timing": (c_int, [ctypes.POINTER(ctypes.c_double * 4), ctypes.POINTER(c_u64)]),
     "cleora_cosine_scores_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp]),
     "cleora_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),
     "cleora_l2_normalize": (c_int, [vp, c_u64, c_u32, vp]),
@@ -103,6 +123,10 @@ def _preload_hip_runtime():
     solver = os.path.join(libdir, "librocsolver.so")
     if os.path.exists(solver):
         os.environ.setdefault("CLEORA_ROCSOLVER", solver)
+    # likewise RCCL for the multi-GPU entry points (csrc/comm.hip)
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("CLEORA_RCCL", rccl)
 
 
 def lib():
@@ -119,8 +143,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.cleora_abi_version() != 1:
-            raise RuntimeError("libcleora_hip.so ABI version mismatch")
+        if L.cleora_abi_version() != ABI_VERSION:
+            raise RuntimeError("libcleora_hip.so ABI version mismatch: rebuild it (cleora_amd/csrc/build.sh)")
         _lib = L
     return _lib
 

@@ -29,8 +29,10 @@ inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 // RAII device buffer for the host-pointer entry points.
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() {
+    ~DevBuf() { release(); }
+    void release() {
         if (p) (void)hipFree(p);
+        p = nullptr;
     }
     int alloc(uint64_t bytes) {
         CL_HIP(hipMalloc(&p, bytes ? bytes : 1));
@@ -449,6 +451,13 @@ int cleora_whiten_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint
     return launch_whiten(x, ldx, n, d, n_components, y, ldy, workspace, eigenvalues_dev, S(stream));
 }
 
+int cleora_whiten_set_timing(int enable) { return whiten_set_timing(enable != 0); }
+
+int cleora_whiten_get_timing(double ms[4], uint64_t *calls) {
+    CL_REQUIRE(ms != nullptr && calls != nullptr, "ms / calls is NULL");
+    return whiten_get_timing(ms, calls);
+}
+
 // ---- host-pointer entry points ----------------------------------------------------------------
 
 int cleora_propagate(const cleora_graph *g, int markov_type, const float *x_host, uint32_t d,
@@ -545,13 +554,15 @@ int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int mark
         return rc;
     float *prev = a, *mid = b, *next = c;
     uint64_t actual = max_iterations;
-    const uint32_t base = CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | (flags & CLEORA_F_FASTNORM);
+    // the Python loop blends for any rw > 0 (pycleora/__init__.py:111-115) and normalises with `normalization`
+    const uint32_t base = ((flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM) | CLEORA_F_RESIDUAL |
+                          CLEORA_F_BLEND_ANY | (flags & CLEORA_F_FASTNORM);
     for (uint64_t it = 0; it < max_iterations; ++it) {
         if ((rc = launch_propagate(g, markov_type, prev, d, d, mid, d, base, rw, prev, nullptr, nullptr, nullptr)) != CLEORA_OK)
             return rc;
         if ((rc = launch_whiten(mid, d, n, d, d, next, d, ws.p, nullptr, nullptr)) != CLEORA_OK) return rc;
         if (check && it > 0) {                                            // :122-125
-            if ((rc = launch_rowops(next, d, n, d, next, d, CLEORA_F_SQDIFF, 0.f, prev, sq.as<double>(), nullptr, nullptr)) != CLEORA_OK ||
+            if ((rc = launch_rowops(next, d, n, d, next, d, CLEORA_F_SQDIFF | CLEORA_F_SQDIFF64, 0.f, prev, sq.as<double>(), nullptr, nullptr)) != CLEORA_OK ||
                 (rc = launch_reduce_sum(sq.as<double>(), n, rws.as<double>(), total.as<double>(), nullptr)) != CLEORA_OK)
                 return rc;
             double sum = 0.0;
@@ -587,8 +598,6 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
     CL_REQUIRE(out_host != nullptr, "out is NULL");
     CL_REQUIRE(entity_hash_host != nullptr || x0_host != nullptr, "need entity hashes or x0");
     CL_REQUIRE(d > 0, "d must be positive");
-    CL_REQUIRE(!(flags & CLEORA_F_WHITEN) || residual_weight < 1.0f,
-               "residual_weight >= 1 is not supported together with CLEORA_F_WHITEN");
     CL_HIP(hipSetDevice(g->device));
     const uint64_t n = g->n_rows;
     const uint64_t bytes = n * (uint64_t)d * sizeof(float);
@@ -627,13 +636,17 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
     const bool tune = bytes >= (256ull << 20) && max_iterations >= 8;
     struct Trial { void *buf; float ms; };
     std::vector<Trial> trials;
-    DevBuf extra[3];
-    int n_extra = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf extra[2];      // candidate partners: at most the best one so far plus the one on trial stay allocated
+    int n_tried = 1;      // `b` is the first candidate
+    struct Ev {
+        hipEvent_t e = nullptr;
+        ~Ev() { if (e) (void)hipEventDestroy(e); }
+    } e0, e1;
     if (tune) {
-        CL_HIP(hipEventCreate(&ev0));
-        CL_HIP(hipEventCreate(&ev1));
+        CL_HIP(hipEventCreate(&e0.e));
+        CL_HIP(hipEventCreate(&e1.e));
     }
+    const hipEvent_t ev0 = e0.e, ev1 = e1.e;
     bool tuning = tune;
     float pair_ms = 0.f;
     float *fixed = a.as<float>();      // holds the iterate after every odd number of trial iterations
@@ -677,21 +690,37 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
                 if (trials[k].ms > hi) hi = trials[k].ms;
             }
             const bool found = trials.size() >= 2 && lo < 0.95f * hi;
-            if (found || n_extra == 3 || it + 8 > max_iterations) {
+            bool more = !(found || n_tried == 4 || it + 8 > max_iterations);
+            if (more) {
+                // draw the next candidate while the rejected ones still hold their memory (a freed buffer would be
+                // handed straight back: same placement), then free every candidate but the best so far
+                DevBuf cand;
+                if (cand.alloc(bytes) == CLEORA_OK) {
+                    ++n_tried;
+                } else {
+                    // out of memory for another candidate (typical at C4 scale): keep the best so far.  The failed
+                    // hipMalloc leaves a sticky hipErrorOutOfMemory that the next launch's hipGetLastError() would
+                    // report as ITS failure: clear it.
+                    (void)hipGetLastError();
+                    more = false;
+                }
+                const Trial keep = trials[best];
+                for (DevBuf &e : extra)
+                    if (e.p && e.p != keep.buf) e.release();
+                trials.assign(1, keep);
+                if (more) {
+                    for (DevBuf &e : extra)
+                        if (!e.p) { std::swap(e.p, cand.p); partner = e.as<float>(); break; }
+                }
+            }
+            if (!more) {
                 tuning = false;
-                partner = static_cast<float *>(trials[best].buf);
-            } else if (extra[n_extra].alloc(bytes) == CLEORA_OK) {
-                partner = extra[n_extra++].as<float>();
-            } else {
-                tuning = false;  // out of memory for another candidate: keep the best so far
-                partner = static_cast<float *>(trials[best].buf);
+                partner = static_cast<float *>(trials[best < trials.size() ? best : 0].buf);
             }
             src = fixed;
             dst = partner;
         }
     }
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
     CL_HIP(hipMemcpy(out_host, src, bytes, hipMemcpyDeviceToHost));
     if (iterations_run) *iterations_run = actual;
     return CLEORA_OK;

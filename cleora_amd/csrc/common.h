@@ -94,7 +94,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
                      const float *val_override = nullptr);   // per-edge values replacing g->val[kind]
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
-                  float *row_sumsq, hipStream_t stream);
+                  float *row_sumsq, hipStream_t stream, uint64_t ldxs = 0);  // ldxs: leading dimension of x_self (0 = ldx)
 // hot.hip
 const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx);
 // rowops.hip
@@ -124,6 +124,8 @@ int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t
                             double *eigenvalues, void *workspace, hipStream_t stream);
 uint64_t whiten_workspace(uint64_t n, uint32_t d);
 const int *whiten_info(void *workspace, uint64_t n, uint32_t d);
+int whiten_set_timing(bool enable);
+int whiten_get_timing(double ms[4], uint64_t *calls);
 int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
                   void *workspace, double *eigenvalues, hipStream_t stream);
 

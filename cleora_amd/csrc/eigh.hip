@@ -200,6 +200,58 @@ inline uint64_t whiten_ws_layout(uint64_t n, uint32_t d, void *base, WhitenWs *o
 
 uint64_t whiten_workspace(uint64_t n, uint32_t d) { return whiten_ws_layout(n, d, nullptr, nullptr); }
 
+// ---- optional per-stage timing of launch_whiten (cleora_whiten_set_timing) ---------------------------------
+// 5 events per call on the launch stream: [statistics | Gram | transform (eigh) | projection].
+namespace {
+struct WhitenTiming {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> pool, used;
+};
+WhitenTiming &wt() {
+    static WhitenTiming t;
+    return t;
+}
+void wt_mark(hipStream_t stream) {
+    WhitenTiming &t = wt();
+    std::lock_guard<std::mutex> lock(t.mu);
+    if (!t.on) return;
+    hipEvent_t e = nullptr;
+    if (!t.pool.empty()) {
+        e = t.pool.back();
+        t.pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        return;
+    }
+    t.used.push_back(e);
+    (void)hipEventRecord(e, stream);
+}
+}  // namespace
+
+int whiten_set_timing(bool enable) {
+    WhitenTiming &t = wt();
+    std::lock_guard<std::mutex> lock(t.mu);
+    t.on = enable;
+    return CLEORA_OK;
+}
+
+int whiten_get_timing(double ms[4], uint64_t *calls) {
+    WhitenTiming &t = wt();
+    std::lock_guard<std::mutex> lock(t.mu);
+    for (int k = 0; k < 4; ++k) ms[k] = 0.0;
+    *calls = t.used.size() / 5;
+    if (!t.used.empty()) CL_HIP(hipEventSynchronize(t.used.back()));
+    for (size_t i = 0; i + 4 < t.used.size(); i += 5)
+        for (int k = 0; k < 4; ++k) {
+            float v = 0.f;
+            CL_HIP(hipEventElapsedTime(&v, t.used[i + k], t.used[i + k + 1]));
+            ms[k] += (double)v;
+        }
+    t.pool.insert(t.pool.end(), t.used.begin(), t.used.end());
+    t.used.clear();
+    return CLEORA_OK;
+}
+
 // dsyevd's convergence flag of the last launch_whiten on this workspace (0 = converged), on the device
 const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
     WhitenWs w;
@@ -224,11 +276,17 @@ int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t
     WhitenWs w;
     whiten_ws_layout(n, d, workspace, &w);
     int rc;
+    wt_mark(stream);
     if ((rc = launch_colsum(x, ldx, n, d, w.colsum_ws, w.colsum, stream)) != CLEORA_OK) return rc;
     if ((rc = launch_mean(w.colsum, n, d, w.mean64, w.mean32, stream)) != CLEORA_OK) return rc;
+    wt_mark(stream);
     if ((rc = launch_gram(x, ldx, n, d, w.mean64, w.gram_ws, w.gram, stream)) != CLEORA_OK) return rc;
+    wt_mark(stream);
     if ((rc = launch_whiten_transform(w.gram, n, d, k, w.transform, eigenvalues, w.eigh, stream)) != CLEORA_OK) return rc;
-    return launch_project(x, ldx, n, d, w.mean32, w.transform, k, y, ldy, stream);
+    wt_mark(stream);
+    rc = launch_project(x, ldx, n, d, w.mean32, w.transform, k, y, ldy, stream);
+    wt_mark(stream);
+    return rc;
 }
 
 }  // namespace cleora

@@ -227,7 +227,8 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
                 acc[v][q] = fadd(fmul(ra.alpha, acc[v][q]), fmul(ra.rw, xs[v][q]));
     }
 
-    if (ra.flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ | CLEORA_F_SCALE)) {
+    if (ra.flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ | CLEORA_F_SCALE | CLEORA_F_L1NORM)) {
+        const bool l1 = (ra.flags & CLEORA_F_L1NORM) != 0;   // sum |v| instead of sum v*v
         float s = 0.f;
         if (ra.flags & CLEORA_F_SCALE) {
             s = ra.row_sumsq[row];  // complete (all-reduced) sum of squares of the whole row
@@ -235,7 +236,7 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
 #pragma unroll
             for (int v = 0; v < V; ++v)
 #pragma unroll
-                for (int q = 0; q < W; ++q) s = fadd(s, fmul(acc[v][q], acc[v][q]));
+                for (int q = 0; q < W; ++q) s = fadd(s, l1 ? fabsf(acc[v][q]) : fmul(acc[v][q], acc[v][q]));
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) s = fadd(s, __shfl_xor(s, o, 64));
         } else {
@@ -245,7 +246,7 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
             for (int v = 0; v < V; ++v) {
                 float sq[W];
 #pragma unroll
-                for (int q = 0; q < W; ++q) sq[q] = fmul(acc[v][q], acc[v][q]);
+                for (int q = 0; q < W; ++q) sq[q] = l1 ? fabsf(acc[v][q]) : fmul(acc[v][q], acc[v][q]);
                 const uint32_t base = (uint32_t)v * G;
                 const uint32_t lim = nchunks > base ? ((nchunks - base) < (uint32_t)G ? (nchunks - base) : (uint32_t)G) : 0u;
                 for (uint32_t g = 0; g < lim; ++g) {
@@ -255,7 +256,14 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
             }
         }
         if ((ra.flags & CLEORA_F_ROWSQ) && gl == 0) ra.row_sumsq[row] = s;
-        if (ra.flags & (CLEORA_F_L2NORM | CLEORA_F_SCALE)) {
+        if (l1) {
+            // norms = max(sum |v|, 1e-10); emb / norms: a true division    (pycleora/__init__.py:947-950)
+            const float norm = fmaxf(s, 1e-10f);
+#pragma unroll
+            for (int v = 0; v < V; ++v)
+#pragma unroll
+                for (int q = 0; q < W; ++q) acc[v][q] = acc[v][q] / norm;
+        } else if (ra.flags & (CLEORA_F_L2NORM | CLEORA_F_SCALE)) {
             // norm = sum_sq.sqrt().max(1e-10); inv = 1/norm; v *= inv    (src/embedding.rs:98-102)
             const float norm = fmaxf(sqrtf(s), 1e-10f);
             const float inv = (1.0f / norm);
@@ -276,7 +284,9 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
             for (int q = 0; q < W; ++q) {
                 const uint32_t j = (uint32_t)(v * G + gl) * W + q;
                 if (FULL || j < d) {
-                    const double delta = (double)fsub(acc[v][q], xs[v][q]);
+                    // f32 difference like src/embedding.rs:172, or the f64 difference of _compute_rmse (pycleora/__init__.py:975)
+                    const double delta = (ra.flags & CLEORA_F_SQDIFF64) ? (double)acc[v][q] - (double)xs[v][q]
+                                                                        : (double)fsub(acc[v][q], xs[v][q]);
                     ds += delta * delta;
                 }
             }
@@ -466,14 +476,15 @@ __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64
     const float *xs = (ra.flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) ? ra.x_self + row * ra.ldxs : nullptr;
     float *yr = ra.y + row * ra.ldy;
     const uint32_t d = ra.d;
+    const bool l1 = (ra.flags & CLEORA_F_L1NORM) != 0;
     float s = 0.f;
     for (uint32_t j0 = 0; j0 < d; j0 += 64) {
         const uint32_t j = j0 + lane;
         float v = j < d ? xr[j] : 0.f;
         if ((ra.flags & CLEORA_F_RESIDUAL) && j < d) v = fadd(fmul(ra.alpha, v), fmul(ra.rw, xs[j]));
         if (j < d) yr[j] = v;
-        if ((ra.flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ)) && !(ra.flags & CLEORA_F_SCALE)) {
-            const float sq = fmul(v, v);
+        if ((ra.flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ | CLEORA_F_L1NORM)) && !(ra.flags & CLEORA_F_SCALE)) {
+            const float sq = l1 ? fabsf(v) : fmul(v, v);
             if (ra.flags & CLEORA_F_FASTNORM) {
                 float t = sq;
 #pragma unroll
@@ -485,19 +496,21 @@ __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64
             }
         }
     }
-    float inv = 1.0f;
+    float inv = 1.0f, div = 1.0f;
     if (ra.flags & CLEORA_F_SCALE) s = ra.row_sumsq[row];
     if ((ra.flags & CLEORA_F_ROWSQ) && lane == 0) ra.row_sumsq[row] = s;
     const bool scale = ra.flags & (CLEORA_F_L2NORM | CLEORA_F_SCALE);
     if (scale) inv = (1.0f / fmaxf(sqrtf(s), 1e-10f));
+    if (l1) div = fmaxf(s, 1e-10f);
     double ds = 0.0;
     for (uint32_t j0 = 0; j0 < d; j0 += 64) {
         const uint32_t j = j0 + lane;
         if (j < d) {
             float v = yr[j];
-            if (scale) v = fmul(v, inv);
+            if (l1) v = v / div;
+            else if (scale) v = fmul(v, inv);
             if (ra.flags & CLEORA_F_SQDIFF) {
-                const double delta = (double)fsub(v, xs[j]);
+                const double delta = (ra.flags & CLEORA_F_SQDIFF64) ? (double)v - (double)xs[j] : (double)fsub(v, xs[j]);
                 ds += delta * delta;
             }
             yr[j] = v;
@@ -516,6 +529,21 @@ constexpr uint32_t kMaxD4 = 64 * 8 * 4;  // widest register-resident row, float4
 constexpr uint32_t kMaxD1 = 64 * 16;     // scalar path
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// The residual blend runs for 0 < rw < 1 (src/embedding.rs:116), or for any rw > 0 when the caller asks for the
+// semantics of the Python loop (pycleora/__init__.py:111-115, CLEORA_F_BLEND_ANY).
+inline uint32_t gate_residual(uint32_t flags, float rw) {
+    if (!(flags & CLEORA_F_RESIDUAL)) return flags;
+    const bool on = rw > 0.0f && (rw < 1.0f || (flags & CLEORA_F_BLEND_ANY));
+    return on ? flags : (flags & ~CLEORA_F_RESIDUAL);
+}
+
+int check_norm_flags(uint32_t flags) {
+    CL_REQUIRE(!((flags & CLEORA_F_ROWSQ) && (flags & CLEORA_F_SCALE)), "ROWSQ and SCALE are exclusive");
+    CL_REQUIRE(!((flags & CLEORA_F_L1NORM) && (flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ | CLEORA_F_SCALE))),
+               "L1NORM is exclusive with L2NORM / ROWSQ / SCALE");
+    return CLEORA_OK;
+}
 
 // Calls f(G, V, W, FULL) with the compile-time shape for a row of d floats.
 template <class F>
@@ -628,14 +656,14 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
     CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
     CL_REQUIRE(x != y, "x and y must not alias");
-    if ((flags & CLEORA_F_RESIDUAL) && !(rw > 0.0f && rw < 1.0f)) flags &= ~CLEORA_F_RESIDUAL;  // embedding.rs:116
+    flags = gate_residual(flags, rw);
     if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) {
         if (!x_self && g->n_rows == g->n_cols) x_self = x;
         CL_REQUIRE(x_self != nullptr, "x_self is required for RESIDUAL / SQDIFF on a row shard");
     }
     if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
     if (flags & (CLEORA_F_ROWSQ | CLEORA_F_SCALE)) CL_REQUIRE(row_sumsq != nullptr, "row_sumsq is NULL");
-    CL_REQUIRE(!((flags & CLEORA_F_ROWSQ) && (flags & CLEORA_F_SCALE)), "ROWSQ and SCALE are exclusive");
+    if (int rc = check_norm_flags(flags)) return rc;
     if (g->n_rows == 0) return CLEORA_OK;
 
     std::lock_guard<std::mutex> lock(g->mu);
@@ -685,27 +713,28 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
         const int rc = propagate_panel(g, p, w4, stream);
         if (rc != CLEORA_OK) return rc;
     }
-    if (flags & (CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF | CLEORA_F_ROWSQ | CLEORA_F_SCALE))
-        return launch_rowops(y, ldy, g->n_rows, d, y, ldy, flags, rw, x_self, row_sqdiff, row_sumsq, stream);
+    if (flags & (CLEORA_F_L2NORM | CLEORA_F_L1NORM | CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF | CLEORA_F_ROWSQ | CLEORA_F_SCALE))
+        return launch_rowops(y, ldy, g->n_rows, d, y, ldy, flags, rw, x_self, row_sqdiff, row_sumsq, stream, ldx);
     return CLEORA_OK;
 }
 
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
-                  float *row_sumsq, hipStream_t stream) {
+                  float *row_sumsq, hipStream_t stream, uint64_t ldxs) {
     CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
-    if ((flags & CLEORA_F_RESIDUAL) && !(rw > 0.0f && rw < 1.0f)) flags &= ~CLEORA_F_RESIDUAL;
+    if (ldxs == 0) ldxs = ldx;   // x_self rows are strided like x unless the caller says otherwise
+    flags = gate_residual(flags, rw);
     if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) CL_REQUIRE(x_self != nullptr, "x_self is NULL");
     if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
     if (flags & (CLEORA_F_ROWSQ | CLEORA_F_SCALE)) CL_REQUIRE(row_sumsq != nullptr, "row_sumsq is NULL");
-    CL_REQUIRE(!((flags & CLEORA_F_ROWSQ) && (flags & CLEORA_F_SCALE)), "ROWSQ and SCALE are exclusive");
+    if (int rc = check_norm_flags(flags)) return rc;
     if (n == 0) return CLEORA_OK;
     RowArgs ra{};
     ra.y = y;
     ra.ldy = ldy;
     ra.x_self = x_self;
-    ra.ldxs = ldx;
+    ra.ldxs = ldxs;
     ra.row_sqdiff = row_sqdiff;
     ra.row_sumsq = row_sumsq;
     ra.rw = rw;
@@ -713,7 +742,7 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
     ra.flags = flags;
     ra.d = d;
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
-                    (!x_self || aligned16(x_self));
+                    (!x_self || (aligned16(x_self) && ldxs % 4 == 0));
     if (flags == CLEORA_F_L2NORM && w4 && d % 64 == 0) {   // plain exact-order normalise: 16 lanes per row
         const dim3 grid = grid_for(n, 16);
         bool done = true;

@@ -1,11 +1,10 @@
 """Device-resident version of the reference's `embed()` loop and `whiten_embeddings`
-(pycleora/__init__.py:51-164, 942-976): the iterate stays in HBM for all iterations; only the
-d-vector of column sums and the d x d Gram matrix cross PCIe per whitening (for the host
-LAPACK `eigh`, exactly the routine the reference itself calls, :145), plus the final result.
+(pycleora/__init__.py:51-164, 942-976): the iterate stays in HBM for all iterations; nothing but the
+final result (and the iterate handed to a callback) crosses PCIe.
 
 Per iteration (reference order, :109-125):
-    propagate (SpMM)  -> residual blend -> L2 normalise      one fused kernel   (cleora_propagate_dev)
-    whiten: column sums (f64) -> centred Gram (f64 MFMA) -> eigh (host) -> project (f32 MFMA)
+    propagate (SpMM)  -> residual blend -> L2 / L1 normalise   one fused kernel   (cleora_propagate_dev)
+    whiten: column statistics (f64) -> centred Gram (f64 MFMA) -> eigh (rocSOLVER) -> project (f32 MFMA)
     callback(i, X) if given (forces a device->host copy) ; RMSE early stop (f64 on device)
 
 The reference's own `pycleora.embed()` also runs unmodified over cleora_amd.pycleora.SparseMatrix
@@ -23,54 +22,24 @@ DEFAULT_FEATURE_DIM = 256       # pycleora/__init__.py:12
 DEFAULT_NUM_ITERATIONS = 40     # pycleora/__init__.py:13
 
 
-def eigh_descending(cov, backend="auto"):
-    """Eigen-decomposition of the covariance on host arrays, eigenvalues descending
-    (pycleora/__init__.py:145-149).  Used by the host-statistics routes (DeviceWhitener(eigh="host" |
-    "device"), the partitioned whitening in sharded.py); the default single-GPU route never leaves the
-    device (cleora_whiten_dev).  backend "host": numpy/LAPACK, the routine the reference itself calls.  "device":
-    torch.linalg.eigh on the GPU (rocSOLVER).  "auto": device when torch sees a GPU, else host.
-    Measured on the MI355X box: d = 256: host 5.1 ms / device 6.4 ms; d = 1024: host 322 ms /
-    device 23 ms.  The device route is the default because the host route is fragile inside a
-    GPU loop: when the kernels between two eigh calls are short (C2 scale) the BLAS threads collide
-    with still-spinning OpenMP workers of the previous CPU op and the same 256 x 256 eigh takes
-    80 ms instead of 5 ms.  Eigenvector signs may differ between the two; whitening is defined only
-    up to that."""
-    use_device = backend == "device"
-    if backend == "auto":
-        try:
-            import torch
-            use_device = torch.cuda.is_available()
-        except ImportError:
-            use_device = False
-    if use_device:
-        import torch
-        w, v = torch.linalg.eigh(torch.from_numpy(cov).cuda())
-        w, v = w.cpu().numpy(), v.cpu().numpy()
-    else:
-        w, v = np.linalg.eigh(cov)
-    idx = np.argsort(w)[::-1]
-    return w[idx], v[:, idx]
+def _n_components(d, n_components):
+    """Columns kept by `eigenvectors[:, :n_components]` (pycleora/__init__.py:151-153): None keeps all d,
+    a count beyond d keeps d, 0 keeps none, a negative count drops that many from the end."""
+    return d if n_components is None else len(range(d)[:int(n_components)])
 
 
 class DeviceWhitener:
-    """whiten_embeddings on device buffers.  Workspaces are sized once per (n, d).
+    """whiten_embeddings on device buffers: the whole chain — column statistics, centred Gram, rocSOLVER dsyevd,
+    transform, projection — is enqueued on one stream by cleora_whiten_dev with no host round trip.
+    Workspaces are sized once per (n, d)."""
 
-    eigh = "library" (what "auto" means): the whole chain — column sums, mean, centred Gram, rocSOLVER
-    dsyevd, transform, projection — is enqueued on one stream by cleora_whiten_dev with no host round
-    trip.  "host" / "device" keep the statistics on the host between the kernels and call
-    np.linalg.eigh / torch.linalg.eigh (see eigh_descending); they exist for A/B comparison with the
-    LAPACK routine the reference itself calls."""
-
-    def __init__(self, n, d, eigh="auto"):
+    def __init__(self, n, d):
         L = _hip.lib()
         self.n, self.d, self.L = n, d, L
-        self.eigh = "library" if eigh == "auto" else eigh
-        self.transform = None
         self._eigenvalues = None
-        self._split = None          # buffers of the host-statistics route, allocated on first use
-        if self.eigh == "library":
-            self.ws = _hip.DevArray((L.cleora_whiten_workspace(n, d),), np.uint8)
-            self.eig_dev = _hip.DevArray((d,), np.float64)
+        self._split = None          # buffers of stats(), allocated on first use
+        self.ws = _hip.DevArray((L.cleora_whiten_workspace(n, d),), np.uint8)
+        self.eig_dev = _hip.DevArray((d,), np.float64)
 
     def _split_buffers(self):
         if self._split is None:
@@ -86,13 +55,13 @@ class DeviceWhitener:
     @property
     def last_eigenvalues(self):
         """Eigenvalues of the last covariance, descending (downloaded on demand)."""
-        if self.eigh == "library" and self._eigenvalues is None:
+        if self._eigenvalues is None:
             _hip.check(self.L.cleora_stream_sync(None))
             self._eigenvalues = self.eig_dev.to_host()
         return self._eigenvalues
 
     def stats(self, x_ptr, ldx, stream=None):
-        """(mean f64[d], cov f64[d,d]) as pycleora/__init__.py:136-143."""
+        """(mean f64[d], cov f64[d,d]) as pycleora/__init__.py:136-143, computed by the device kernels."""
         L, n, d, b = self.L, self.n, self.d, self._split_buffers()
         _hip.check(L.cleora_colsum_dev(x_ptr, ldx, n, d, b["colsum_ws"].ptr, b["colsum"].ptr, stream))
         _hip.check(L.cleora_mean_dev(b["colsum"].ptr, n, d, b["mean64"].ptr, b["mean32"].ptr, stream))
@@ -104,27 +73,13 @@ class DeviceWhitener:
         return b["mean64"].to_host(), cov
 
     def whiten(self, x_ptr, ldx, out_ptr, ldo, n_components=None, stream=None):
-        """out = whiten_embeddings(x).  Returns k (columns written)."""
-        L, n, d = self.L, self.n, self.d
-        if self.eigh == "library":
-            k = d if n_components is None else min(int(n_components), d)
-            _hip.check(L.cleora_whiten_dev(x_ptr, ldx, n, d, k, out_ptr, ldo, self.ws.ptr, self.eig_dev.ptr,
-                                           stream))
-            self._eigenvalues = None
-            return k
-        mean, cov = self.stats(x_ptr, ldx, stream)
-        w, v = eigh_descending(cov, self.eigh)           # :145-149
-        if n_components is not None:                     # :151-153
-            w, v = w[:n_components], v[:, :n_components]
-        scale = 1.0 / np.sqrt(np.maximum(w, 1e-10))      # :155
-        transform = np.ascontiguousarray((v * scale).astype(np.float32))
-        k = transform.shape[1]
-        if self.transform is None or self.transform.shape != transform.shape:
-            self.transform = _hip.DevArray(transform.shape, np.float32)
-        _hip.check(L.cleora_memcpy_h2d(self.transform.ptr, _hip.ptr(transform), transform.nbytes, stream))
-        _hip.check(L.cleora_project_dev(x_ptr, ldx, n, d, self._split["mean32"].ptr, self.transform.ptr, k,
-                                        out_ptr, ldo, stream))
-        self._eigenvalues = w
+        """out = whiten_embeddings(x).  Returns k (columns written; 0 writes nothing)."""
+        k = _n_components(self.d, n_components)
+        if k == 0:
+            return 0
+        _hip.check(self.L.cleora_whiten_dev(x_ptr, ldx, self.n, self.d, k, out_ptr, ldo, self.ws.ptr,
+                                            self.eig_dev.ptr, stream))
+        self._eigenvalues = None
         return k
 
 
@@ -134,9 +89,10 @@ def whiten_embeddings(embeddings, n_components=None):
     n, d = x.shape
     if n <= 1:
         return x.copy()                                   # :132-133
-    k = d if n_components is None else min(int(n_components), d)
+    k = _n_components(d, n_components)
     out = np.empty((n, k), np.float32)
-    _hip.check(_hip.lib().cleora_whiten(_hip.ptr(x), n, d, k, _hip.ptr(out)))
+    if k:                                                 # the C ABI reads n_components = 0 as "all d"
+        _hip.check(_hip.lib().cleora_whiten(_hip.ptr(x), n, d, k, _hip.ptr(out)))
     return out
 
 
@@ -151,9 +107,11 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
             raise ValueError(f"num_iterations must be an int or 'auto', got '{num_iterations}'")
     if propagation not in ("left", "symmetric"):
         raise ValueError(f"Unknown propagation type: '{propagation}'. Use 'left' or 'symmetric'.")
-    if normalization not in ("l2", "none"):
-        raise ValueError(f"cleora_amd.embed runs normalization 'l2' or 'none' on the device; got "
-                         f"'{normalization}' (use the reference's pycleora.embed for 'l1'/'spectral')")
+    if normalization not in ("l2", "l1", "none"):
+        if normalization == "spectral":
+            raise ValueError("cleora_amd.embed runs normalization 'l2', 'l1' or 'none' on the device; 'spectral' "
+                             "(a full SVD per iteration, pycleora/__init__.py:951-956) stays with the reference's pycleora.embed")
+        raise ValueError(f"Unknown normalization method: {normalization}. Use 'l2', 'l1', 'spectral', or 'none'.")
     if not isinstance(graph, SparseMatrix):
         raise TypeError("graph must be a cleora_amd.pycleora.SparseMatrix")
     kind = _hip.LEFT if propagation == "left" else _hip.SYMMETRIC
@@ -196,8 +154,8 @@ def embed_csr(rowptr, col, val, initial_embeddings, num_iterations=DEFAULT_NUM_I
     n = int(np.asarray(rowptr).shape[0]) - 1
     if x0.ndim != 2 or x0.shape[0] != n:
         raise ValueError(f"initial_embeddings has shape {x0.shape} but the adjacency has {n} rows")
-    if normalization not in ("l2", "none"):
-        raise ValueError("normalization must be 'l2' or 'none' on the device path")
+    if normalization not in ("l2", "l1", "none"):
+        raise ValueError("normalization must be 'l2', 'l1' or 'none' on the device path")
     if n == 0 or x0.shape[1] == 0 or num_iterations <= 0:
         return x0
     g = _hip.Graph.from_host(rowptr, col, val, None, n_cols=n, device=device)
@@ -225,13 +183,11 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
     ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None
     tot = _hip.DevArray((1,), np.float64) if check else None
     attn = _hip.DevArray((max(int(g.info().nnz), 1),), np.float32) if attention_temperature is not None else None
-    flags = (_hip.F_L2NORM if normalization == "l2" else 0)
-    # the reference's slow path blends for any rw > 0 (:114); the kernel gates on 0 < rw < 1
-    # like the Rust loop (src/embedding.rs:116).  rw >= 1 is rejected rather than guessed.
-    if residual_weight >= 1.0:
-        raise ValueError("residual_weight must be < 1 on the device path")
+    flags = {"l2": _hip.F_L2NORM, "l1": _hip.F_L1NORM, "none": 0}[normalization]   # _normalize, :942-959
+    # this is the Python loop of embed(): it blends for ANY rw > 0 (:111-115), unlike the Rust loop's
+    # 0 < rw < 1 (src/embedding.rs:116) that the kernel applies without CLEORA_F_BLEND_ANY
     if residual_weight > 0:
-        flags |= _hip.F_RESIDUAL
+        flags |= _hip.F_RESIDUAL | _hip.F_BLEND_ANY
     taken = []
     for i in range(int(num_iterations)):
         if attn is not None and i > 0:                # pycleora/__init__.py:241-269
@@ -254,7 +210,7 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
             taken.append(result.to_host())
         stop = False
         if check and i > 0:                           # :122-125, f64 RMSE vs the previous iterate
-            _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF, 0.0,
+            _hip.check(L.cleora_rowops_dev(result.ptr, d, n, d, result.ptr, d, _hip.F_SQDIFF | _hip.F_SQDIFF64, 0.0,
                                            cur.ptr, sq.ptr, None, None))
             _hip.check(L.cleora_reduce_sum_f64_dev(sq.ptr, n, ws.ptr, tot.ptr, None))
             _hip.check(L.cleora_stream_sync(None))

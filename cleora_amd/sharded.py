@@ -6,24 +6,27 @@ multi-GPU design BASELINE.json:north_star asks for, not a port of anything:
   * output rows are independent, each needs arbitrary rows of the PREVIOUS iterate, so every
     rank keeps a full replica of X (n x d f32: 10 GB at |V| = 10M, d = 256 — small next to
     288 GB of HBM) and owns a set of row blocks of the CSR and of the next iterate;
-  * rows are dealt out BLOCK-CYCLICALLY: with P ranks and K steps per iteration the padded row
-    space is cut into P*K blocks of B rows and rank r owns blocks {k*P + r}.  Step k of an
+  * rows are dealt out BLOCK-CYCLICALLY: with P ranks and K steps per iteration the row space is
+    cut into P*K contiguous blocks (equal row counts, or balanced on the rowptr prefix sum when the
+    ids are ordered by degree: `row_bounds`) and rank r owns blocks {k*P + r}.  Step k of an
     iteration computes block (k, r) on every rank and then all-gathers exactly the contiguous
-    row range [k*P*B, (k+1)*P*B) of the next replica, IN PLACE (`all_gather_into_tensor` with
-    the input being the rank's own slot of the output) — no staging copies, natural row order;
-  * the collective of step k runs on the process group's stream while the SpMM of step k+1
+    row range of blocks [k*P, (k+1)*P) of the next replica, IN PLACE (the rank's own slot of the
+    output is the input: cleora_allgatherv_f32_dev) — no staging copies, natural row order;
+  * the collective of step k runs on the communicator's stream while the SpMM of step k+1
     runs on the compute stream, so only the last step's gather is exposed (the all-gather, not
     the SpMM, is the critical path at 8 GPUs: SURVEY.md §8e);
   * the L2 normalisation is row-local and fused into the SpMM epilogue, so what travels over
     xGMI is the finished next iterate.
 
-`backend` does the per-block arithmetic.  HipBackend is the product path (libcleora_hip.so);
-tests inject a CPU backend so the partition / collective logic runs under gloo without a GPU.
+`backend` does the per-block arithmetic and `comm` the exchange steps (cleora_amd/comm.py).  The product
+path is HipBackend + RcclComm: kernels AND collectives go through the C ABI of libcleora_hip.so (RCCL bound
+directly, csrc/comm.hip), so the same loop can be driven by a non-Python host.  Tests inject a CPU backend
+and a gloo TorchComm so the partition / collective logic runs without a GPU.
 """
 import torch
-import torch.distributed as dist
 
 from . import _hip
+from . import comm as comm_mod
 
 
 class HipBackend:
@@ -91,126 +94,142 @@ class HipBackend:
                                                out.stride(0), self._stream()))
 
 
-def transform_from_gram(backend, gram, n, kdim):
-    """cov = gram/(n-1) -> eigh -> descending -> V / sqrt(max(lambda, 1e-10)) as f32, d x kdim
-    (pycleora/__init__.py:143-156).  On the HIP backend this stays on the device
-    (cleora_whiten_transform_dev: rocSOLVER dsyevd); injected CPU backends use numpy's LAPACK."""
-    if hasattr(backend, "whiten_transform"):
-        return backend.whiten_transform(gram, n, kdim)
-    import numpy as np
-    w, v = np.linalg.eigh(gram.cpu().numpy() * (1.0 / (n - 1)))
-    idx = np.argsort(w)[::-1][:kdim]                                       # :147-153
-    scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))                       # :155
-    return torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32))).to(gram.device)
-
-
 def block_size(n, world, steps):
-    """Rows per block: the padded row count is block * world * steps (block a multiple of 4 so
-    every block of a 16-byte-aligned matrix stays 16-byte aligned for any d)."""
+    """Rows per block of the equal-rows split: the padded row count is block * world * steps (block a
+    multiple of 4 so every block of a 16-byte-aligned matrix stays 16-byte aligned for any d)."""
     b = -(-n // (world * steps))
     return max(4, -(-b // 4) * 4)
+
+
+def row_bounds(n, rowptr, world, steps, balance="auto"):
+    """Row boundaries of the world * steps contiguous blocks, block j = rows [bounds[j], bounds[j+1]).
+    Rank r owns blocks {k * world + r}; step k's exchange covers blocks [k * world, (k+1) * world).
+
+    "rows": equal row counts (a multiple of 4; the row space is padded to block * world * steps, the padding
+            rows are empty) — the shards of a step are equal, so the exchange is one ncclAllGather.
+    "nnz":  SURVEY.md §8e: split on the prefix sum of the work per row, weight(row) = edges + 1 (one gathered
+            X row per edge plus the one Y row written), so that power-law graphs with ORDERED ids do not leave
+            one rank with the hubs.  Boundaries are multiples of 4 rows; shards are unequal (all-gather-v).
+    "auto": "rows" when its heaviest block is within 3 % of the mean (true for randomly permuted ids), else "nnz".
+    Returns (bounds list, n_pad, mode)."""
+    nb = world * steps
+    rp = rowptr.to(torch.int64)
+    block = block_size(n, world, steps)
+    eq = [j * block for j in range(nb + 1)]
+    if balance not in ("auto", "rows", "nnz"):
+        raise ValueError("balance must be 'auto', 'rows' or 'nnz'")
+    if balance == "auto" and nb > 1:
+        cut = torch.tensor([min(b, n) for b in eq], dtype=torch.int64, device=rp.device)
+        w = (rp[cut[1:]] - rp[cut[:-1]]) + (cut[1:] - cut[:-1])
+        total = float(rp[n]) + n
+        balance = "rows" if float(w.max()) <= 1.03 * total / nb else "nnz"
+    if balance != "nnz" or nb == 1:
+        return eq, block * nb, "rows"
+    n4 = -(-n // 4) * 4
+    cum = rp[: n + 1] + torch.arange(n + 1, dtype=torch.int64, device=rp.device)     # work before row r
+    total = int(cum[n])
+    targets = torch.tensor([total * j // nb for j in range(1, nb)], dtype=torch.int64, device=rp.device)
+    cuts = torch.searchsorted(cum, targets).cpu().tolist() if nb > 1 else []
+    bounds, prev = [0], 0
+    for c in cuts:
+        c = min(n4, max(prev, (int(c) + 3) // 4 * 4))
+        bounds.append(c)
+        prev = c
+    bounds.append(n4)
+    return bounds, n4, "nnz"
 
 
 class ShardedGraph:
     """This rank's row blocks of a CSR graph plus the replica bookkeeping."""
 
     def __init__(self, n, rowptr, col, val_left, val_sym, rank, world, steps, backend,
-                 hub_threshold=0, hub_segment=0, group=None):
+                 hub_threshold=0, hub_segment=0, comm=None, balance="auto", group=None):
         self.n, self.rank, self.world, self.steps = n, rank, world, steps
-        self.backend, self.group = backend, group
-        self.block = block_size(n, world, steps)
-        self.n_pad = self.block * world * steps
-        self.blocks = []
+        self.backend = backend
+        self.comm = comm if comm is not None else comm_mod.default_comm(group)
+        self.bounds, self.n_pad, self.balance = row_bounds(n, rowptr, world, steps, balance)
+        self.block = self.bounds[1] - self.bounds[0]       # rows of the first block (every block, in "rows" mode)
+        self.blocks, self.my_rows, self.sq_offset = [], [], [0]
         self.local_nnz = 0
         rp = rowptr.to(torch.int64)
         for k in range(steps):
-            r0 = min((k * world + rank) * self.block, n)
-            r1 = min(r0 + self.block, n)
+            b0, b1 = self.bounds[k * world + rank], self.bounds[k * world + rank + 1]
+            r0, r1 = min(b0, n), min(b1, n)
             e0, e1 = int(rp[r0]), int(rp[r1])
-            brp = torch.full((self.block + 1,), e1 - e0, dtype=torch.int64, device=rp.device)
-            brp[: r1 - r0 + 1] = rp[r0:r1 + 1] - e0     # padded rows are empty
+            brp = torch.full((b1 - b0 + 1,), e1 - e0, dtype=torch.int64, device=rp.device)
+            brp[: r1 - r0 + 1] = rp[r0:r1 + 1] - e0     # padding rows are empty
             blk = backend.make_block(brp, col[e0:e1].clone(), val_left[e0:e1].clone(),
                                      val_sym[e0:e1].clone() if val_sym is not None else None,
                                      self.n_pad, hub_threshold, hub_segment)
             self.blocks.append(blk)
+            self.my_rows.append((b0, b1))
+            self.sq_offset.append(self.sq_offset[-1] + (b1 - b0))
             self.local_nnz += e1 - e0
 
-    def rows_of_step(self, k):
-        """(first row of this rank's block, first row of the step's gathered range)."""
-        g0 = k * self.world * self.block
-        return g0 + self.rank * self.block, g0
+    @property
+    def local_rows(self):
+        return self.sq_offset[-1]
 
-    def _gather_step(self, buf, k):
-        """Enqueue the in-place all-gather of step k's row range of `buf` (async)."""
-        mine, g0 = self.rows_of_step(k)
-        return dist.all_gather_into_tensor(buf[g0:g0 + self.world * self.block],
-                                           buf[mine:mine + self.block], group=self.group, async_op=True)
+    def step_bounds(self, k):
+        """Row boundaries of the world shards of step k's exchange."""
+        return self.bounds[k * self.world:(k + 1) * self.world + 1]
 
     def propagate(self, kind, x, x_next, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, gather=True):
         """One iteration: x_next <- rowops(A @ x), replicated on every rank (gather=True) or only
         this rank's row blocks of x_next written (gather=False: whitening follows).
-        x, x_next: (n_pad, d) f32 replicas.  Returns after the collectives are enqueued and
-        waited on the current stream (no host sync)."""
-        works = []
+        x, x_next: (n_pad, d) f32 replicas.  The exchange of block k runs beside the SpMM of block k+1;
+        returns with every collective enqueued and ordered before later work on the compute stream
+        (no host synchronisation)."""
         for k in range(self.steps):
-            mine, _ = self.rows_of_step(k)
-            y = x_next[mine:mine + self.block]
-            xs = x[mine:mine + self.block]
-            sq = row_sqdiff[k * self.block:(k + 1) * self.block] if row_sqdiff is not None else None
-            self.backend.propagate(self.blocks[k], kind, x, y, flags, rw, xs, sq)
+            b0, b1 = self.my_rows[k]
+            sq = row_sqdiff[self.sq_offset[k]:self.sq_offset[k + 1]] if row_sqdiff is not None else None
+            self.backend.propagate(self.blocks[k], kind, x, x_next[b0:b1], flags, rw, x[b0:b1], sq)
             if self.world > 1 and gather:
-                works.append(self._gather_step(x_next, k))
-        for w in works:
-            w.wait()
+                self.comm.allgather_rows(x_next, self.step_bounds(k))
+        self.comm.join()
 
     def _valid_rows(self, k):
-        mine, _ = self.rows_of_step(k)
-        return mine, max(0, min(self.block, self.n - mine))
+        b0, b1 = self.my_rows[k]
+        return b0, max(0, min(b1, self.n) - b0)
 
     def whiten(self, y, out, n_components=None):
         """whiten_embeddings (pycleora/__init__.py:130-164) over the row partition: `y` holds this
         rank's blocks of the matrix to whiten; `out` receives the whitened matrix, replicated.
         Local f64 column sums and centred Gram -> all-reduce (d and d*d doubles) -> transform
-        (cleora_whiten_transform_dev, replicated; rank 0's copy is broadcast) -> row-local projection -> in-place all-gather per block."""
-        import numpy as np
+        (cleora_whiten_transform_dev, replicated; rank 0's copy is broadcast) -> row-local projection ->
+        in-place all-gather per block."""
         d = y.shape[1]
         cs = torch.zeros(d, dtype=torch.float64, device=y.device)
         for k in range(self.steps):
             r0, nv = self._valid_rows(k)
             if nv:
                 cs += self.backend.colsum(y[r0:r0 + nv])
-        if self.world > 1:
-            dist.all_reduce(cs, group=self.group)
+        self.comm.allreduce(cs)
         mean = cs / float(self.n)
         gram = torch.zeros((d, d), dtype=torch.float64, device=y.device)
         for k in range(self.steps):
             r0, nv = self._valid_rows(k)
             if nv:
                 gram += self.backend.gram(y[r0:r0 + nv], mean)
-        if self.world > 1:
-            dist.all_reduce(gram, group=self.group)
+        self.comm.allreduce(gram)
         kdim = d if n_components is None else min(int(n_components), d)
         # every rank holds the same all-reduced Gram, so the (deterministic) eigensolver is replicated;
         # the transform is still broadcast from rank 0 so that the ranks cannot drift apart
-        transform = transform_from_gram(self.backend, gram, self.n, kdim)
-        if self.world > 1:
-            dist.broadcast(transform, src=0, group=self.group)
+        transform = self.backend.whiten_transform(gram, self.n, kdim)
+        self.comm.broadcast(transform, 0)
         mean32 = mean.to(torch.float32)
-        works = []
         for k in range(self.steps):
             r0, nv = self._valid_rows(k)
             if nv:
                 self.backend.project(y[r0:r0 + nv], mean32, transform, out[r0:r0 + nv])
             if self.world > 1:
-                works.append(self._gather_step(out, k))
-        for w_ in works:
-            w_.wait()
+                self.comm.allgather_rows(out, self.step_bounds(k))
+        self.comm.join()
 
     def sqdiff_total(self, row_sqdiff):
         """Sum of the per-row squared differences over all ranks (f64)."""
         t = row_sqdiff.sum(dtype=torch.float64).reshape(1)
-        if self.world > 1:
-            dist.all_reduce(t, group=self.group)
+        self.comm.allreduce(t)
         return float(t)
 
 
@@ -231,7 +250,7 @@ def embed_sharded(sg, kind, x0, iterations, residual_weight=0.0, convergence_thr
         return x, iterations
     check = convergence_threshold > 0
     flags = flags | _hip.F_RESIDUAL
-    sq = torch.zeros(sg.steps * sg.block, dtype=torch.float64, device=x0.device) if check else None
+    sq = torch.zeros(sg.local_rows, dtype=torch.float64, device=x0.device) if check else None
     ran = iterations
     total = float(sg.n) * x0.shape[1]
     for it in range(iterations):
@@ -266,13 +285,14 @@ class ColumnShardedGraph:
     """
 
     def __init__(self, n, rowptr, col, val_left, val_sym, d, rank, world, backend,
-                 hub_threshold=0, hub_segment=0, group=None, steps=1):
+                 hub_threshold=0, hub_segment=0, comm=None, steps=1, group=None):
         if d % world != 0:
             raise ValueError(f"feature_dim {d} must be divisible by the number of ranks {world}")
         self.n, self.d, self.rank, self.world = n, d, rank, world
         self.dl = d // world
         self.c0 = rank * self.dl
-        self.backend, self.group = backend, group
+        self.backend = backend
+        self.comm = comm if comm is not None else comm_mod.default_comm(group)
         self.nnz = int(col.numel())
         # `steps` row blocks per iteration: the all-reduce of block k's row sums overlaps the SpMM
         # of block k+1 (the blocks are zero-copy views of the one CSR every rank holds)
@@ -302,17 +322,15 @@ class ColumnShardedGraph:
                                        row_sqdiff[r0:r1] if row_sqdiff is not None else None)
             return
         first = (flags & ~(_hip.F_L2NORM | _hip.F_SQDIFF)) | (_hip.F_ROWSQ if norm else 0)
-        works = []
         for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
             self.backend.propagate(blk, kind, x, x_next[r0:r1], first, rw, x[r0:r1], None,
                                    rowsq[r0:r1] if norm else None)
             if norm:
-                works.append(dist.all_reduce(rowsq[r0:r1], group=self.group, async_op=True))
+                self.comm.allreduce_async(rowsq[r0:r1])       # beside the next block's SpMM
+        self.comm.join()
         second = (_hip.F_SCALE if norm else 0) | (flags & _hip.F_SQDIFF)
-        for k, (r0, r1) in enumerate(self.row_blocks):
-            if norm:
-                works[k].wait()
-            if second:
+        if second:
+            for r0, r1 in self.row_blocks:
                 self.backend.rowops(x_next[r0:r1], x_next[r0:r1], second, 0.0,
                                     x[r0:r1] if (flags & _hip.F_SQDIFF) else None,
                                     row_sqdiff[r0:r1] if row_sqdiff is not None else None,
@@ -328,44 +346,48 @@ class ColumnShardedGraph:
         P, rp, dl, d = self.world, self.rows_per, self.dl, self.d
         if P > 1:
             recv = torch.empty((P, rp, dl), dtype=y_local.dtype, device=y_local.device)
-            dist.all_to_all_single(recv.view(-1), y_local[: self.n_pad].reshape(-1), group=self.group)
+            self.comm.alltoall(y_local[: self.n_pad].contiguous(), recv)
             rows = recv.permute(1, 0, 2).reshape(rp, d).contiguous()      # my rows, all columns
         else:
             rows = y_local[: self.n_pad]
         nv = max(0, min(rp, self.n - self.rank * rp))
         cs = self.backend.colsum(rows[:nv]) if nv else torch.zeros(d, dtype=torch.float64, device=rows.device)
-        if P > 1:
-            dist.all_reduce(cs, group=self.group)
+        self.comm.allreduce(cs)
         mean = cs / float(self.n)
         gram = self.backend.gram(rows[:nv], mean) if nv else torch.zeros((d, d), dtype=torch.float64, device=rows.device)
-        if P > 1:
-            dist.all_reduce(gram, group=self.group)
+        self.comm.allreduce(gram)
         # every rank holds the same all-reduced Gram: eigh is replicated (deterministic routine),
         # but the transform is still broadcast from rank 0 so the ranks cannot drift apart
-        transform = transform_from_gram(self.backend, gram, self.n, d)
-        if P > 1:
-            dist.broadcast(transform, src=0, group=self.group)
+        transform = self.backend.whiten_transform(gram, self.n, d)
+        self.comm.broadcast(transform, 0)
         proj = torch.zeros((rp, d), dtype=torch.float32, device=rows.device)
         if nv:
             self.backend.project(rows[:nv], mean.to(torch.float32), transform, proj[:nv])
         if P > 1:
             send = proj.view(rp, P, dl).permute(1, 0, 2).contiguous()       # column block j -> rank j
-            dist.all_to_all_single(out_local[: self.n_pad].view(-1), send.view(-1), group=self.group)
+            if out_local.shape[0] == self.n_pad and out_local.is_contiguous():
+                self.comm.alltoall(send, out_local)
+            else:
+                tmp = torch.empty((self.n_pad, dl), dtype=out_local.dtype, device=out_local.device)
+                self.comm.alltoall(send, tmp)
+                out_local[: self.n_pad].copy_(tmp)
         else:
             out_local[: self.n_pad].copy_(proj)
 
     def gather_columns(self, x_local):
-        """(n, d) on every rank from the (n, d/P) slices (not part of the iteration)."""
+        """(rows, d) on every rank from the (rows, d/P) slices (not part of the iteration)."""
         if self.world == 1:
             return x_local
-        parts = [torch.empty_like(x_local) for _ in range(self.world)]
-        dist.all_gather(parts, x_local.contiguous(), group=self.group)
-        return torch.cat(parts, dim=1)
+        rows = x_local.shape[0]
+        parts = torch.empty((self.world * rows, self.dl), dtype=x_local.dtype, device=x_local.device)
+        parts[self.rank * rows:(self.rank + 1) * rows].copy_(x_local)
+        self.comm.allgather_rows(parts, [r * rows for r in range(self.world + 1)])
+        self.comm.join()
+        return parts.view(self.world, rows, self.dl).permute(1, 0, 2).reshape(rows, self.d).contiguous()
 
     def sqdiff_total(self, row_sqdiff):
         t = row_sqdiff.sum(dtype=torch.float64).reshape(1)
-        if self.world > 1:
-            dist.all_reduce(t, group=self.group)
+        self.comm.allreduce(t)
         return float(t)
 
 

@@ -27,8 +27,8 @@ def _validate_propagation(propagation):
 
 
 def _check_device_normalization(normalization):
-    if normalization not in ("l2", "none"):
-        raise ValueError(f"the device path runs normalization 'l2' or 'none'; got '{normalization}'")
+    if normalization not in ("l2", "l1", "none"):
+        raise ValueError(f"the device path runs normalization 'l2', 'l1' or 'none'; got '{normalization}'")
 
 
 def _row_normalised(rowptr, vals64):

@@ -34,13 +34,14 @@
 extern "C" {
 #endif
 
-#define CLEORA_ABI_VERSION 1
+#define CLEORA_ABI_VERSION 2
 
 #define CLEORA_OK 0
 #define CLEORA_E_INVALID (-1)   /* bad argument (shape, null pointer, unknown enum) */
 #define CLEORA_E_OOM (-2)       /* device or host allocation failed */
 #define CLEORA_E_HIP (-3)       /* a HIP runtime call failed; see cleora_last_error() */
 #define CLEORA_E_NODEVICE (-4)  /* no usable GPU */
+#define CLEORA_E_RCCL (-5)      /* RCCL could not be loaded or a collective failed; see cleora_last_error() */
 
 /* MarkovType (src/embedding.rs:7-10) */
 #define CLEORA_LEFT 0
@@ -58,6 +59,12 @@ extern "C" {
 #define CLEORA_F_SCALE 32u    /* IN: row_sumsq[r] is the complete sum of squares; y[r] *= 1/max(sqrt(.),1e-10)
                                  (src/embedding.rs:98-102) without recomputing it */
 #define CLEORA_F_WHITEN 64u   /* cleora_embed only: whiten_embeddings after the L2 norm of every iteration (pycleora/__init__.py:963-971) */
+#define CLEORA_F_L1NORM 128u  /* y[r] /= max(sum_j |y[r][j]|, 1e-10): _normalize(emb, "l1") (pycleora/__init__.py:947-950);
+                                 exclusive with L2NORM / ROWSQ / SCALE */
+#define CLEORA_F_BLEND_ANY 256u /* with RESIDUAL: blend for ANY rw > 0, like the Python loop of embed() (pycleora/__init__.py:111-115);
+                                 without it the blend is gated on 0 < rw < 1 like the Rust loop (src/embedding.rs:116) */
+#define CLEORA_F_SQDIFF64 512u /* with SQDIFF: delta = (double)y - (double)x_self, like _compute_rmse (pycleora/__init__.py:974-976);
+                                 without it delta is the f32 difference like src/embedding.rs:172 */
 
 typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct SparseMatrix, src/sparse_matrix.rs:56-78) */
 
@@ -86,6 +93,12 @@ int cleora_memcpy_d2h(void *dst_host, const void *src_dev, uint64_t bytes, void 
 int cleora_memcpy_d2d(void *dst_dev, const void *src_dev, uint64_t bytes, void *stream);
 int cleora_memset(void *dst_dev, int value, uint64_t bytes, void *stream);
 int cleora_stream_sync(void *stream);
+/* A non-blocking stream of the current device, and the one ordering primitive the multi-GPU loop needs:
+ * everything enqueued on `waiter` after this call runs after everything enqueued on `signaller` before it
+ * (an event record + stream-wait; no host synchronisation).  NULL = the default stream. */
+int cleora_stream_create(void **stream);
+int cleora_stream_destroy(void *stream);
+int cleora_stream_wait_stream(void *waiter, void *signaller);
 
 /* ---- graph: the CSR the kernels read ------------------------------------------------
  * Replaces the in-memory `edges`/`slices` of struct SparseMatrix (src/sparse_matrix.rs:56-78):
@@ -218,6 +231,13 @@ uint64_t cleora_whiten_workspace(uint64_t n, uint32_t d);
 int cleora_whiten_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t n_components,
                       float *y, uint64_t ldy, void *workspace, double *eigenvalues_dev, void *stream);
 
+/* Per-stage timing of cleora_whiten_dev for roofline reporting (no reference counterpart; process-wide).  While
+ * enabled every call brackets its stages with HIP events on the launch stream; cleora_whiten_get_timing waits for
+ * them, returns the summed milliseconds — ms[0] column statistics (mean), ms[1] centred Gram (f64 MFMA),
+ * ms[2] eigensolver + transform, ms[3] projection (f32 MFMA) — and the number of calls covered, then resets. */
+int cleora_whiten_set_timing(int enable);
+int cleora_whiten_get_timing(double ms[4], uint64_t *calls);
+
 /* ---- similarity ---------------------------------------------------- */
 
 /* scores[r] = (x[r] . query) / max(||x[r]||, 1e-10): the row-normalise + GEMV of find_most_similar /
@@ -225,6 +245,39 @@ int cleora_whiten_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint
  * already normalised (d floats, device). */
 int cleora_cosine_scores_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                              const float *query_dev, float *scores_dev, void *stream);
+
+/* ---- multi-GPU exchange steps: RCCL over xGMI (no reference counterpart: pycleora is single-process) ----
+ * BASELINE.json:north_star: "the graph is row-partitioned across the 8 GPUs of one node with an RCCL all-gather of
+ * the embedding matrix over xGMI between iterations", reachable "through a thin extern-C FFI".  One communicator
+ * per process (= per GPU).  RCCL is bound with dlopen on the first call (CLEORA_RCCL=<path> overrides the name), so
+ * single-GPU hosts never load it.  Bootstrap like NCCL: rank 0 calls cleora_comm_unique_id and the HOST distributes
+ * the CLEORA_COMM_ID_BYTES bytes to the other ranks by its own means (MPI, a TCP store, a file), then every rank
+ * calls cleora_comm_create (collective: returns once all ranks have joined).
+ * Every collective works IN PLACE on device memory, only ENQUEUES on `stream`, and must be called by all ranks in
+ * the same order; order it against the kernels with cleora_stream_wait_stream. */
+#define CLEORA_COMM_ID_BYTES 128
+#define CLEORA_ALLGATHER_RING 0  /* ncclAllGather for equal shards (grouped ncclBroadcast for unequal ones) */
+#define CLEORA_ALLGATHER_P2P 1   /* grouped ncclSend/ncclRecv: every shard crosses each xGMI link once, directly */
+typedef struct cleora_comm cleora_comm;
+int cleora_comm_unique_id(void *id_out);
+int cleora_comm_create(const void *id, int rank, int world, int device, cleora_comm **out);
+int cleora_comm_destroy(cleora_comm *c);
+int cleora_comm_info(const cleora_comm *c, int *rank, int *world, int *device);
+int cleora_comm_set_allgather(cleora_comm *c, int algo);   /* default RING; env CLEORA_ALLGATHER=p2p selects P2P */
+
+/* The exchange step of the row partition: buf holds offsets[world] floats (e.g. a row range of the next iterate,
+ * contiguous, ld = d); rank r has just written elements [offsets[r], offsets[r+1]) and every rank ends up with all
+ * of them.  cleora_allgather_f32_dev is the equal-shard form (offsets[r] = r * elems_per_rank). */
+int cleora_allgatherv_f32_dev(cleora_comm *c, float *buf, const uint64_t *offsets, void *stream);
+int cleora_allgather_f32_dev(cleora_comm *c, float *buf, uint64_t elems_per_rank, void *stream);
+/* Sums over ranks, in place: the row sums of squares of the column partition (f32) and the whitening statistics
+ * (f64 column sums and Gram matrix, pycleora/__init__.py:136-143) under either partition. */
+int cleora_allreduce_f32_dev(cleora_comm *c, float *buf, uint64_t n, void *stream);
+int cleora_allreduce_f64_dev(cleora_comm *c, double *buf, uint64_t n, void *stream);
+int cleora_broadcast_dev(cleora_comm *c, void *buf, uint64_t bytes, int root, void *stream);
+/* recv[j * elems_per_rank ...] <- rank j's send[me * elems_per_rank ...]: the column <-> row layout switch around the
+ * whitening step of the column partition. */
+int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint64_t elems_per_rank, void *stream);
 
 /* ---- host-pointer entry points: what the PyO3 methods call ------------------------- */
 
@@ -250,9 +303,9 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
  * 0 < rw < 1, L2), optional RMSE early stop (threshold > 0, from iteration 1).
  * The graph must be square (n_rows == n_cols).  out_host: n x d.  iterations_run may be NULL.
  * With CLEORA_F_WHITEN in `flags` the loop is the default path of pycleora.embed() instead
- * (pycleora/__init__.py:97-127 with _postprocess_iteration :963-971): every iteration is SpMM, residual
- * (rw must be < 1), L2 normalise, THEN whiten_embeddings; the RMSE of the early stop is taken between
- * whitened iterates in f64 (:122-125, :974-976). */
+ * (pycleora/__init__.py:97-127 with _postprocess_iteration :963-971): every iteration is SpMM, residual blend for
+ * ANY rw > 0 (:111-115 — unlike the Rust loop's 0 < rw < 1), L2 normalise (L1 with CLEORA_F_L1NORM), THEN
+ * whiten_embeddings; the RMSE of the early stop is taken between whitened iterates in f64 (:122-125, :974-976). */
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,

@@ -17,6 +17,8 @@ What it writes
                         on seeded inputs (the seeds are stored with the outputs).
   variants_ref.npz      embed_multiscale / embed_weighted / embed_directed / embed_with_attention /
                         embed_edge_features / predict_links of the reference, on karate club.
+  edge_semantics_ref.npz  embed() corners where the Python and the Rust loop differ (rw >= 1, 'l1' / 'none',
+                        early stop between whitened iterates) and whiten_embeddings' n_components slicing.
   karate_ref.npz        config 1: karate_club lines + labels (datasets.py:283-331,
                         data only) and the result of the reference's embed()
                         (:51-127, whiten=True and whiten=False) run UNMODIFIED over
@@ -178,8 +180,46 @@ def main():
         var[f"pred_{tag}_target"] = np.array([p["target"] for p in pred])
         var[f"pred_{tag}_score"] = np.array([p["score"] for p in pred])
     np.savez_compressed(os.path.join(HERE, "variants_ref.npz"), **var)
+    edge_semantics(pc, g)
     print("golden fixtures written to", HERE)
 
 
+def edge_semantics(pc, g):
+    """edge_semantics_ref.npz: the corners of embed() where the Python loop and the Rust loop differ
+    (SURVEY.md §8 A10): residual_weight >= 1 blends on the Python path (pycleora/__init__.py:111-115),
+    normalization 'l1' / 'none' (:947-959), early stop between whitened iterates (:122-125), and the
+    n_components slicing of whiten_embeddings (:151-153).  Reference functions, unmodified, on karate club."""
+    out = {}
+    noop = lambda i, e: None
+    out["l1_nowhiten"] = pc.embed(g, 16, 6, normalization="l1", whiten=False)
+    out["l1_whiten"] = pc.embed(g, 16, 6, normalization="l1")
+    out["none_nowhiten"] = pc.embed(g, 16, 4, normalization="none", whiten=False)
+    out["rw10_nowhiten"] = pc.embed(g, 16, 6, residual_weight=1.0, whiten=False, callback=noop)
+    out["rw15_nowhiten"] = pc.embed(g, 16, 6, residual_weight=1.5, whiten=False, callback=noop)
+    out["rw15_whiten"] = pc.embed(g, 16, 6, residual_weight=1.5)
+    out["rw15_sym_l1"] = pc.embed(g, 16, 5, propagation="symmetric", normalization="l1", residual_weight=1.5,
+                                  whiten=False)
+    # (no early-stop fixture for whiten=True: the RMSE between whitened iterates is dominated by eigenvector sign
+    # flips — 1.2-1.5 for all 40 iterations here — so its stopping iteration is a property of the LAPACK build)
+    seen2 = []
+    out["conv_nowhiten"] = pc.embed(g, 16, 40, convergence_threshold=0.02, whiten=False,
+                                    callback=lambda i, e: seen2.append(i))
+    out["conv_nowhiten_iters"] = np.array([len(seen2)])
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((300, 12)) * np.linspace(0.5, 2.0, 12)).astype(np.float32)
+    out["nc_x"] = x
+    out["nc_0"] = pc.whiten_embeddings(x, n_components=0)
+    out["nc_m3"] = pc.whiten_embeddings(x, n_components=-3)
+    out["nc_40"] = pc.whiten_embeddings(x, n_components=40)
+    np.savez_compressed(os.path.join(HERE, "edge_semantics_ref.npz"), **out)
+    return out
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["edge_semantics"]:      # only the newest fixture (the others stay byte-identical)
+        _pc = import_reference()
+        from pycleora.datasets import load_karate_club as _lk
+        _ds = _lk()
+        edge_semantics(_pc, StubSparseMatrix.from_iterator(iter(_ds["edges"]), _ds["columns"]))
+    else:
+        main()

@@ -30,12 +30,29 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_error_channel():
     L = _hip.lib()
-    assert L.cleora_abi_version() == 1
+    assert L.cleora_abi_version() == _hip.ABI_VERSION == 2
     # argument validation happens before any device work
     n = ctypes.c_int(-1)
     assert L.cleora_device_count(ctypes.byref(n)) == _hip.OK and n.value >= 0
     assert L.cleora_graph_get_info(None, None) == _hip.E_INVALID
     assert "NULL" in _hip.last_error()
+
+
+def test_comm_entry_points_validate_before_touching_rccl():
+    """The multi-GPU section of the ABI (csrc/comm.hip): argument checks come first, and without a device the
+    communicator cannot be created — there is no host-side emulation of the collectives."""
+    L = _hip.lib()
+    assert L.cleora_comm_create(None, 0, 1, 0, None) == _hip.E_INVALID
+    h = ctypes.c_void_p()
+    assert L.cleora_comm_create(None, 0, 1, 0, ctypes.byref(h)) == _hip.E_INVALID and "id" in _hip.last_error()
+    ident = (ctypes.c_char * _hip.COMM_ID_BYTES)()
+    assert L.cleora_comm_create(ctypes.cast(ident, ctypes.c_void_p), 2, 2, 0, ctypes.byref(h)) == _hip.E_INVALID
+    assert L.cleora_allreduce_f32_dev(None, None, 4, None) == _hip.E_INVALID
+    assert L.cleora_allgatherv_f32_dev(None, None, None, None) == _hip.E_INVALID
+    assert L.cleora_comm_destroy(None) == _hip.OK
+    if _hip.device_count() == 0:
+        rc = L.cleora_comm_create(ctypes.cast(ident, ctypes.c_void_p), 0, 1, 0, ctypes.byref(h))
+        assert rc in (_hip.E_RCCL, _hip.E_HIP, _hip.E_NODEVICE) and not h.value
 
 
 @pytest.mark.skipif(_hip.device_count() > 0, reason="only meaningful without a GPU")

@@ -147,7 +147,8 @@ def test_properties_at_baseline_sizes(config):
     rp = g["rowptr"].cpu().numpy()
     colh, vsh = g["col"].cpu().numpy().view(np.uint32), g["val_sym"].cpu().numpy()
     xh = x.cpu().numpy()
-    ys = prop(graph, x, 0, 1).cpu().numpy()
+    ys_dev = prop(graph, x, 0, 1)
+    ys = ys_dev.cpu().numpy()
     for r in rows[:400]:
         b, e = int(rp[r]), int(rp[r + 1])
         if e - b > 1024:
@@ -156,6 +157,61 @@ def test_properties_at_baseline_sizes(config):
         for k in range(b, e):
             acc += vsh[k] * xh[colh[k]]
         np.testing.assert_array_equal(ys[r], acc)
+    # 7. WHOLE-GRAPH parity with the oracle (src/embedding.rs:52-104), left and symmetric, same graph and X:
+    #    one fused SpMM + L2 iteration — every row that is not split must be bit-identical; split (hub) rows are
+    #    summed in segment order on the GPU and carry <= 2e-6 * sum|terms| on the un-normalised product
+    rp64 = rp.astype(np.uint64)
+    edges = np.empty(nnz, dtype=oracle.EDGE_DTYPE)
+    edges["col"], edges["left"], edges["sym"] = colh, g["val_left"].cpu().numpy(), vsh
+    hub = np.diff(rp.astype(np.int64)) > graph.info().hub_threshold
+    threads = oracle.max_threads()
+    want = np.empty((n, d), np.float32)
+    for kind, vals in ((0, edges["left"]), (1, edges["sym"])):
+        oracle.spmm_aos_l2_inplace(rp64, edges, kind == 1, xh, want, threads)
+        got = prop(graph, x, _hip.F_L2NORM, kind).cpu().numpy()
+        same = (got.view(np.uint32) == want.view(np.uint32)).all(axis=1)
+        assert same[~hub].all(), f"{(~same[~hub]).sum()} of {(~hub).sum()} unsplit rows differ from the oracle"
+        raw = y1 if kind == 0 else ys_dev
+        hub_rows = np.flatnonzero(hub)
+        big = hub_rows[np.argsort(-np.diff(rp.astype(np.int64))[hub_rows])[:24]]
+        rnd = np.random.default_rng(7).choice(hub_rows, size=min(150, hub_rows.size), replace=False) if hub_rows.size else hub_rows
+        for r in np.unique(np.concatenate([big, rnd])):
+            b, e = int(rp[r]), int(rp[r + 1])
+            terms = vals[b:e, None].astype(np.float64) * xh[colh[b:e]].astype(np.float64)
+            ref, bound = terms.sum(axis=0), 2e-6 * np.abs(terms).sum(axis=0)
+            assert np.all(np.abs(raw[r].cpu().numpy().astype(np.float64) - ref) <= bound + 1e-12)
+        del got
+    del want, edges
+
+
+def test_whitening_at_c2_size_against_numpy_oracle():
+    """whiten_embeddings (pycleora/__init__.py:130-164) at BASELINE config 2's shape, 1M x 256: the device chain
+    (cleora_whiten_dev) against the numpy fp64 restatement, columns sign-aligned; tolerance 2e-4 relative like the
+    small-size tests (f32 projection with a different summation order)."""
+    import torch
+    from oracle import whiten as ow
+    dev = torch.device("cuda:0")
+    n, d = 1_000_000, 256
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    x = torch.randn((n, d), generator=gen, device=dev, dtype=torch.float32)
+    x = x * torch.linspace(0.5, 3.0, d, device=dev) + torch.randn(d, generator=gen, device=dev)
+    x = (x / x.norm(dim=1, keepdim=True)).contiguous()             # unit rows, anisotropic, non-centred
+    L = _hip.lib()
+    ws = torch.empty(L.cleora_whiten_workspace(n, d), dtype=torch.uint8, device=dev)
+    y = torch.empty_like(x)
+    eig = torch.empty(d, dtype=torch.float64, device=dev)
+    _hip.check(L.cleora_whiten_dev(x.data_ptr(), d, n, d, d, y.data_ptr(), d, ws.data_ptr(), eig.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream))
+    got = y.cpu().numpy()
+    xh = x.cpu().numpy()
+    mean, cov = ow.whiten_stats(xh)
+    _, w = ow.whiten_transform(cov)
+    assert np.abs(eig.cpu().numpy() - w).max() <= 1e-10 * w[0]
+    want = ow.whiten_embeddings(xh)
+    sgn = np.sign((got[:200_000] * want[:200_000]).sum(axis=0))
+    sgn[sgn == 0] = 1
+    assert np.abs(got * sgn - want).max() <= 2e-4 * np.abs(want).max()
 
 
 def test_adopted_device_csr_is_bounds_checked():

@@ -188,8 +188,8 @@ def test_install_shim():
 
 
 def test_accelerate_rebinds_reference_entry_points():
-    """cleora_amd.accelerate() on a stand-in package object: l2/none go to the device loop, other
-    normalisations and foreign graph types are forwarded to the original function."""
+    """cleora_amd.accelerate() on a stand-in package object: l2 / l1 / none go to the device loop, 'spectral'
+    and foreign graph types are forwarded to the original function."""
     import types
     import cleora_amd
     from cleora_amd import embed as dev
@@ -200,8 +200,8 @@ def test_accelerate_rebinds_reference_entry_points():
     assert pkg.whiten_embeddings is dev.whiten_embeddings and pkg.embed.__wrapped__ is not None
     assert pkg.embed(object(), 8, 2) == "orig"                                  # not our SparseMatrix
     g = SparseMatrix.from_iterator(iter(["a b", "b c"]), "complex::reflexive::n")
-    assert pkg.embed(g, 8, 2, normalization="l1") == "orig"
-    assert calls == [("orig", None), ("orig", "l1")]
+    assert pkg.embed(g, 8, 2, normalization="spectral") == "orig"
+    assert calls == [("orig", None), ("orig", "spectral")]
     # the variants are rebound when the package has them; foreign graphs / normalisations are forwarded
     pkg2 = types.SimpleNamespace(embed=pkg.embed.__wrapped__, whiten_embeddings=None,
                                  embed_multiscale=lambda *a, **k: "orig-ms", predict_links=lambda *a, **k: "orig-pl")

@@ -53,6 +53,14 @@ class OracleBackend:
         blk = x.numpy().astype(np.float64) - mean.numpy()
         return torch.from_numpy(blk.T @ blk)
 
+    def whiten_transform(self, gram, n, kdim):
+        """cov = gram/(n-1) -> eigh -> descending -> V / sqrt(max(lambda, 1e-10)) as f32, d x kdim
+        (pycleora/__init__.py:143-156) with numpy's LAPACK, like the reference."""
+        w, v = np.linalg.eigh(gram.numpy() * (1.0 / (n - 1)))
+        idx = np.argsort(w)[::-1][:kdim]
+        scale = 1.0 / np.sqrt(np.maximum(w[idx], 1e-10))
+        return torch.from_numpy(np.ascontiguousarray((v[:, idx] * scale).astype(np.float32)))
+
     def project(self, x, mean32, transform, out):
         out.copy_(torch.from_numpy((x.numpy() - mean32.numpy()) @ transform.numpy()))
 
@@ -65,7 +73,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, steps, q):
+def _worker(rank, world, port, steps, q, balance="rows"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -73,7 +81,7 @@ def _worker(rank, world, port, steps, q):
         rowptr, col, vl, vs = random_csr(n, 7, seed=3, empty_frac=0.05, hubs=[(5, 300)])
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.kind == "u" else a)
         sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
-                                  torch.from_numpy(vs), rank, world, steps, OracleBackend())
+                                  torch.from_numpy(vs), rank, world, steps, OracleBackend(), balance=balance)
         x0 = np.zeros((sg.n_pad, d), np.float32)
         x0[:n] = np.random.default_rng(9).standard_normal((n, d)).astype(np.float32)
         res = {}
@@ -82,17 +90,19 @@ def _worker(rank, world, port, steps, q):
             res[(kind, rw, thr)] = (x[:n].numpy().copy(), ran, float(x[n:].abs().max()) if sg.n_pad > n else 0.0)
         xw, _ = sharded.embed_sharded(sg, 0, torch.from_numpy(x0.copy()), 3, whiten=True)
         res["whiten"] = xw[:n].numpy().copy()
-        q.put((rank, sg.block, sg.n_pad, sg.local_nnz, res))
+        q.put((rank, sg.bounds, sg.n_pad, sg.local_nnz, res))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("steps", [1, 3])
-def test_world2_matches_single_process(steps):
+@pytest.mark.parametrize("steps,balance", [(1, "rows"), (3, "rows"), (2, "nnz"), (3, "auto")])
+def test_world2_matches_single_process(steps, balance):
+    """Equal-rows split (one all-gather per step) and the nnz-balanced split (unequal shards: all-gather-v);
+    "auto" picks nnz here because row 5 is a 300-edge hub."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q, balance)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
@@ -103,7 +113,17 @@ def test_world2_matches_single_process(steps):
     rowptr, col, vl, vs = random_csr(n, 7, seed=3, empty_frac=0.05, hubs=[(5, 300)])
     x0 = np.random.default_rng(9).standard_normal((n, d)).astype(np.float32)
     assert sum(g[3] for g in got) == int(rowptr[-1])            # every edge owned exactly once
-    assert got[0][2] == got[1][2] and got[0][2] >= n and got[0][2] % (world * steps * 4) == 0
+    assert got[0][2] == got[1][2] and got[0][2] >= n and got[0][1] == got[1][1]
+    bounds = got[0][1]
+    assert bounds[0] == 0 and bounds[-1] == got[0][2] and len(bounds) == world * steps + 1
+    assert all(b % 4 == 0 for b in bounds) and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    if balance == "rows":
+        assert got[0][2] % (world * steps * 4) == 0 and len({b - a for a, b in zip(bounds, bounds[1:])}) == 1
+    else:
+        # blocks balanced on the rowptr prefix sum — every block within one max-row of the mean work
+        work = [int(rowptr[min(b, n)] - rowptr[min(a, n)]) + (min(b, n) - min(a, n)) for a, b in zip(bounds, bounds[1:])]
+        mean = (int(rowptr[-1]) + n) / len(work)
+        assert got[0][2] == -(-n // 4) * 4 and max(abs(w - mean) for w in work) <= 300 + 4 * 8 + 4
     from oracle import whiten as ow
     want_w, _ = ow.embed_slow(lambda x: oracle.spmm(rowptr, col, vl, x), x0, 3, whiten=True)
     for rank, _, _, _, res in got:

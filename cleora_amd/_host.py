@@ -150,7 +150,8 @@ class HostGraph:
 
     def set_entity_ids(self, ids):
         data, offsets = pack_strings(ids)
-        lib().cleora_host_set_ids(self.handle, data, offsets.ctypes.data_as(vp), len(ids))
+        if lib().cleora_host_set_ids(self.handle, data, offsets.ctypes.data_as(vp), len(ids)) != 0:
+            raise ValueError(last_error())
 
     def descriptor(self):
         a, b = ctypes.c_uint8(0), ctypes.c_uint8(0)

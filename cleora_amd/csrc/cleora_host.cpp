@@ -579,6 +579,12 @@ int cleora_host_descriptor(const cleora_hostgraph *g, uint8_t *a_id, const char 
 
 int cleora_host_set_ids(cleora_hostgraph *g, const char *buf, const uint64_t *offsets, uint64_t n) {
     if (!g || (n && !offsets)) { g_err = "NULL argument"; return -1; }
+    // every per-entity array (row sums, hashes, column ids, rowptr) is indexed by entity: a list of another length
+    // would leave them inconsistent (the reference's setter accepts it and then fails on the next propagate)
+    if (n + 1 != g->rowptr.size() && !(n == 0 && g->rowptr.empty())) {
+        g_err = "entity_ids must have one id per entity (" + std::to_string(g->rowptr.empty() ? 0 : g->rowptr.size() - 1) + ")";
+        return -1;
+    }
     g->ids.resize(n);
     g->hashes.resize(n);
     for (uint64_t i = 0; i < n; ++i) {
@@ -629,6 +635,7 @@ int cleora_host_deserialize(const uint8_t *bytes, uint64_t len, cleora_hostgraph
     }
     uint64_t ne = r.get<uint64_t>();
     if (!r.ok || ne > len) return fail("entities");
+    if (ne != n) return fail("entities and entity_ids differ in length");
     g->row_sum.resize(ne);
     for (uint64_t i = 0; i < ne; ++i) g->row_sum[i] = r.get<float>();
     uint64_t nnz = r.get<uint64_t>();
@@ -650,6 +657,7 @@ int cleora_host_deserialize(const uint8_t *bytes, uint64_t len, cleora_hostgraph
     if (prev_end != nnz) return fail("slices do not cover the edges");
     uint64_t nc = r.get<uint64_t>();
     if (!r.ok || nc > len) return fail("column_ids");
+    if (nc != n) return fail("column_ids and entity_ids differ in length");
     g->column_ids.resize(nc);
     for (uint64_t i = 0; i < nc; ++i) g->column_ids[i] = r.get<uint8_t>();
     if (!r.ok) return fail("truncated input");

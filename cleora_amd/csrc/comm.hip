@@ -210,7 +210,7 @@ int cleora_allgatherv_f32_dev(cleora_comm *c, float *buf, const uint64_t *offset
         CL_REQUIRE(offsets[r] <= offsets[r + 1], "offsets must be non-decreasing");
         if (offsets[r + 1] - offsets[r] != offsets[1] - offsets[0]) equal = false;
     }
-    if (P == 1) return CLEORA_OK;
+    // (a world of one still goes through RCCL: a single-GPU box then exercises the same calls)
     Rccl *r;
     int rc = need_rccl(&r);
     if (rc != CLEORA_OK) return rc;
@@ -256,7 +256,7 @@ int cleora_allgather_f32_dev(cleora_comm *c, float *buf, uint64_t elems_per_rank
 static int allreduce(cleora_comm *c, void *buf, uint64_t n, ncclDataType_t t, void *stream) {
     CL_REQUIRE(c != nullptr, "comm is NULL");
     CL_REQUIRE(buf != nullptr || n == 0, "buf is NULL");
-    if (c->world == 1 || n == 0) return CLEORA_OK;
+    if (n == 0) return CLEORA_OK;
     Rccl *r;
     int rc = need_rccl(&r);
     if (rc != CLEORA_OK) return rc;
@@ -278,7 +278,7 @@ int cleora_broadcast_dev(cleora_comm *c, void *buf, uint64_t bytes, int root, vo
     CL_REQUIRE(c != nullptr, "comm is NULL");
     CL_REQUIRE(root >= 0 && root < c->world, "bad root");
     CL_REQUIRE(buf != nullptr || bytes == 0, "buf is NULL");
-    if (c->world == 1 || bytes == 0) return CLEORA_OK;
+    if (bytes == 0) return CLEORA_OK;
     Rccl *r;
     int rc = need_rccl(&r);
     if (rc != CLEORA_OK) return rc;

@@ -16,6 +16,22 @@ exist (ids are compacted), as in the reference.
 import torch
 
 
+def _sqrt_f32_correctly_rounded(p):
+    """IEEE-correct f32 square root of an f32 tensor, whatever the backend's math library does (torch's CPU sqrt
+    is off by one ulp on some inputs; the reference divides by Rust's correctly rounded f32::sqrt,
+    src/sparse_matrix_builder.rs:326-330).  A candidate c is the correctly rounded root iff
+    (c - ulp/2)^2 <= p <= (c + ulp/2)^2; the midpoints have 25 significant bits, so their squares are exact in f64."""
+    s = torch.sqrt(p)
+    p64 = p.double()
+    inf = torch.full_like(s, float("inf"))
+    for _ in range(2):
+        up, down = torch.nextafter(s, inf), torch.nextafter(s, -inf)
+        hi = (s.double() + up.double()) * 0.5
+        lo = (s.double() + down.double()) * 0.5
+        s = torch.where(hi * hi < p64, up, torch.where(lo * lo > p64, down, s))
+    return s
+
+
 def _csr_from_undirected(a, b, n_nodes, reflexive):
     """a, b: int64 endpoint tensors of DISTINCT undirected pairs with a != b."""
     dev = a.device
@@ -45,7 +61,7 @@ def _csr_from_undirected(a, b, n_nodes, reflexive):
     degf = deg.to(torch.float32)
     base = torch.tensor(0.5 if reflexive else 1.0, dtype=torch.float32, device=dev)
     val_left = base / degf[rows]
-    val_sym = base / torch.sqrt(degf[rows] * degf[cols])
+    val_sym = base / _sqrt_f32_correctly_rounded(degf[rows] * degf[cols])
     if reflexive:
         is_diag = rows == cols
         val_left[is_diag] = 0.5   # (deg/2)/deg

@@ -1,0 +1,95 @@
+// mfma_peak.hip — measured ceilings of the two MFMA shapes the whitening kernels use, on this chip:
+//   v_mfma_f64_16x16x4_f64  (gram_kernel)      v_mfma_f32_32x32x2_f32  (project_kernel)
+// One wave per SIMD (256-thread blocks, 1 block/CU) and 2 waves per SIMD (2 blocks/CU); N independent
+// accumulators per wave so the dependent-issue latency is covered.  Prints TFLOP/s and the effective clock
+// implied by the known cycles per instruction.   hipcc --offload-arch=gfx950 -O3 mfma_peak.hip -o mfma_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_f64(double *out, int iters, double a0, double b0) {
+    d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_f32(float *out, int iters, float a0, float b0) {
+    f16v acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <class K, class T>
+double run(K kernel, int blocks, int iters, T *out, T a, T b) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, iters / 8, a, b);   // warm
+    hipDeviceSynchronize();
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, iters, a, b);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    void *buf;
+    hipMalloc(&buf, (size_t)cus * 4 * 256 * 8);
+    const int iters = 20000;
+    for (int bpc : {1, 2}) {
+        const int blocks = cus * bpc;
+        {
+            const double ms = run(k_f64<8>, blocks, iters, (double *)buf, 1.0, 0.5);
+            const double mf = (double)blocks * 4 * iters * 8;             // wave-level MFMA instructions
+            const double tf = mf * 2.0 * 16 * 16 * 4 / (ms * 1e-3) / 1e12;
+            // 64 cycles per instruction per SIMD if the f64 matrix rate is 32 flop/clk/SIMD
+            printf("f64 16x16x4  %d wave(s)/SIMD: %8.3f ms  %7.2f TFLOP/s   (%.0f cycles/instr/SIMD at 2.4 GHz)\n", bpc, ms, tf,
+                   ms * 1e-3 * 2.4e9 / (mf / (cus * 4.0)));
+        }
+        {
+            const double ms = run(k_f32<4>, blocks, iters, (float *)buf, 1.0f, 0.5f);
+            const double mf = (double)blocks * 4 * iters * 4;
+            const double tf = mf * 2.0 * 32 * 32 * 2 / (ms * 1e-3) / 1e12;
+            printf("f32 32x32x2  %d wave(s)/SIMD: %8.3f ms  %7.2f TFLOP/s   (%.0f cycles/instr/SIMD at 2.4 GHz)\n", bpc, ms, tf,
+                   ms * 1e-3 * 2.4e9 / (mf / (cus * 4.0)));
+        }
+    }
+    hipFree(buf);
+    return 0;
+}

@@ -299,3 +299,24 @@ def test_more_than_2_pow_24_blocks():
     _hip.check(L.cleora_cosine_scores_dev(y.data_ptr(), d, n, d, q.data_ptr(), sc.data_ptr(), s))
     torch.cuda.synchronize()
     assert float((sc - (y * q).sum(1)).abs().max()) < 1e-5          # (not y @ q: the BLAS gemv is itself wrong beyond 2^24 rows)
+
+
+def test_generator_values_on_the_gpu_equal_the_cpu_generator():
+    """bench.py builds its graph with cleora_amd/synth.py ON THE GPU; tests/test_wire_and_generator.py pins the same
+    code on the CPU against the string builder.  Same pairs on both devices: the Markov values
+    (f32 divide, correctly rounded f32 sqrt) must be bit-identical, so the pin carries over to the bench graph."""
+    import torch
+    from cleora_amd import synth
+    cpu = synth.power_law_graph(200_000, 400_000, 3, torch.device("cpu"))
+    rp = cpu["rowptr"].numpy()
+    rows = np.repeat(np.arange(cpu["n"]), np.diff(rp))
+    cols = cpu["col"].numpy().astype(np.int64)
+    keep = rows < cols
+    a, b = torch.from_numpy(rows[keep]), torch.from_numpy(cols[keep])
+    dev = torch.device("cuda:0")
+    for reflexive in (True, False):
+        c = synth._csr_from_undirected(a, b, cpu["n"], reflexive)
+        g = synth._csr_from_undirected(a.to(dev), b.to(dev), cpu["n"], reflexive)
+        assert c["n"] == g["n"] and c["nnz"] == g["nnz"]
+        for key in ("rowptr", "col", "val_left", "val_sym"):
+            assert torch.equal(c[key], g[key].cpu()), key

@@ -1,0 +1,236 @@
+"""CPU: pins that do not need a GPU.
+
+  * N2 — the pickle wire format: bincode 1.3.3's default configuration (little endian, fixed-width integers, u64
+    lengths, struct fields in declaration order, no field names) of `struct SparseMatrix`
+    (src/sparse_matrix.rs:48-78; written by __getstate__, src/lib.rs:463-475).  The expected bytes are assembled
+    HERE from that description with `struct.pack`, independently of cleora_host_serialize.
+  * SURVEY.md §8d — the vectorised graph generators of cleora_amd/synth.py (what bench.py measures on) against
+    the string builder (cleora_host_build_from_lines, N1) on <= 1e5-line subsamples: same CSR, bit for bit.
+  * config 1 plumbing — the reference's REAL command-line entry point (`pycleora.cli.main`, info command) running
+    over cleora_amd.install(); only in the build container, where /root/reference exists.
+"""
+import io
+import os
+import pickle
+import struct
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+from hypothesis import given, settings, strategies as st
+
+import cleora_amd
+from cleora_amd import synth
+from cleora_amd.pycleora import SparseMatrix
+
+
+def bincode_string(s):
+    b = s.encode("utf-8")
+    return struct.pack("<Q", len(b)) + b
+
+
+def bincode_sparse_matrix(col_a, col_b, entity_ids, row_sums, edges, slices, column_ids):
+    """bincode 1.3.3 default options: every integer fixed width little endian, Vec/String = u64 length + items,
+    tuples and structs = their fields in order."""
+    out = struct.pack("<B", col_a[0]) + bincode_string(col_a[1]) + struct.pack("<B", col_b[0]) + bincode_string(col_b[1])
+    out += struct.pack("<Q", len(entity_ids)) + b"".join(bincode_string(s) for s in entity_ids)
+    out += struct.pack("<Q", len(row_sums)) + b"".join(struct.pack("<f", v) for v in row_sums)          # Vec<Entity{row_sum: f32}>
+    out += struct.pack("<Q", len(edges)) + b"".join(struct.pack("<Iff", c, l, s) for c, l, s in edges)   # Vec<Edge{u32, f32, f32}>
+    out += struct.pack("<Q", len(slices)) + b"".join(struct.pack("<QQ", a, b) for a, b in slices)         # Vec<(usize, usize)>
+    out += struct.pack("<Q", len(column_ids)) + bytes(column_ids)                                         # Vec<u8>
+    return out
+
+
+def test_getstate_equals_hand_assembled_bincode():
+    # lines "a b", "b c" in one complex::reflexive column: per line value = 1/4 per ordered pair occurrence
+    # (SURVEY.md Appendix B): E[a,a] = 1/2, E[a,b] = 1/2, E[b,b] = 1, E[b,c] = 1/2, E[c,c] = 1/2; row sums 1, 2, 1
+    g = SparseMatrix.from_iterator(iter(["a b", "b c"]), "complex::reflexive::n")
+    f = np.float32
+    s2 = f(1.0) / np.sqrt(f(2.0), dtype=f)                      # value / sqrt(row_sum[a] * row_sum[b]) with f32 ops
+    half = f(0.5)
+    sym_ab = half / np.sqrt(f(1.0) * f(2.0), dtype=f)
+    edges = [(0, 0.5, 0.5), (1, 0.5, float(sym_ab)),
+             (0, 0.25, float(sym_ab)), (1, 0.5, 0.5), (2, 0.25, float(sym_ab)),
+             (1, 0.5, float(sym_ab)), (2, 0.5, 0.5)]
+    want = bincode_sparse_matrix((0, "n"), (1, "n"), ["a", "b", "c"], [1.0, 2.0, 1.0], edges,
+                                 [(0, 2), (2, 5), (5, 7)], [0, 0, 0])
+    assert g.__getstate__() == want
+    # and the other direction: bytes assembled by hand load into an equal graph
+    h = SparseMatrix()
+    h.__setstate__(want)
+    assert h.entity_ids == ["a", "b", "c"] and h.num_edges == 7 and repr(h) == repr(g)
+    np.testing.assert_array_equal(h.to_sparse_csr()[2], g.to_sparse_csr()[2])
+    np.testing.assert_array_equal(h.to_sparse_csr("symmetric")[2], g.to_sparse_csr("symmetric")[2])
+    np.testing.assert_array_equal(h.entity_degrees, np.array([1.0, 2.0, 1.0], np.float32))
+    assert pickle.loads(pickle.dumps(h)).__getstate__() == want
+    del s2
+
+
+def test_two_column_graph_bincode_and_unicode_ids():
+    g = SparseMatrix.from_iterator(iter(["żółw\tp1 p2", "u2\tp1"]), "user complex::product")
+    state = g.__getstate__()
+    ids = g.entity_ids
+    assert ids == ["żółw", "p1", "p2", "u2"]
+    # header: descriptor {u8 0, "user", u8 1, "product"} then the ids with their UTF-8 byte lengths
+    head = struct.pack("<B", 0) + bincode_string("user") + struct.pack("<B", 1) + bincode_string("product")
+    head += struct.pack("<Q", 4) + b"".join(bincode_string(s) for s in ids)
+    assert state.startswith(head)
+    assert state.endswith(struct.pack("<Q", 4) + bytes([0, 1, 1, 0]))                 # column_ids: first-seen column
+    rows, cols, vals, _, _ = g.to_sparse_csr()
+    body = state[len(head):]
+    (n_ent,) = struct.unpack_from("<Q", body, 0)
+    sums = struct.unpack_from("<4f", body, 8)
+    assert n_ent == 4 and sums == tuple(float(v) for v in g.entity_degrees)
+    (n_edges,) = struct.unpack_from("<Q", body, 8 + 16)
+    assert n_edges == len(cols) == g.num_edges
+    first = struct.unpack_from("<Iff", body, 8 + 16 + 8)
+    assert first[0] == cols[0] and first[1] == vals[0]
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.data())
+def test_corrupted_blobs_raise_and_never_crash(data):
+    """Truncations, bit flips and spliced garbage: __setstate__ answers RuntimeError("Deserialization failed…")
+    like the reference (src/lib.rs:471-472) or loads a self-consistent graph — it never crashes or over-reads."""
+    g = SparseMatrix.from_iterator(iter(["a b c", "c d", "e a"]), "complex::reflexive::n")
+    blob = bytearray(g.__getstate__())
+    kind = data.draw(st.sampled_from(["truncate", "flip", "splice", "length"]))
+    if kind == "truncate":
+        blob = blob[: data.draw(st.integers(0, len(blob) - 1))]
+    elif kind == "flip":
+        for _ in range(data.draw(st.integers(1, 4))):
+            i = data.draw(st.integers(0, len(blob) - 1))
+            blob[i] ^= 1 << data.draw(st.integers(0, 7))
+    elif kind == "splice":
+        i = data.draw(st.integers(0, len(blob)))
+        blob[i:i] = data.draw(st.binary(min_size=1, max_size=24))
+    else:   # overwrite one of the u64 length fields with a huge count
+        i = data.draw(st.integers(0, max(0, len(blob) - 8)))
+        blob[i:i + 8] = struct.pack("<Q", data.draw(st.integers(2 ** 31, 2 ** 64 - 1)))
+    h = SparseMatrix()
+    try:
+        h.__setstate__(bytes(blob))
+    except RuntimeError as e:
+        assert "Deserialization failed" in str(e)
+        return
+    # it loaded: every per-entity array is consistent, so the accessors cannot over-read
+    n = h.num_entities
+    assert len(h.entity_ids) == n == len(h.entity_degrees)
+    rows, cols, vals, _, _ = h.to_sparse_csr()
+    assert len(rows) == len(cols) == len(vals) == h.num_edges and (cols < max(n, 1)).all()
+    assert isinstance(h.__getstate__(), bytes)
+
+
+def test_entity_ids_setter_rejects_a_list_of_another_length():
+    g = SparseMatrix.from_iterator(iter(["a b", "b c"]), "complex::reflexive::n")
+    with pytest.raises(ValueError, match="one id per entity"):
+        g.entity_ids = ["x", "y"]
+    assert g.entity_ids == ["a", "b", "c"] and g._arr["hashes"].shape == (3,)
+    g.entity_ids = ["x", "y", "z"]
+    assert g.entity_ids == ["x", "y", "z"]
+
+
+# ---- the vectorised generators against the string builder --------------------------------------------
+
+def _csr_of(g):
+    rows, cols, left, _, _ = g.to_sparse_csr()
+    sym = g.to_sparse_csr("symmetric")[2]
+    return rows, cols, left, sym
+
+
+def _compare_with_string_builder(gen, lines, columns, name_of_row):
+    """`gen` = synth's CSR dict (CPU tensors); `lines` = the same edges as text.  The builder numbers entities in
+    first-seen order, the generator by node id: compare through the id strings."""
+    g = SparseMatrix.from_iterator(iter(lines), columns)
+    assert g.num_entities == gen["n"] and g.num_edges == gen["nnz"]
+    ids = g.entity_ids
+    index_of = {s: i for i, s in enumerate(ids)}
+    perm = np.array([index_of[name_of_row(r)] for r in range(gen["n"])], dtype=np.int64)      # generator row -> builder row
+    rows_b, cols_b, left_b, sym_b = _csr_of(g)
+    rp = gen["rowptr"].numpy()
+    rows_g = np.repeat(np.arange(gen["n"]), np.diff(rp))
+    cols_g = gen["col"].numpy().astype(np.int64)
+    # generator edges keyed in the builder's numbering, sorted like the builder sorts (row, col)
+    kr, kc = perm[rows_g], perm[cols_g]
+    order = np.lexsort((kc, kr))
+    np.testing.assert_array_equal(kr[order], rows_b.astype(np.int64))
+    np.testing.assert_array_equal(kc[order], cols_b.astype(np.int64))
+    np.testing.assert_array_equal(gen["val_left"].numpy()[order].view(np.uint32), left_b.view(np.uint32))
+    np.testing.assert_array_equal(gen["val_sym"].numpy()[order].view(np.uint32), sym_b.view(np.uint32))
+
+
+def _undirected_pairs(gen):
+    rp = gen["rowptr"].numpy()
+    rows = np.repeat(np.arange(gen["n"]), np.diff(rp))
+    cols = gen["col"].numpy().astype(np.int64)
+    keep = rows < cols
+    return rows[keep], cols[keep]
+
+
+def test_power_law_generator_equals_the_string_builder():
+    """BASELINE config 3's generator at 1/100 scale (95 000 lines): reflexive 2-token lines "a b" through
+    cleora_host_build_from_lines give the generator's CSR — structure, left and symmetric values — bit for bit."""
+    gen = synth.power_law_graph(100_000, 95_000, 2, torch.device("cpu"))
+    a, b = _undirected_pairs(gen)
+    assert gen["nnz"] == 2 * len(a) + gen["n"]
+    lines = [f"v{x} v{y}" for x, y in zip(a.tolist(), b.tolist())]
+    _compare_with_string_builder(gen, lines, "complex::reflexive::node", lambda r: f"v{r}")
+
+
+def test_bipartite_generator_equals_the_string_builder():
+    """BASELINE config 2's generator at 1/100 scale (<= 100 000 lines): two plain columns `user product`."""
+    gen = synth.bipartite_graph(5_000, 5_000, 100_000, 1, torch.device("cpu"))
+    a, b = _undirected_pairs(gen)
+    assert gen["nnz"] == 2 * len(a)
+    # generator ids are compacted over users then products: recover which side a node is on from its edges
+    is_user = np.zeros(gen["n"], bool)
+    is_user[a] = True                      # users have the smaller id of every pair (users are numbered first)
+    assert not is_user[b].any()
+    name = lambda r: (f"u{r}" if is_user[r] else f"p{r}")
+    lines = [f"{name(x)}\t{name(y)}" for x, y in zip(a.tolist(), b.tolist())]
+    _compare_with_string_builder(gen, lines, "user product", name)
+
+
+# ---- config 1 plumbing: the reference's real CLI over install() (build container only) --------------------------------
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pycleora")), reason="the reference checkout exists only in the build container")
+def test_reference_cli_info_runs_over_install(tmp_path, golden_dir):
+    """`pycleora info` (pycleora/cli.py:127-140) — the reference's own entry point, unmodified — builds its graph
+    with OUR SparseMatrix after cleora_amd.install(): `from .pycleora import SparseMatrix` binds to cleora_amd."""
+    k = np.load(os.path.join(golden_dir, "karate_ref.npz"))
+    edges = tmp_path / "karate.txt"
+    edges.write_text("\n".join(str(s) for s in k["edges"]) + "\n")
+    saved = {m: sys.modules.get(m) for m in list(sys.modules) if m == "pycleora" or m.startswith("pycleora.")}
+    for m in saved:
+        sys.modules.pop(m)
+    sys.path.insert(0, REF)
+    argv = sys.argv
+    try:
+        mod = cleora_amd.install()
+        import pycleora
+        import pycleora.cli as cli
+        assert os.path.realpath(pycleora.__file__).startswith(REF)
+        assert pycleora.SparseMatrix is mod.SparseMatrix                      # the reference package now uses our class
+        sys.argv = ["pycleora", "info", "--input", str(edges), "--columns", str(k["columns"])]
+        out = io.StringIO()
+        with redirect_stdout(out):
+            cli.main()
+        text = out.getvalue()
+        assert "Graph: 34 entities, 190 edges" in text and "Degree stats:" in text
+        # a graph pickled under the reference's module path loads back into our class
+        g = pycleora.SparseMatrix.from_iterator(iter(str(s) for s in k["edges"]), str(k["columns"]))
+        assert type(pickle.loads(pickle.dumps(g))).__module__ == "pycleora.pycleora"
+    finally:
+        sys.argv = argv
+        sys.path.remove(REF)
+        cleora_amd.pycleora.SparseMatrix.__module__ = "cleora_amd.pycleora"
+        for m in [m for m in sys.modules if m == "pycleora" or m.startswith("pycleora.")]:
+            sys.modules.pop(m)
+        for m, v in saved.items():
+            if v is not None:
+                sys.modules[m] = v

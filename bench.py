@@ -85,7 +85,7 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
     oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)  # page-touch + pool spin-up; also the check
     deg = np.diff(rowptr.astype(np.int64))
     hub = deg > hub_threshold
-    equal_rows, hub_max, chunk = 0, 0.0, 1 << 20
+    equal_rows, hub_max, hub_worst, chunk = 0, 0.0, -1, 1 << 20
     for r0 in range(0, n, chunk):
         r1 = min(n, r0 + chunk)
         got = y_dev[r0:r1].cpu().numpy()
@@ -93,10 +93,24 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
         h = hub[r0:r1]
         equal_rows += int(same[~h].sum())
         if h.any():
-            hub_max = max(hub_max, float(np.abs(got[h] - y[r0:r1][h]).max()))
+            diff = np.abs(got[h] - y[r0:r1][h]).max(axis=1)
+            if float(diff.max()) >= hub_max:
+                hub_max, hub_worst = float(diff.max()), r0 + int(np.flatnonzero(h)[int(diff.argmax())])
     checks = {"oracle_rows_compared": int(n), "oracle_nonhub_rows": int((~hub).sum()),
               "oracle_rows_bit_equal": equal_rows, "hub_rows": int(hub.sum()),
               "hub_max_abs_diff_unit_rows": hub_max}
+    if hub_worst >= 0:
+        # the worst split row in the units of the tests' bound: |delta| of the un-normalised sum relative to
+        # sum|terms| (both summation orders — the reference's sequential one too — are within ~n*eps of the exact sum)
+        b0, e0 = int(rowptr[hub_worst]), int(rowptr[hub_worst + 1])
+        terms = edges["left"][b0:e0, None].astype(np.float64) * x[edges["col"][b0:e0]].astype(np.float64)
+        exact = terms.sum(axis=0)
+        got = y_dev[hub_worst].cpu().numpy().astype(np.float64) * np.linalg.norm(exact)
+        ref = y[hub_worst].astype(np.float64) * np.linalg.norm(exact)
+        sabs = np.abs(terms).sum(axis=0)
+        checks.update({"hub_worst_row_edges": e0 - b0,
+                       "hub_worst_gpu_vs_exact_rel_sum_abs_terms": float((np.abs(got - exact) / sabs).max()),
+                       "hub_worst_oracle_vs_exact_rel_sum_abs_terms": float((np.abs(ref - exact) / sabs).max())})
     count, t0 = 0, time.perf_counter()
     while True:
         oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)
@@ -144,6 +158,18 @@ class Launcher:
         return float(t)
 
 
+def placed_pair(block, rows, d, dev, args):
+    """The two iterate buffers, placed by the LIBRARY's search (cleora_alloc_iterates — the same call the product's
+    loops make: cleora_amd/embed.py, cleora_embed), as torch views.  Outside the timed region."""
+    if args.no_placement:
+        return (torch.empty((rows, d), dtype=torch.float32, device=dev), torch.empty((rows, d), dtype=torch.float32, device=dev),
+                {"library_search": False})
+    (a, b), ms = _hip.DevArray.iterates(block, rows, d, 2)
+    return (torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev),
+            {"library_search": True, "untuned_launch_ms": round(ms[0], 3), "chosen_launch_ms": round(ms[1], 3),
+             "note": "one SpMM launch per candidate partner buffer; untuned = the first (plain) allocation pair"})
+
+
 def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, backend, L):
     """W + K iterations of one partition; returns (result dict, x, x_next, iterate, blocks, n_pad)."""
     n, nnz, d = g["n"], g["nnz"], args.dim
@@ -162,8 +188,9 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
             # and writes every row except the hub rows (hub_finish_kernel writes those)
             n_hub = int((dk > blocks[k].info().hub_threshold).sum())
             launch_bytes.append(algorithmic_bytes(int(dk.sum()), (b1 - b0) - n_hub, b1 - b0, d))
-        x = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
-        x_next = torch.zeros_like(x)
+        x, x_next, placement = placed_pair(blocks[0], sg.n_pad, d, dev, args)
+        x.zero_()
+        x_next.zero_()
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
         dl = d
         par = (f"row-block-cyclic x{world} ({sg.balance}-balanced), {steps_per_iter} block(s)/rank/iter"
@@ -179,8 +206,7 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
             dk = deg[r0:r1]
             n_hub = int((dk > blk.info().hub_threshold).sum())
             launch_bytes.append(algorithmic_bytes(int(dk.sum()), (r1 - r0) - n_hub, r1 - r0, dl))
-        x = torch.empty((n, dl), dtype=torch.float32, device=dev)
-        x_next = torch.empty_like(x)
+        x, x_next, placement = placed_pair(blocks[0], n, dl, dev, args)
         rowsq = torch.zeros(n, dtype=torch.float32, device=dev)
         # columns [c0, c0 + dl) of the deterministic init: init_value depends on hash + col + seed only
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, dl, cg.c0, x.data_ptr(), dl, stream))
@@ -214,42 +240,6 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         extra["allgather_ms_per_iter_tried"] = {k: round(v, 3) for k, v in tried.items()}
         extra["allgather"] = best
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
-
-    # ---- placement (outside the timed region; one GPU only) ----------------------------------------
-    # The same launch runs up to 12 % slower when the two ping-pong allocations fall into the same placement
-    # class.  X stays where it is; candidate partners are tried until one is clearly faster.
-    placement = None
-    ncand = max(1, args.placement_candidates)
-    if world == 1 and ncand > 1:
-        src = x.clone()
-
-        def step_time(a, b):
-            a.copy_(src)
-            iterate(a, b)                      # warm
-            a.copy_(src)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            iterate(a, b)
-            e1.record()
-            torch.cuda.synchronize()
-            return e0.elapsed_time(e1)
-
-        tried, spacers = [], []
-        for k in range(ncand):
-            cand = x_next if k == 0 else torch.zeros_like(x)
-            tried.append((step_time(x, cand) + step_time(cand, x), cand))
-            lo, hi = min(t for t, _ in tried), max(t for t, _ in tried)
-            if k >= 1 and lo < 0.95 * hi:
-                break
-            spacers.append(torch.empty(int((0.6 + 0.83 * (k + 1)) * 2 ** 30), dtype=torch.uint8, device=dev))
-        best_t, best = min(tried, key=lambda p: p[0])
-        x_next = best
-        x.copy_(src)
-        placement = {"partners_tried": len(tried), "pair_ms_tried": [round(t / 2, 3) for t, _ in tried],
-                     "untuned_pair_ms": round(tried[0][0] / 2, 3), "chosen_pair_ms": round(best_t / 2, 3)}
-        del tried, spacers, src, best
-        torch.cuda.empty_cache()
 
     a, b = x, x_next
     for _ in range(args.warmup):
@@ -308,8 +298,10 @@ def run_whitened(args, g, x, dev, L, iters):
     n, nnz, d = g["n"], g["nnz"], args.dim
     gr = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(), g["val_left"].data_ptr(),
                                 None, dev.index or 0, keepalive=(g["rowptr"], g["col"], g["val_left"]))
-    prev = x[:n].clone()
-    mid, nxt = torch.empty_like(prev), torch.empty_like(prev)
+    # SpMM output in the first buffer, the two whitened iterates tuned against it (as cleora_amd/embed.py does)
+    (m_, p_, n_), place_ms = _hip.DevArray.iterates(gr, n, d, 3)
+    mid, prev, nxt = (torch.as_tensor(b, device=dev) for b in (m_, p_, n_))
+    prev.copy_(x[:n])
     ws = torch.empty(L.cleora_whiten_workspace(n, d), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -347,6 +339,7 @@ def run_whitened(args, g, x, dev, L, iters):
     cov = torch.cov(prev[: min(n, 2_000_000)].double().T)
     out = {
         "ms_per_iter": el / iters * 1e3, "iterations": iters, "iterations_per_sec": iters / el,
+        "placement_launch_ms": {"untuned": round(place_ms[0], 3), "chosen": round(place_ms[1], 3)},
         "kernels_ms": {"spmm_l2": ms[1] / max(c, 1) + (ms[0] + ms[2]) / max(c, 1), "column_statistics": stats_ms,
                        "gram_f64_mfma": gram_ms, "eigensolver_transform": eigh_ms, "project_f32_mfma": proj_ms},
         "gram_roofline": {"bound": "mfma", "dtype": "f64", "achieved": gram_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else 0.0,
@@ -380,9 +373,8 @@ def main():
                          "iteration); both (default) measures the two and reports the faster as `value`")
     ap.add_argument("--balance", default="auto", choices=["auto", "rows", "nnz"],
                     help="row partition: equal row counts, or balanced on the rowptr prefix sum")
-    ap.add_argument("--placement-candidates", type=int, default=8,
-                    help="before the timed region, try up to this many allocations as the partner buffer of X "
-                         "and keep the fastest ping-pong pair (1 = no tuning); DESIGN.md §3.1")
+    ap.add_argument("--no-placement", action="store_true",
+                    help="plain allocations for the iterates instead of cleora_alloc_iterates (DESIGN.md §3.1)")
     ap.add_argument("--whiten-iters", type=int, default=8, help="iterations of the whitened default loop (N = 1); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--watchdog", type=int, default=1500, help="seconds before every thread's traceback is dumped and the run exits")
@@ -417,7 +409,16 @@ def main():
         comm = comm_mod.LocalComm()
 
     d = args.dim
-    g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)  # same seed on every rank
+    if args.share_gpu and world > 1:
+        # developer mode: FOUR processes building the graph at once on ONE GPU (torch sort / unique / mask-index) stalled
+        # for minutes before any collective ran (round 1's "hang"; tracebacks in gpurun_out/r02a/share4.log) — take turns
+        for r in range(world):
+            if r == rank:
+                g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        g = synth.power_law_graph(args.nodes, args.pairs, 2, dev)  # same seed on every rank
     n, nnz = g["n"], g["nnz"]
     deg = torch.diff(g["rowptr"])
     hashes = synth.entity_hashes(n, 0, dev)

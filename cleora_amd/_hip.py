@@ -67,6 +67,7 @@ SIGNATURES = {
     "cleora_graph_set_hot_cache": (c_int, [vp, c_i64]),
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
+    "cleora_alloc_iterates": (c_int, [vp, c_u32, c_u32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double * 2)]),
     "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_propagate_vals_dev": (c_int, [vp, vp, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_edge_attention_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, c_f32, vp, vp]),
@@ -252,13 +253,25 @@ class DevArray:
     """A device buffer shaped like a numpy array (hipMalloc through the C ABI).  Lets hosts
     without torch keep matrices resident in HBM across calls."""
 
-    def __init__(self, shape, dtype):
+    def __init__(self, shape, dtype, _ptr=None):
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        if _ptr is not None:
+            self.ptr = _ptr
+            return
         p = vp()
         check(lib().cleora_malloc(self.nbytes, ctypes.byref(p)))
         self.ptr = p
+
+    @classmethod
+    def iterates(cls, graph, rows, d, count):
+        """`count` (rows, d) f32 buffers placed for the SpMM of `graph` (cleora_alloc_iterates): every SpMM of the
+        loop should read or write the FIRST one.  Returns (list of DevArray, (first-candidate ms, chosen ms))."""
+        bufs = (vp * count)()
+        ms = (ctypes.c_double * 2)()
+        check(lib().cleora_alloc_iterates(graph.handle, int(d), int(count), bufs, ctypes.byref(ms)))
+        return [cls((rows, d), np.float32, _ptr=vp(bufs[i])) for i in range(count)], (ms[0], ms[1])
 
     @classmethod
     def from_host(cls, a):
@@ -276,6 +289,12 @@ class DevArray:
 
     def offset(self, nbytes):
         return vp(self.ptr.value + int(nbytes))
+
+    @property
+    def __cuda_array_interface__(self):
+        """Lets torch.as_tensor(dev_array, device=...) view the buffer without a copy (the tensor keeps this object,
+        and with it the allocation, alive)."""
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr.value or 0), False), "version": 2}
 
     def free(self):
         if self.ptr:

@@ -110,7 +110,8 @@ int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const fl
 // whiten.hip
 uint64_t gram_workspace(uint64_t n, uint32_t d);
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
-                double *ws, double *gram, hipStream_t stream);
+                double *ws, double *gram, hipStream_t stream, double *mean_out64 = nullptr,
+                float *mean_out32 = nullptr);   // outputs given: `mean` is only a shift, the exact mean is produced
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
 

@@ -12,6 +12,8 @@
 //     as the reference's sgemm; summation order differs, tolerance documented in the tests).
 //
 // Both are MFMA-bound (2 n d^2 flops against 1-3 passes over X), unlike the SpMM.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cleora {
@@ -35,7 +37,8 @@ struct GramArgs {
     uint64_t ldx;
     uint64_t n;
     uint32_t d;
-    const double *mean;
+    const double *mean;     // centring vector: the exact mean (two-pass form) or a nearby shift (one-pass form)
+    double *colsum;         // [s_diag][tiles * GT]: per-slice column sums of (x - mean), written by the DIAG blocks
     double *partial;        // [slices][pairs][GT][GT]
     uint32_t tiles;         // ceil(d / GT)
     uint32_t pairs;         // tiles (tiles + 1) / 2
@@ -114,6 +117,7 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
     float4 pa[2], pb[2];
     bool ok[2];
     pb[0] = pb[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};   // DIAG: this thread's share of sum_r (x[r, colA + q] - mean): every row once
     auto prefetch = [&](uint64_t row0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -135,6 +139,7 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
             for (int q = 0; q < 4; ++q) {
                 // centre in f64: block.astype(float64) - mean          (pycleora/__init__.py:141)
                 da[q] = (ok[h] && colA + q < a.d) ? (double)va[q] - mA[q] : 0.0;
+                if constexpr (DIAG) cs[q] += da[q];
                 if constexpr (!DIAG) db[q] = (ok[h] && colB + q < a.d) ? (double)vb[q] - mB[q] : 0.0;
             }
         }
@@ -181,6 +186,21 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
         __syncthreads();
     }
 
+    if constexpr (DIAG) {
+        // column sums of the centred panel: the 8 row groups (lr) of a column are added in order through LDS
+        // (the main loop ended on a barrier, so the staging buffers are free)
+        double *red = &lds[0][0][0][0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[lr * GT + c4 * 4 + q] = cs[q];
+        __syncthreads();
+        if (t < GT) {
+            double sum = red[t];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) sum += red[g * GT + t];
+            a.colsum[(uint64_t)blockIdx.y * a.tiles * GT + bi * GT + t] = sum;
+        }
+    }
+
     double *out = a.partial + ((uint64_t)blockIdx.y * a.pairs + pair) * (uint64_t)(GT * GT);
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
@@ -215,10 +235,29 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
     gram_body<DIAG>(a, lds, bi, bj, pair_index(bi, bj, a.tiles));
 }
 
+// One-pass form: the Gram was centred with a shift c near the mean.  delta = sum_r (x_r - c) / n (slices added in
+// order), mean = c + delta (pycleora/__init__.py:136), mean32 = (float)mean (:159).
+__global__ __launch_bounds__(256) void gram_mean_kernel(const double *__restrict__ colsum, uint32_t s_diag,
+                                                        uint32_t tiles, uint32_t d, uint64_t n,
+                                                        const double *__restrict__ shift, double *__restrict__ delta,
+                                                        double *__restrict__ mean64, float *__restrict__ mean32) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0;
+    for (uint32_t sl = 0; sl < s_diag; ++sl) s += colsum[(uint64_t)sl * tiles * GT + c];
+    const double dl = s / (double)n;
+    delta[c] = dl;
+    const double m = shift[c] + dl;
+    mean64[c] = m;
+    mean32[c] = (float)m;
+}
+
 // gram[gi][gj] = sum over slices (fixed order) of the partial tiles; mirrors the upper triangle.
+// delta != nullptr: sum_r (x-c)(x-c)^T - n delta delta^T = sum_r (x-mu)(x-mu)^T  (exact identity, mu = c + delta).
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restrict__ partial,
                                                           uint32_t s_diag, uint32_t s_off,
                                                           uint32_t pairs, uint32_t tiles, uint32_t d,
+                                                          const double *__restrict__ delta, double n_rows,
                                                           double *__restrict__ gram) {
     const uint32_t p = blockIdx.y;
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;  // element of the GT x GT tile
@@ -233,6 +272,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
     double s = 0.0;
     for (uint32_t sl = 0; sl < slices; ++sl)
         s += partial[((uint64_t)sl * pairs + p) * (uint64_t)(GT * GT) + e];
+    if (delta) s -= n_rows * delta[gi] * delta[gj];
     gram[(uint64_t)gi * d + gj] = s;
     if (!diag || (r / 16) < (c / 16)) gram[(uint64_t)gj * d + gi] = s;
 }
@@ -375,20 +415,158 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// projection, second form: the X tile lives in LDS for the whole block, T comes straight from L2
+// ---------------------------------------------------------------------------------------------
+// For d <= 512 a block owns RM rows of X and keeps them — centred, all d columns — in LDS (each row is read from HBM
+// exactly once, as whole 1 KiB lines), while the transform is streamed from L2 into registers in the exact order the
+// MFMA fragments need it.  No barrier in the main loop, no LDS traffic for T:
+//   * T is repacked once per call (pack_transform_kernel, d*k floats) into fragment order: for k-group g (8 values of
+//     the reduction index), 32-column tile j and lane l = (n, h): Tp[((g*tiles + j)*64 + l)*4 + q] = T[8g + 4h + q][32j + n],
+//     so one global_load_dwordx4 per wave = one contiguous 1 KiB = the B fragments of FOUR consecutive MFMAs;
+//   * the A fragments of the same four MFMAs are one ds_read_b128: lane (i, h) reads X_lds[row i][8g + 4h .. +3]
+//     (row stride d + 4 floats: the 16 lanes of a ds_read_b128 group land on all 64 banks);
+//   * MFMA q of group g therefore multiplies the k pair (8g + q, 8g + 4 + q): a fixed, documented summation order
+//     (f32 fma chain) — not numpy's sgemm order either; same tolerance as the first form.
+// Two 256-thread blocks per CU (LDS 2 x 66.5 KiB at d = 256): one block's prologue / epilogue runs under the other's MFMAs.
+constexpr int RM = 64;   // rows per block
+
+template <int WN>   // 32-column tiles per wave (2: the wave owns 64 output columns)
+__global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, const float *__restrict__ tp,
+                                                              uint32_t col_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];       // [RM][d + 4]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t d = a.d, lds = d + 4;
+    const uint64_t m0 = (uint64_t)blockIdx.x * RM;
+    const uint32_t n0 = (blockIdx.y * 4 + w) * (WN * 32);            // first output column of this wave
+
+    // ---- prologue: RM rows x d columns, centred in f32 (pycleora/__init__.py:161), one wave per row -----------------
+    {
+        const uint32_t c = (uint32_t)lane * 4;
+        for (uint32_t c0 = 0; c0 < d; c0 += 256) {
+            float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + c < d) mu = *reinterpret_cast<const float4 *>(a.mean + c0 + c);
+            for (int r = w; r < RM; r += 4 * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t row = m0 + r + 4 * u;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < a.n && c0 + c < d && r + 4 * u < RM) v[u] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + c0 + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t row = m0 + r + 4 * u;
+                    if (c0 + c < d && r + 4 * u < RM) {
+                        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row < a.n) o = make_float4(__fsub_rn(v[u].x, mu.x), __fsub_rn(v[u].y, mu.y), __fsub_rn(v[u].z, mu.z), __fsub_rn(v[u].w, mu.w));
+                        *reinterpret_cast<float4 *>(&xs[(r + 4 * u) * lds + c0 + c]) = o;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (n0 >= a.k) return;                                             // (after the barrier: this wave has no columns)
+
+    f16v acc[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t groups = d / 8;
+    const uint32_t jt0 = n0 / 32;
+    const float *ap = xs + (lane & 31) * lds + 4 * (lane >> 5);        // + 32*i*lds + 8*g
+    const float *bp = tp + ((uint64_t)jt0 * 64 + lane) * 4;            // + (g*col_tiles + j)*256
+    constexpr int PF = 4;                                              // groups of B in flight
+    float4 bq[PF][WN];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+            bq[p][j] = (uint32_t)p < groups && jt0 + j < col_tiles
+                           ? *reinterpret_cast<const float4 *>(bp + ((uint64_t)p * col_tiles + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (uint32_t g0 = 0; g0 < groups; g0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const uint32_t g = g0 + p;
+            if (g >= groups) break;
+            float4 af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4 *>(ap + 32 * i * lds + 8 * g);
+            float4 bf[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                bf[j] = bq[p][j];
+                const uint32_t gn = g + PF;                            // refill this slot for PF groups ahead
+                bq[p][j] = gn < groups && jt0 + j < col_tiles
+                               ? *reinterpret_cast<const float4 *>(bp + ((uint64_t)gn * col_tiles + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const float a4[2][4] = {{af[0].x, af[0].y, af[0].z, af[0].w}, {af[1].x, af[1].y, af[1].z, af[1].w}};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float b = q == 0 ? bf[j].x : q == 1 ? bf[j].y : q == 2 ? bf[j].z : bf[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][q], b, acc[i][j], 0, 0, 0);
+                    }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                const uint64_t row = m0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+                const uint32_t col = n0 + j * 32 + (lane & 31);
+                if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[i][j][reg];
+            }
+}
+
+// T (d x k row-major) -> fragment order, zero-padded to whole 32-column tiles.
+__global__ __launch_bounds__(256) void pack_transform_kernel(const float *__restrict__ t, uint32_t d, uint32_t k,
+                                                             uint32_t col_tiles, float *__restrict__ tp) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;     // one float4 of the packed array
+    const uint64_t total = (uint64_t)(d / 8) * col_tiles * 64;
+    if (idx >= total) return;
+    const uint32_t lane = (uint32_t)(idx & 63);
+    const uint32_t j = (uint32_t)((idx >> 6) % col_tiles), g = (uint32_t)((idx >> 6) / col_tiles);
+    const uint32_t n = j * 32 + (lane & 31), k0 = 8 * g + 4 * (lane >> 5);
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = n < k ? t[(uint64_t)(k0 + q) * k + n] : 0.f;
+    reinterpret_cast<float4 *>(tp)[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 }  // namespace
 
 uint64_t gram_workspace(uint64_t n, uint32_t d) {
     const GramPlan p = gram_plan(n, d);
-    return (uint64_t)p.s_max * p.pairs * GT * GT;
+    // tile partials, per-slice column sums of the diagonal blocks, delta
+    return (uint64_t)p.s_max * p.pairs * GT * GT + (uint64_t)p.s_diag * p.tiles * GT + (uint64_t)p.tiles * GT;
 }
 
+// mean_out64 / mean_out32 == nullptr: `mean` is the exact mean (two-pass form, pycleora/__init__.py:136-143 literally).
+// Otherwise `mean` is a shift near the mean; the exact mean comes out of the same pass over X (gram_mean_kernel).
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
-                double *ws, double *gram, hipStream_t stream) {
+                double *ws, double *gram, hipStream_t stream, double *mean_out64, float *mean_out32) {
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && mean != nullptr && ws != nullptr && gram != nullptr,
                "x / mean / workspace / gram is NULL");
+    CL_REQUIRE((mean_out64 == nullptr) == (mean_out32 == nullptr), "mean outputs come in pairs");
     const GramPlan p = gram_plan(n, d);
     GramArgs a{};
+    a.colsum = ws + (uint64_t)p.s_max * p.pairs * GT * GT;
+    double *delta = a.colsum + (uint64_t)p.s_diag * p.tiles * GT;
     a.x = x;
     a.ldx = ldx;
     a.n = n;
@@ -411,8 +589,11 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
         a.rows_per_slice = rows_per_slice(p.s_off);
         hipLaunchKernelGGL(gram_kernel<false>, dim3(p.pairs - p.tiles, p.s_off), dim3(256), 0, stream, a);
     }
+    if (mean_out64)
+        hipLaunchKernelGGL(gram_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, a.colsum, p.s_diag, p.tiles, d, n,
+                           mean, delta, mean_out64, mean_out32);
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(GT * GT / 256, p.pairs), dim3(256), 0, stream, ws,
-                       p.s_diag, p.s_off, p.pairs, p.tiles, d, gram);
+                       p.s_diag, p.s_off, p.pairs, p.tiles, d, mean_out64 ? delta : nullptr, (double)n, gram);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }
@@ -437,6 +618,31 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.nb_n = (k + PN - 1) / PN;
     a.w4x = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
     a.w4t = (k % 4 == 0) && aligned16(t);
+    // rows-in-LDS form: whole rows as float4, reduction index in groups of 8, the X tile within the LDS budget
+    static const bool first_form_only = std::getenv("CLEORA_PROJECT_TILED") != nullptr;   // A/B switch for profiling
+    if (!first_form_only && a.w4x && d % 8 == 0 && d <= 512 && aligned16(mean) && n >= 4 * RM) {
+        const uint32_t col_tiles = (k + 31) / 32;
+        const uint64_t packed = (uint64_t)(d / 8) * col_tiles * 64 * 4;     // floats
+        float *tp = nullptr;
+        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), packed * sizeof(float), stream));
+        hipLaunchKernelGGL(pack_transform_kernel, dim3((unsigned)((packed / 4 + 255) / 256)), dim3(256), 0, stream, t, d, k,
+                           col_tiles, tp);
+        const size_t lds_bytes = (size_t)RM * (d + 4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(project_rows_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const uint64_t row_blocks = (n + RM - 1) / RM;
+        CL_REQUIRE(row_blocks < (1ull << 31), "internal: too many row blocks");
+        hipLaunchKernelGGL(project_rows_kernel<2>, dim3((unsigned)row_blocks, (col_tiles + 7) / 8), dim3(256), lds_bytes,
+                           stream, a, tp, col_tiles);
+        const hipError_t le = hipGetLastError();
+        CL_HIP(hipFreeAsync(tp, stream));
+        CL_HIP(le);
+        return CLEORA_OK;
+    }
     const uint64_t blocks = ((n + PM - 1) / PM) * a.nb_n;
     a.n_blocks = blocks;
     hipLaunchKernelGGL(project_kernel, grid_1d_as_2d(blocks), dim3(256), 0, stream, a);

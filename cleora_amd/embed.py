@@ -174,10 +174,12 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
     values are recomputed from the current iterate (embed_with_attention)."""
     L = _hip.lib()
     d = x0.shape[1]
-    cur = _hip.DevArray.from_host(x0)
-    nxt = _hip.DevArray((n, d), np.float32)
-    wht = _hip.DevArray((n, d), np.float32) if whiten else None
     whitener = DeviceWhitener(n, d) if (whiten and n > 1) else None
+    # iterate buffers placed for the SpMM (cleora_alloc_iterates): the SpMM always WRITES `nxt` and reads `cur` — which
+    # is, in turn, each of the other buffers — so `nxt` is the buffer the partners are tuned against
+    (nxt, cur, *rest), _ = _hip.DevArray.iterates(g, n, d, 3 if whitener is not None else 2)
+    wht = rest[0] if rest else None
+    _hip.check(L.cleora_memcpy_h2d(cur.ptr, _hip.ptr(x0), cur.nbytes, None))
     check = convergence_threshold > 0
     sq = _hip.DevArray((n,), np.float64) if check else None
     ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None

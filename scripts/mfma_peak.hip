@@ -46,6 +46,43 @@ __global__ __launch_bounds__(256) void k_f32(float *out, int iters, float a0, fl
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// f64 VALU FMA ceiling (v_fma_f64): NACC independent chains per lane
+template <int NACC>
+__global__ __launch_bounds__(256) void k_valu64(double *out, int iters, double a0, double b0) {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = threadIdx.x * 1e-3 + i;
+    const double a = a0 + threadIdx.x * 1e-9, b = b0 * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// effective shader clock under a given load: s_memtime ticks per 100 MHz wall-clock tick, sampled by one wave
+template <int NACC>
+__global__ __launch_bounds__(256) void k_f64_clock(double *out, int iters, double a0, double b0, unsigned long long *ticks) {
+    d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4){0, 0, 0, 0};
+    double a = a0 + threadIdx.x * 1e-9, b = b0;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = w1 - w0; }
+}
+
 template <class K, class T>
 double run(K kernel, int blocks, int iters, T *out, T a, T b) {
     hipEvent_t e0, e1;
@@ -89,6 +126,26 @@ int main() {
             printf("f32 32x32x2  %d wave(s)/SIMD: %8.3f ms  %7.2f TFLOP/s   (%.0f cycles/instr/SIMD at 2.4 GHz)\n", bpc, ms, tf,
                    ms * 1e-3 * 2.4e9 / (mf / (cus * 4.0)));
         }
+    }
+    // more waves per SIMD and other accumulator counts for the f64 matrix instruction; the f64 vector FMA beside it
+    for (int bpc : {1, 2, 4}) {
+        const int blocks = cus * bpc;
+        const double ms16 = run(k_f64<16>, blocks, iters / 2, (double *)buf, 1.0, 0.5);
+        const double ms4 = run(k_f64<4>, blocks, iters * 2, (double *)buf, 1.0, 0.5);
+        const double mf = (double)blocks * 4 * iters * 8;
+        printf("f64 16x16x4  %d wave(s)/SIMD: 16 accumulators %7.2f TFLOP/s   4 accumulators %7.2f TFLOP/s\n", bpc,
+               mf * 2048.0 / (ms16 * 1e-3) / 1e12, mf * 2048.0 / (ms4 * 1e-3) / 1e12);
+        const double msv = run(k_valu64<16>, blocks, iters * 4, (double *)buf, 1.0000001, 0.5);
+        printf("f64 v_fma    %d wave(s)/SIMD: %7.2f TFLOP/s\n", bpc, (double)blocks * 256 * iters * 4 * 16 * 2.0 / (msv * 1e-3) / 1e12);
+    }
+    unsigned long long *ticks;
+    hipMalloc(&ticks, 16);
+    for (int bpc : {1, 2}) {
+        hipLaunchKernelGGL(k_f64_clock<8>, dim3(cus * bpc), dim3(256), 0, 0, (double *)buf, iters, 1.0, 0.5, ticks);
+        unsigned long long h[2];
+        hipMemcpy(h, ticks, 16, hipMemcpyDeviceToHost);
+        printf("f64 16x16x4  %d wave(s)/SIMD: %.1f s_memtime ticks per MFMA per wave, %.3f ticks per 10 ns of wall clock\n", bpc,
+               (double)h[0] / ((double)iters * 8), (double)h[0] / (double)h[1]);
     }
     hipFree(buf);
     return 0;

@@ -143,13 +143,23 @@ def test_whiten_dev_matches_host_statistics_route(n, d, k):
     x = case_input(3 * n + d, n, d)
     dx = _hip.DevArray.from_host(x)
     kk = d if k is None else k
-    outs = []
-    for route in ("library", "host"):
-        w = dev_embed.DeviceWhitener(n, d, eigh=route)
-        out = _hip.DevArray((n, kk), np.float32)
-        assert w.whiten(dx.ptr, d, out.ptr, kk, k) == kk
-        _hip.check(_hip.lib().cleora_stream_sync(None))
-        outs.append((out.to_host(), w.last_eigenvalues))
+    L = _hip.lib()
+    w = dev_embed.DeviceWhitener(n, d)
+    out = _hip.DevArray((n, kk), np.float32)
+    assert w.whiten(dx.ptr, d, out.ptr, kk, k) == kk
+    _hip.check(L.cleora_stream_sync(None))
+    outs = [(out.to_host(), w.last_eigenvalues)]
+    # the host-statistics route, assembled here from the public pieces: device mean / covariance, numpy's LAPACK
+    # eigh (the routine the reference itself calls, pycleora/__init__.py:145), device projection
+    mean, cov = w.stats(dx.ptr, d)
+    ev, evec = np.linalg.eigh(cov)
+    idx = np.argsort(ev)[::-1][:kk]
+    transform = np.ascontiguousarray((evec[:, idx] / np.sqrt(np.maximum(ev[idx], 1e-10))).astype(np.float32))
+    dt, dm = _hip.DevArray.from_host(transform), _hip.DevArray.from_host(mean.astype(np.float32))
+    out2 = _hip.DevArray((n, kk), np.float32)
+    _hip.check(L.cleora_project_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, kk, out2.ptr, kk, None))
+    _hip.check(L.cleora_stream_sync(None))
+    outs.append((out2.to_host(), ev[np.argsort(ev)[::-1]]))
     (a, wa), (b, wb) = outs
     assert np.abs(wa[:kk] - wb[:kk]).max() <= 1e-10 * max(wb[0], 1e-300)
     if n > d:        # full-rank covariance: columns are defined up to sign

@@ -142,6 +142,8 @@ void free_graph(cleora_graph *g) {
     (void)hipFree(g->seg_begin);
     (void)hipFree(g->hub_partial);
     (void)hipFree(g->col_hot);
+    (void)hipFree(g->io_buf[0]);
+    (void)hipFree(g->io_buf[1]);
     for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : g->ev_used) (void)hipEventDestroy(e);
     delete g;
@@ -182,16 +184,16 @@ int cleora_free(void *dev_ptr) {
     return CLEORA_OK;
 }
 
+// (synchronous with respect to the host; ordered after the work already enqueued on `stream`; pageable host memory
+// goes through the pinned pipeline of stager.hip)
 int cleora_memcpy_h2d(void *dst, const void *src, uint64_t bytes, void *stream) {
-    CL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(stream)));
-    CL_HIP(hipStreamSynchronize(S(stream)));
-    return CLEORA_OK;
+    CL_REQUIRE((dst != nullptr && src != nullptr) || bytes == 0, "dst / src is NULL");
+    return staged_h2d(dst, src, bytes, S(stream));
 }
 
 int cleora_memcpy_d2h(void *dst, const void *src, uint64_t bytes, void *stream) {
-    CL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(stream)));
-    CL_HIP(hipStreamSynchronize(S(stream)));
-    return CLEORA_OK;
+    CL_REQUIRE((dst != nullptr && src != nullptr) || bytes == 0, "dst / src is NULL");
+    return staged_d2h(dst, src, bytes, S(stream));
 }
 
 int cleora_memcpy_d2d(void *dst, const void *src, uint64_t bytes, void *stream) {
@@ -241,7 +243,10 @@ int cleora_graph_create(int device, uint64_t n_rows, uint64_t n_cols, uint64_t n
         void *p = nullptr;
         CL_HIP(hipMalloc(&p, bytes ? bytes : 1));
         *dst = static_cast<std::remove_reference_t<decltype(**dst)> *>(p);
-        if (bytes) CL_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        if (bytes) {
+            const int r = staged_h2d(p, src, bytes, nullptr);
+            if (r != CLEORA_OK) return r;
+        }
         g->device_bytes += bytes;
         return CLEORA_OK;
     };
@@ -567,16 +572,24 @@ int cleora_propagate(const cleora_graph *g, int markov_type, const float *x_host
     CL_REQUIRE(x_host != nullptr && y_host != nullptr, "x / y is NULL");
     CL_REQUIRE(d > 0, "d must be positive");
     CL_HIP(hipSetDevice(g->device));
-    DevBuf x, y;
+    // This is what the reference's unmodified embed() calls once per iteration: no allocation per call (the device
+    // staging buffers stay with the handle) and both copies through the pinned pipeline of stager.hip.
+    std::lock_guard<std::mutex> io(g->io_mu);
+    const uint64_t need[2] = {g->n_cols * (uint64_t)d * sizeof(float), g->n_rows * (uint64_t)d * sizeof(float)};
+    for (int k = 0; k < 2; ++k) {
+        if (g->io_bytes[k] >= need[k] && g->io_buf[k]) continue;
+        if (g->io_buf[k]) CL_HIP(hipFree(g->io_buf[k]));
+        g->io_buf[k] = nullptr;
+        g->io_bytes[k] = 0;
+        CL_HIP(hipMalloc(&g->io_buf[k], need[k] ? need[k] : 1));
+        g->io_bytes[k] = need[k];
+    }
     int rc;
-    const uint64_t xb = g->n_cols * (uint64_t)d * sizeof(float), yb = g->n_rows * (uint64_t)d * sizeof(float);
-    if ((rc = x.alloc(xb)) != CLEORA_OK || (rc = y.alloc(yb)) != CLEORA_OK) return rc;
-    CL_HIP(hipMemcpy(x.p, x_host, xb, hipMemcpyHostToDevice));
-    rc = launch_propagate(g, markov_type, x.as<float>(), d, d, y.as<float>(), d, 0, 0.f, nullptr,
-                          nullptr, nullptr, nullptr);
+    if ((rc = staged_h2d(g->io_buf[0], x_host, need[0], nullptr)) != CLEORA_OK) return rc;
+    rc = launch_propagate(g, markov_type, static_cast<const float *>(g->io_buf[0]), d, d, static_cast<float *>(g->io_buf[1]), d, 0,
+                          0.f, nullptr, nullptr, nullptr, nullptr);
     if (rc != CLEORA_OK) return rc;
-    CL_HIP(hipMemcpy(y_host, y.p, yb, hipMemcpyDeviceToHost));
-    return CLEORA_OK;
+    return staged_d2h(y_host, g->io_buf[1], need[1], nullptr);
 }
 
 int cleora_l2_normalize(const float *x_host, uint64_t n, uint32_t d, float *y_host) {
@@ -587,12 +600,11 @@ int cleora_l2_normalize(const float *x_host, uint64_t n, uint32_t d, float *y_ho
     DevBuf x;
     const uint64_t bytes = n * (uint64_t)d * sizeof(float);
     if ((rc = x.alloc(bytes)) != CLEORA_OK) return rc;
-    CL_HIP(hipMemcpy(x.p, x_host, bytes, hipMemcpyHostToDevice));
+    if ((rc = staged_h2d(x.p, x_host, bytes, nullptr)) != CLEORA_OK) return rc;
     rc = launch_rowops(x.as<float>(), d, n, d, x.as<float>(), d, CLEORA_F_L2NORM, 0.f, nullptr,
                        nullptr, nullptr, nullptr);
     if (rc != CLEORA_OK) return rc;
-    CL_HIP(hipMemcpy(y_host, x.p, bytes, hipMemcpyDeviceToHost));
-    return CLEORA_OK;
+    return staged_d2h(y_host, x.p, bytes, nullptr);
 }
 
 int cleora_init(const uint64_t *entity_hash_host, uint64_t n, uint32_t d, int64_t seed,
@@ -607,8 +619,7 @@ int cleora_init(const uint64_t *entity_hash_host, uint64_t n, uint32_t d, int64_
     CL_HIP(hipMemcpy(h.p, entity_hash_host, n * sizeof(uint64_t), hipMemcpyHostToDevice));
     rc = launch_init(h.as<uint64_t>(), n, d, seed, x.as<float>(), d, nullptr);
     if (rc != CLEORA_OK) return rc;
-    CL_HIP(hipMemcpy(x_host, x.p, bytes, hipMemcpyDeviceToHost));
-    return CLEORA_OK;
+    return staged_d2h(x_host, x.p, bytes, nullptr);
 }
 
 int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_components, float *y_host) {
@@ -623,9 +634,9 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
         (rc = y.alloc(n * (uint64_t)k * sizeof(float))) != CLEORA_OK ||
         (rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK)
         return rc;
-    CL_HIP(hipMemcpy(x.p, x_host, n * (uint64_t)d * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = staged_h2d(x.p, x_host, n * (uint64_t)d * sizeof(float), nullptr)) != CLEORA_OK) return rc;
     if ((rc = launch_whiten(x.as<float>(), d, n, d, k, y.as<float>(), k, ws.p, nullptr, nullptr)) != CLEORA_OK) return rc;
-    CL_HIP(hipMemcpy(y_host, y.p, n * (uint64_t)k * sizeof(float), hipMemcpyDeviceToHost));
+    if ((rc = staged_d2h(y_host, y.p, n * (uint64_t)k * sizeof(float), nullptr)) != CLEORA_OK) return rc;
     if (n > 1) {
         int info = 0;
         CL_HIP(hipMemcpy(&info, whiten_info(ws.p, n, d), sizeof(int), hipMemcpyDeviceToHost));
@@ -718,7 +729,7 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
         return rc;
     }
     if (x0_host) {
-        CL_HIP(hipMemcpy(a.p, x0_host, bytes, hipMemcpyHostToDevice));
+        if ((rc = staged_h2d(a.p, x0_host, bytes, nullptr)) != CLEORA_OK) return rc;
     } else {
         if ((rc = h.alloc(n * sizeof(uint64_t))) != CLEORA_OK) return rc;
         CL_HIP(hipMemcpy(h.p, entity_hash_host, n * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -729,8 +740,7 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
         rc = embed_whitened(g, a.as<float>(), b.as<float>(), c.as<float>(), markov_type, d, max_iterations,
                             residual_weight, convergence_threshold, flags, &result, iterations_run);
         if (rc != CLEORA_OK) return rc;
-        CL_HIP(hipMemcpy(out_host, result, bytes, hipMemcpyDeviceToHost));
-        return CLEORA_OK;
+        return staged_d2h(out_host, result, bytes, nullptr);
     }
     if (check) {
         if ((rc = sq.alloc(n * sizeof(double))) != CLEORA_OK ||
@@ -831,9 +841,8 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
             dst = partner;
         }
     }
-    CL_HIP(hipMemcpy(out_host, src, bytes, hipMemcpyDeviceToHost));
     if (iterations_run) *iterations_run = actual;
-    return CLEORA_OK;
+    return staged_d2h(out_host, src, bytes, nullptr);
 }
 
 }  // extern "C"

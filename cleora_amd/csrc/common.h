@@ -78,6 +78,11 @@ struct cleora_graph {
     mutable bool hot_failed = false;        // building the marks failed once (e.g. out of memory): policy stays off
     mutable uint32_t auto_launches = 0;     // automatic mode arms itself on the third eligible launch
 
+    // device staging of the host-pointer entry points (cleora_propagate): kept between calls, grow-only
+    mutable std::mutex io_mu;
+    mutable void *io_buf[2] = {nullptr, nullptr};
+    mutable uint64_t io_bytes[2] = {0, 0};
+
     // optional per-kernel timing (cleora_graph_set_timing): 4 events per propagate call,
     // recorded on the launch stream: [hub_partial | rows | hub_finish]
     mutable bool timing = false;
@@ -114,6 +119,10 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
                 float *mean_out32 = nullptr);   // outputs given: `mean` is only a shift, the exact mean is produced
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
+
+// stager.hip: pageable host memory <-> device through a pinned ring, at PCIe speed
+int staged_h2d(void *dst_dev, const void *src_host, uint64_t bytes, hipStream_t after);
+int staged_d2h(void *dst_host, const void *src_dev, uint64_t bytes, hipStream_t after);
 
 // attention.hip
 int launch_edge_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,

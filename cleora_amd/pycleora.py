@@ -39,7 +39,7 @@ def _as_f32_matrix(x, name="x"):
 
 
 class SparseMatrix:
-    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_lock", "_bufs", "_lookup", "__weakref__")
+    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_lock", "_lookup", "__weakref__")
 
     # ---- construction -------------------------------------------------------------------------
     def __new__(cls, *args):
@@ -56,7 +56,6 @@ class SparseMatrix:
         self._ids = None
         self._dev_graph = None
         self._lock = threading.Lock()
-        self._bufs = {}
         self._lookup = {}       # id -> index tables, built on first use
 
     @classmethod
@@ -103,21 +102,6 @@ class SparseMatrix:
                                                    device=_device_index())
         return self._dev_graph
 
-    def _buf(self, key, shape, dtype=np.float32):
-        b = self._bufs.get(key)
-        if b is None or b.shape != tuple(shape) or b.dtype != np.dtype(dtype):
-            if b is not None:
-                b.free()
-            b = _hip.DevArray(shape, dtype)
-            self._bufs[key] = b
-        return b
-
-    def _upload(self, key, a):
-        b = self._buf(key, a.shape, a.dtype)
-        if b.nbytes:
-            _hip.check(_hip.lib().cleora_memcpy_h2d(b.ptr, _hip.ptr(a), b.nbytes, None))
-        return b
-
     # ---- propagation (src/lib.rs:29-47, 86-102) --------------------------------------------------
     def _markov_propagate(self, x, kind):
         x = _as_f32_matrix(x)
@@ -127,13 +111,12 @@ class SparseMatrix:
         d = x.shape[1]
         if n == 0 or d == 0:
             return np.zeros((n, d), np.float32)
+        out = np.empty((n, d), np.float32)
         with self._lock:
-            g = self._graph()
-            dx = self._upload("x", x)
-            dy = self._buf("y", (n, d))
-            _hip.check(_hip.lib().cleora_propagate_dev(g.handle, kind, dx.ptr, d, d, dy.ptr, d, 0, 0.0,
-                                                       None, None, None, None))
-            return dy.to_host()
+            # the host-pointer entry point: device staging buffers live with the graph handle, both copies run
+            # through the pinned pipeline of csrc/stager.hip (what a Rust host's FFI call would do)
+            _hip.check(_hip.lib().cleora_propagate(self._graph().handle, kind, _hip.ptr(x), d, _hip.ptr(out)))
+        return out
 
     def left_markov_propagate(self, x, num_workers=None):
         return self._markov_propagate(x, _hip.LEFT)

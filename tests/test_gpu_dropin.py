@@ -242,3 +242,27 @@ def test_concurrent_calls_from_several_threads(karate):
     for got, want in zip(results, serial):
         for a, b in zip(got, want):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("nbytes", [1, 4095, (4 << 20) - 4, (4 << 20) + 4, (32 << 20) * 3 + 12345, (32 << 20) * 6])
+def test_staged_host_copies_round_trip_bit_exact(nbytes):
+    """Host-pointer entry points move pageable memory through a pinned ring with worker threads (csrc/stager.hip):
+    every size class — plain copy below 4 MiB, partial chunks, more chunks than ring slots — round-trips bit for bit."""
+    L = _hip.lib()
+    rng = np.random.default_rng(nbytes)
+    src = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    dev = _hip.DevArray((nbytes,), np.uint8)
+    _hip.check(L.cleora_memcpy_h2d(dev.ptr, _hip.ptr(src), nbytes, None))
+    back = np.zeros(nbytes, np.uint8)
+    _hip.check(L.cleora_memcpy_d2h(_hip.ptr(back), dev.ptr, nbytes, None))
+    np.testing.assert_array_equal(back, src)
+
+
+def test_host_pointer_propagate_reuses_device_staging(karate):
+    """cleora_propagate (what SparseMatrix.left_markov_propagate calls): repeated calls with different widths on one
+    handle — the device staging buffers are kept and grown — stay bit-exact against the oracle."""
+    k, g = karate
+    for d in (8, 300, 16, 300):
+        x = np.random.default_rng(d).standard_normal((34, d)).astype(np.float32)
+        np.testing.assert_array_equal(g.left_markov_propagate(x), oracle.spmm(k["rowptr"], k["col"], k["val_left"], x))
+        np.testing.assert_array_equal(g.symmetric_markov_propagate(x), oracle.spmm(k["rowptr"], k["col"], k["val_sym"], x))

@@ -142,6 +142,7 @@ void free_graph(cleora_graph *g) {
     (void)hipFree(g->seg_begin);
     (void)hipFree(g->hub_partial);
     (void)hipFree(g->col_hot);
+    (void)hipFree(g->hot_meta);
     (void)hipFree(g->io_buf[0]);
     (void)hipFree(g->io_buf[1]);
     for (hipEvent_t e : g->ev_pool) (void)hipEventDestroy(e);
@@ -323,7 +324,7 @@ int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info) {
     {
         std::lock_guard<std::mutex> lock(g->mu);
         info->device_bytes = g->device_bytes + (g->col_hot ? g->nnz * sizeof(uint32_t) : 0);
-        info->hot_rows = (g->col_hot && g->hot_rows_target) ? g->hot_rows_marked : 0;
+        info->hot_rows = hot_rows_marked(g);
     }
     info->hub_threshold = g->hub_threshold;
     info->hub_segment = g->hub_segment;

@@ -74,7 +74,7 @@ struct cleora_graph {
     mutable int64_t hot_bytes = -1;
     mutable uint32_t *col_hot = nullptr;
     mutable uint64_t hot_rows_target = 0;
-    mutable uint64_t hot_rows_marked = 0;
+    mutable uint32_t *hot_meta = nullptr;   // device: {threshold in-degree, rows marked}
     mutable bool hot_failed = false;        // building the marks failed once (e.g. out of memory): policy stays off
     mutable uint32_t auto_launches = 0;     // automatic mode arms itself on the third eligible launch
 
@@ -101,7 +101,8 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
                   float *row_sumsq, hipStream_t stream, uint64_t ldxs = 0);  // ldxs: leading dimension of x_self (0 = ldx)
 // hot.hip
-const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx);
+const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx, hipStream_t stream);
+uint64_t hot_rows_marked(const cleora_graph *g);
 // rowops.hip
 int launch_init(const uint64_t *hash, uint64_t n, uint32_t d, int64_t seed, float *x, uint64_t ldx,
                 hipStream_t stream);

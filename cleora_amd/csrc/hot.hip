@@ -42,9 +42,26 @@ __global__ __launch_bounds__(256) void degree_hist_kernel(const uint32_t *__rest
         if (sm[b]) atomicAdd(&bins[b], sm[b]);
 }
 
+// meta[0] = smallest in-degree that is still "hot", meta[1] = rows at or above it: whole degree classes from the top
+// down to the budget `want` (the first class is always taken).  One thread: 4096 bins.
+__global__ void select_threshold_kernel(const uint32_t *__restrict__ bins, uint64_t want, uint32_t *__restrict__ meta) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t threshold = kDegBins;
+    uint64_t cum = 0;
+    for (int b = kDegBins - 1; b >= 1; --b) {
+        if (cum + bins[b] > want && cum > 0) break;
+        cum += bins[b];
+        threshold = (uint32_t)b;
+        if (cum >= want) break;
+    }
+    meta[0] = threshold;
+    meta[1] = (uint32_t)(cum > 0xffffffffull ? 0xffffffffull : cum);
+}
+
 __global__ __launch_bounds__(256) void mark_kernel(const uint32_t *__restrict__ col, uint64_t nnz,
-                                                   const uint32_t *__restrict__ indeg, uint32_t threshold,
+                                                   const uint32_t *__restrict__ indeg, const uint32_t *__restrict__ meta,
                                                    uint32_t *__restrict__ out) {
+    const uint32_t threshold = meta[0];
     for (uint64_t i = CLEORA_LINEAR_BLOCK() * 256 + threadIdx.x; i < nnz;
          i += (uint64_t)gridDim.x * gridDim.y * 256) {
         const uint32_t c = col[i];
@@ -55,13 +72,15 @@ __global__ __launch_bounds__(256) void mark_kernel(const uint32_t *__restrict__ 
 }  // namespace
 
 namespace {
-const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want);
+const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want, hipStream_t stream);
 }
 
 // Returns the marked column array for rows of `d` floats (building or rebuilding it if needed), or
-// nullptr when the policy does not apply.  Called with g->mu held.
+// nullptr when the policy does not apply.  Called with g->mu held.  Everything it does is ENQUEUED on `stream`
+// (stream-ordered allocations, kernels; the threshold is chosen on the device): a `*_dev` entry point never
+// synchronises, allocates with hipMalloc or copies to the host because of it.
 
-const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx) {
+const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx, hipStream_t stream) {
     if (g->hot_bytes == 0 || g->hot_failed || g->nnz == 0 || g->n_cols >= (1ull << 31)) return nullptr;
     const uint64_t row_bytes = (uint64_t)d * sizeof(float);
     const uint64_t x_bytes = g->n_cols * ldx * sizeof(float);
@@ -83,7 +102,7 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
     if (want > g->n_cols / 2) want = g->n_cols / 2;
     if (want == 0) return nullptr;
     if (g->col_hot && g->hot_rows_target == want) return g->col_hot;
-    const uint32_t *marked = build_hot_cols(g, want);
+    const uint32_t *marked = build_hot_cols(g, want, stream);
     if (!marked) {
         // the policy is an optimisation: a failure here (typically out of memory for the marked copy) must not
         // fail the launch or be retried on every call — clear the sticky HIP error and switch the policy off
@@ -94,42 +113,46 @@ const uint32_t *ensure_hot_cols(const cleora_graph *g, uint32_t d, uint64_t ldx)
 }
 
 namespace {
-const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want) {
+const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want, hipStream_t stream) {
     if (hipSetDevice(g->device) != hipSuccess) return nullptr;
-    // a rebuild overwrites col_hot in place: launches still reading the previous marks (any stream) finish first
-    if (g->col_hot && hipDeviceSynchronize() != hipSuccess) return nullptr;
+    // a rebuild overwrites col_hot in place, ordered on `stream` like every launch of this handle (one stream per
+    // handle: include/cleora_hip.h)
     uint32_t *indeg = nullptr, *bins = nullptr;
-    if (hipMalloc(&indeg, g->n_cols * sizeof(uint32_t)) != hipSuccess) return nullptr;
-    if (hipMalloc(&bins, kDegBins * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(indeg); return nullptr; }
-    if (!g->col_hot && hipMalloc(&g->col_hot, g->nnz * sizeof(uint32_t)) != hipSuccess) {
-        (void)hipFree(indeg); (void)hipFree(bins); g->col_hot = nullptr; return nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&indeg), g->n_cols * sizeof(uint32_t), stream) != hipSuccess) return nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&bins), kDegBins * sizeof(uint32_t), stream) != hipSuccess) {
+        (void)hipFreeAsync(indeg, stream);
+        return nullptr;
     }
-    (void)hipMemset(indeg, 0, g->n_cols * sizeof(uint32_t));
-    (void)hipMemset(bins, 0, kDegBins * sizeof(uint32_t));
+    if (!g->hot_meta && hipMallocAsync(reinterpret_cast<void **>(&g->hot_meta), 2 * sizeof(uint32_t), stream) != hipSuccess) g->hot_meta = nullptr;
+    if (g->hot_meta && !g->col_hot && hipMallocAsync(reinterpret_cast<void **>(&g->col_hot), g->nnz * sizeof(uint32_t), stream) != hipSuccess)
+        g->col_hot = nullptr;
+    if (!g->hot_meta || !g->col_hot) {
+        (void)hipFreeAsync(indeg, stream);
+        (void)hipFreeAsync(bins, stream);
+        return nullptr;
+    }
+    (void)hipMemsetAsync(indeg, 0, g->n_cols * sizeof(uint32_t), stream);
+    (void)hipMemsetAsync(bins, 0, kDegBins * sizeof(uint32_t), stream);
     const dim3 grid(4096);
-    hipLaunchKernelGGL(indegree_kernel, grid, dim3(256), 0, nullptr, g->col, g->nnz, indeg);
-    hipLaunchKernelGGL(degree_hist_kernel, grid, dim3(256), 0, nullptr, indeg, g->n_cols, bins);
-    std::vector<uint32_t> h(kDegBins);
-    bool ok = hipMemcpy(h.data(), bins, kDegBins * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess;
-    uint32_t threshold = kDegBins;                     // smallest in-degree that is still "hot"
-    uint64_t cum = 0;
-    if (ok) {
-        for (int b = kDegBins - 1; b >= 1; --b) {
-            if (cum + h[b] > want && cum > 0) break;
-            cum += h[b];
-            threshold = (uint32_t)b;
-            if (cum >= want) break;
-        }
-        hipLaunchKernelGGL(mark_kernel, grid, dim3(256), 0, nullptr, g->col, g->nnz, indeg, threshold, g->col_hot);
-        ok = hipDeviceSynchronize() == hipSuccess;
-    }
-    (void)hipFree(indeg);
-    (void)hipFree(bins);
+    hipLaunchKernelGGL(indegree_kernel, grid, dim3(256), 0, stream, g->col, g->nnz, indeg);
+    hipLaunchKernelGGL(degree_hist_kernel, grid, dim3(256), 0, stream, indeg, g->n_cols, bins);
+    hipLaunchKernelGGL(select_threshold_kernel, dim3(1), dim3(64), 0, stream, bins, want, g->hot_meta);
+    hipLaunchKernelGGL(mark_kernel, grid, dim3(256), 0, stream, g->col, g->nnz, indeg, g->hot_meta, g->col_hot);
+    const bool ok = hipGetLastError() == hipSuccess;
+    (void)hipFreeAsync(indeg, stream);
+    (void)hipFreeAsync(bins, stream);
     if (!ok) return nullptr;
     g->hot_rows_target = want;
-    g->hot_rows_marked = cum;
     return g->col_hot;
 }
 }  // namespace
+
+// rows currently marked hot (a host query: waits for the build if it is still in flight)
+uint64_t hot_rows_marked(const cleora_graph *g) {
+    if (!g->col_hot || !g->hot_meta || !g->hot_rows_target) return 0;
+    uint32_t meta[2] = {0, 0};
+    if (hipMemcpy(meta, g->hot_meta, sizeof(meta), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return meta[1];
+}
 
 }  // namespace cleora

@@ -571,13 +571,15 @@ inline dim3 grid_for(uint64_t items, int per_block) {
     return grid_1d_as_2d((items + per_block - 1) / per_block);
 }
 
-int ensure_partial(const cleora_graph *g, uint32_t d) {
+// Scratch for the hub-segment partial sums, grown when a wider d arrives: stream-ordered (the old block is released
+// behind the launches that still use it), so a `*_dev` call stays enqueue-only.
+int ensure_partial(const cleora_graph *g, uint32_t d, hipStream_t stream) {
     const uint64_t need = g->n_hub_segments * (uint64_t)d;
     if (need <= g->hub_partial_elems) return CLEORA_OK;
-    if (g->hub_partial) CL_HIP(hipFree(g->hub_partial));
+    if (g->hub_partial) CL_HIP(hipFreeAsync(g->hub_partial, stream));
     g->hub_partial = nullptr;
     g->hub_partial_elems = 0;
-    CL_HIP(hipMalloc(&g->hub_partial, need * sizeof(float)));
+    CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&g->hub_partial), need * sizeof(float), stream));
     g->hub_partial_elems = need;
     return CLEORA_OK;
 }
@@ -614,7 +616,7 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
             if constexpr (kW == 4) {
                 // hot-column cache policy: needs the marked column copy and, for sub-wave groups, a
                 // matrix that one buffer descriptor can span
-                const uint32_t *hot = (kG == 64 || a.x_bytes < (1ull << 32)) ? ensure_hot_cols(g, d, a.ldx) : nullptr;
+                const uint32_t *hot = (kG == 64 || a.x_bytes < (1ull << 32)) ? ensure_hot_cols(g, d, a.ldx, stream) : nullptr;
                 if (hot) {
                     SpmmArgs h = a;
                     h.col = hot;
@@ -669,7 +671,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
     std::lock_guard<std::mutex> lock(g->mu);
     CL_HIP(hipSetDevice(g->device));
     if (g->n_hub_segments) {
-        const int rc = ensure_partial(g, d);
+        const int rc = ensure_partial(g, d, stream);
         if (rc != CLEORA_OK) return rc;
     }
 

@@ -478,44 +478,49 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const uint32_t groups = d / 8;
+    // Main loop, software-pipelined by hand with NO conditionals (the packed T is zero-padded by PF groups and to whole
+    // 8-tile column blocks, the LDS tile by one group): B fragments are fetched PF groups ahead into fixed register
+    // slots, A fragments one group ahead, so every wait is a counted s_waitcnt behind ~1000+ cycles of MFMAs.
+    const uint32_t groups = d / 8;                                     // a multiple of PF (d % 32 == 0)
     const uint32_t jt0 = n0 / 32;
     const float *ap = xs + (lane & 31) * lds + 4 * (lane >> 5);        // + 32*i*lds + 8*g
     const float *bp = tp + ((uint64_t)jt0 * 64 + lane) * 4;            // + (g*col_tiles + j)*256
+    const uint64_t bstep = (uint64_t)col_tiles * 256;                  // floats per group
     constexpr int PF = 4;                                              // groups of B in flight
     float4 bq[PF][WN];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-            bq[p][j] = (uint32_t)p < groups && jt0 + j < col_tiles
-                           ? *reinterpret_cast<const float4 *>(bp + ((uint64_t)p * col_tiles + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t g0 = 0; g0 < groups; g0 += PF) {
+        for (int j = 0; j < WN; ++j) bq[p][j] = *reinterpret_cast<const float4 *>(bp + p * bstep + j * 256);
+    float4 af[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4 *>(ap + 32 * i * lds);
+    const float *bnext = bp + PF * bstep;
+    for (uint32_t g0 = 0; g0 < groups; g0 += PF, bnext += PF * bstep) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const uint32_t g = g0 + p;
-            if (g >= groups) break;
-            float4 af[2];
+            float4 an[2];                                              // A of the next group (one past the end: the pad)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4 *>(ap + 32 * i * lds + 8 * g);
-            float4 bf[WN];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                bf[j] = bq[p][j];
-                const uint32_t gn = g + PF;                            // refill this slot for PF groups ahead
-                bq[p][j] = gn < groups && jt0 + j < col_tiles
-                               ? *reinterpret_cast<const float4 *>(bp + ((uint64_t)gn * col_tiles + j) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int i = 0; i < 2; ++i) an[i] = *reinterpret_cast<const float4 *>(ap + 32 * i * lds + 8 * (g0 + p + 1));
+            __builtin_amdgcn_sched_barrier(0);                         // keep the read-ahead ABOVE this group's MFMAs
             const float a4[2][4] = {{af[0].x, af[0].y, af[0].z, af[0].w}, {af[1].x, af[1].y, af[1].z, af[1].w}};
+            float b4[WN][4];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) { b4[j][0] = bq[p][j].x; b4[j][1] = bq[p][j].y; b4[j][2] = bq[p][j].z; b4[j][3] = bq[p][j].w; }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        const float b = q == 0 ? bf[j].x : q == 1 ? bf[j].y : q == 2 ? bf[j].z : bf[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][q], b, acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][q], b4[j][q], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bq[p][j] = *reinterpret_cast<const float4 *>(bnext + p * bstep + j * 256);
+            // hipcc's scheduler otherwise sinks these loads down to their consumer PF groups later (one register slot, a
+            // full L2 latency exposed per group: measured 35 % MFMA idle); nothing may move across this point
+            __builtin_amdgcn_sched_barrier(0);
+            af[0] = an[0];
+            af[1] = an[1];
         }
     }
 
@@ -536,14 +541,14 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
 __global__ __launch_bounds__(256) void pack_transform_kernel(const float *__restrict__ t, uint32_t d, uint32_t k,
                                                              uint32_t col_tiles, float *__restrict__ tp) {
     const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;     // one float4 of the packed array
-    const uint64_t total = (uint64_t)(d / 8) * col_tiles * 64;
+    const uint64_t total = (uint64_t)(d / 8 + 4) * col_tiles * 64;     // 4 = PF groups of zero padding behind the last
     if (idx >= total) return;
     const uint32_t lane = (uint32_t)(idx & 63);
     const uint32_t j = (uint32_t)((idx >> 6) % col_tiles), g = (uint32_t)((idx >> 6) / col_tiles);
     const uint32_t n = j * 32 + (lane & 31), k0 = 8 * g + 4 * (lane >> 5);
     float v[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = n < k ? t[(uint64_t)(k0 + q) * k + n] : 0.f;
+    for (int q = 0; q < 4; ++q) v[q] = (n < k && k0 + q < d) ? t[(uint64_t)(k0 + q) * k + n] : 0.f;
     reinterpret_cast<float4 *>(tp)[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
@@ -620,14 +625,14 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.w4t = (k % 4 == 0) && aligned16(t);
     // rows-in-LDS form: whole rows as float4, reduction index in groups of 8, the X tile within the LDS budget
     static const bool first_form_only = std::getenv("CLEORA_PROJECT_TILED") != nullptr;   // A/B switch for profiling
-    if (!first_form_only && a.w4x && d % 8 == 0 && d <= 512 && aligned16(mean) && n >= 4 * RM) {
-        const uint32_t col_tiles = (k + 31) / 32;
-        const uint64_t packed = (uint64_t)(d / 8) * col_tiles * 64 * 4;     // floats
+    if (!first_form_only && a.w4x && d % 32 == 0 && d <= 512 && aligned16(mean) && n >= 4 * RM) {
+        const uint32_t col_tiles = ((k + 31) / 32 + 7) / 8 * 8;           // whole 8-tile (256-column) blocks, zero-padded
+        const uint64_t packed = (uint64_t)(d / 8 + 4) * col_tiles * 64 * 4; // floats, incl. 4 groups of padding
         float *tp = nullptr;
         CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), packed * sizeof(float), stream));
         hipLaunchKernelGGL(pack_transform_kernel, dim3((unsigned)((packed / 4 + 255) / 256)), dim3(256), 0, stream, t, d, k,
                            col_tiles, tp);
-        const size_t lds_bytes = (size_t)RM * (d + 4) * sizeof(float);
+        const size_t lds_bytes = (size_t)RM * (d + 4) * sizeof(float) + 64;   // + the one-group read-ahead of the last row
         static bool attr_set = false;
         if (!attr_set) {
             CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(project_rows_kernel<2>),
@@ -636,7 +641,7 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         }
         const uint64_t row_blocks = (n + RM - 1) / RM;
         CL_REQUIRE(row_blocks < (1ull << 31), "internal: too many row blocks");
-        hipLaunchKernelGGL(project_rows_kernel<2>, dim3((unsigned)row_blocks, (col_tiles + 7) / 8), dim3(256), lds_bytes,
+        hipLaunchKernelGGL(project_rows_kernel<2>, dim3((unsigned)row_blocks, col_tiles / 8), dim3(256), lds_bytes,
                            stream, a, tp, col_tiles);
         const hipError_t le = hipGetLastError();
         CL_HIP(hipFreeAsync(tp, stream));

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_hot_global(const Args a) {
 // Hot/cold split: bit 31 of the column index marks a "hot" (high in-degree) row; hot rows are gathered
 // with the default cache policy, cold rows non-temporally, to keep the hot set resident in L2/MALL.
 // EXTRA bit 0: Y rows stored non-temporally; bit 1: the CSR col / val streams loaded non-temporally.
-template <int U, bool HOT_NT, int AUX_A = 2, int AUX_B = 0, int EXTRA = 0>
+template <int U, bool COLD_NT, int AUX_A = 2, int AUX_B = 0, int EXTRA = 0>
 __global__ __launch_bounds__(256) void k_hot(const Args a) {
     const int lane = threadIdx.x & 63;
     uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -253,14 +253,14 @@ __global__ __launch_bounds__(256) void k_hot(const Args a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t c = rl(cv, k + u);
-                r[u] = ld_policy<AUX_A, AUX_B>(a.x + (uint64_t)(c & 0x7fffffffu) * 256, lane, (c >> 31) != (HOT_NT ? 1u : 0u));
+                r[u] = ld_policy<AUX_A, AUX_B>(a.x + (uint64_t)(c & 0x7fffffffu) * 256, lane, (c >> 31) != (COLD_NT ? 1u : 0u));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) fma_sep(acc, rlf(wv, k + u), r[u]);
         }
         for (; k < cnt; ++k) {
             const uint32_t c = rl(cv, k);
-            v4f r = ld_policy<AUX_A, AUX_B>(a.x + (uint64_t)(c & 0x7fffffffu) * 256, lane, (c >> 31) != (HOT_NT ? 1u : 0u));
+            v4f r = ld_policy<AUX_A, AUX_B>(a.x + (uint64_t)(c & 0x7fffffffu) * 256, lane, (c >> 31) != (COLD_NT ? 1u : 0u));
             fma_sep(acc, rlf(wv, k), r);
         }
     }

@@ -423,6 +423,15 @@ int cleora_cosine_scores_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t 
     return launch_cosine(x, ldx, n, d, query_dev, scores_dev, S(stream));
 }
 
+uint64_t cleora_topk_workspace(uint64_t n, uint32_t k) { return topk_workspace_bytes(n, k); }
+
+int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                           const uint32_t *query_rows_dev, uint32_t n_queries, uint32_t k, int exclude_self,
+                           int exclude_existing, uint32_t *out_index_dev, float *out_score_dev, void *workspace, void *stream) {
+    return launch_topk_cosine(g, x, ldx, n, d, query_rows_dev, n_queries, k, exclude_self, exclude_existing, out_index_dev,
+                              out_score_dev, workspace, S(stream));
+}
+
 uint64_t cleora_gram_workspace(uint64_t n, uint32_t d) { return gram_workspace(n, d); }
 
 int cleora_centered_gram_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,

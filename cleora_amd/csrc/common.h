@@ -121,6 +121,12 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
 
+// similarity.hip
+uint64_t topk_workspace_bytes(uint64_t n, uint32_t k);
+int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                       const uint32_t *queries_dev, uint32_t n_queries, uint32_t k, int exclude_self, int exclude_edges,
+                       uint32_t *out_index, float *out_score, void *workspace, hipStream_t stream);
+
 // stager.hip: pageable host memory <-> device through a pinned ring, at PCIe speed
 int staged_h2d(void *dst_dev, const void *src_host, uint64_t bytes, hipStream_t after);
 int staged_d2h(void *dst_host, const void *src_dev, uint64_t bytes, hipStream_t after);

@@ -1,0 +1,229 @@
+// similarity.hip — top-k cosine neighbours on the device: the `normed @ normed[src]`, masking and
+// `argsort()[::-1][:top_k]` of predict_links / find_most_similar (pycleora/__init__.py:636-681, 753-781) for a BATCH of
+// query rows per pass over X, with the selection on the device: no per-query launch + sync + n-float download.
+//
+//   scores   one wavefront per row of X, up to 8 queries at once (query rows normalised into LDS): X is read once
+//            per batch — HBM-bound;
+//   mask     the query itself and, optionally, every r with a stored edge (q, r) or (r, q) get -2 like the reference
+//            (one pass over the CSR per batch);
+//   top-k    per 2048-element chunk k rounds of a block-wide arg-max in LDS (ties: the LARGER row index first, which
+//            is what numpy's argsort()[::-1] yields), then the chunk winners are merged the same way.
+#include <utility>
+
+#include "common.h"
+
+namespace cleora {
+namespace {
+
+constexpr int QB = 8;           // queries per pass
+constexpr int CHUNK = 2048;     // elements per selection block
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// scores[q * n + r] = (x[r] . qn_q) / max(||x[r]||, 1e-10), qn_q = x[query_q] / max(||x[query_q]||, 1e-10)
+template <bool W4>
+__global__ __launch_bounds__(256) void cosine_batch_kernel(const float *__restrict__ x, uint64_t ldx, uint64_t n, uint32_t d,
+                                                           const uint32_t *__restrict__ queries, uint32_t nq,
+                                                           float *__restrict__ scores) {
+    extern __shared__ float qs[];                       // [nq][d]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t q = w; q < nq; q += 4) {              // one wave normalises one query row into LDS
+        const float *xq = x + (uint64_t)queries[q] * ldx;
+        float sq = 0.f;
+        for (uint32_t c = lane; c < d; c += 64) sq += xq[c] * xq[c];
+        const float inv = 1.0f / fmaxf(sqrtf(wsum(sq)), 1e-10f);
+        for (uint32_t c = lane; c < d; c += 64) qs[q * d + c] = xq[c] * inv;
+    }
+    __syncthreads();
+    const uint64_t waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = (uint64_t)blockIdx.x * 4 + w; row < n; row += waves) {
+        const float *xr = x + row * ldx;
+        float dot[QB], sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < QB; ++q) dot[q] = 0.f;
+        if constexpr (W4) {
+            for (uint32_t c = lane * 4; c < d; c += 256) {
+                const float4 v = *reinterpret_cast<const float4 *>(xr + c);
+                sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+                    if ((uint32_t)q < nq) {
+                        const float4 t = *reinterpret_cast<const float4 *>(qs + q * d + c);
+                        dot[q] += v.x * t.x + v.y * t.y + v.z * t.z + v.w * t.w;
+                    }
+            }
+        } else {
+            for (uint32_t c = lane; c < d; c += 64) {
+                const float v = xr[c];
+                sq += v * v;
+#pragma unroll
+                for (int q = 0; q < QB; ++q)
+                    if ((uint32_t)q < nq) dot[q] += v * qs[q * d + c];
+            }
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(wsum(sq)), 1e-10f);
+#pragma unroll
+        for (int q = 0; q < QB; ++q)
+            if ((uint32_t)q < nq) {
+                const float s = wsum(dot[q]);
+                if (lane == 0) scores[(uint64_t)q * n + row] = s * inv;
+            }
+    }
+}
+
+// -2 for the query itself and for both directions of every stored edge that touches it (:650-660)
+__global__ __launch_bounds__(256) void mask_kernel(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                   uint64_t n_rows, uint64_t n, const uint32_t *__restrict__ queries, uint32_t nq,
+                                                   int exclude_self, int exclude_edges, float *__restrict__ scores) {
+    __shared__ uint32_t qv[QB];
+    if (threadIdx.x < nq) qv[threadIdx.x] = queries[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t waves = (uint64_t)gridDim.x * 4;
+    if (exclude_self && blockIdx.x == 0 && threadIdx.x < nq) scores[(uint64_t)threadIdx.x * n + qv[threadIdx.x]] = -2.0f;
+    if (!exclude_edges) return;
+    for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += waves) {
+        const uint64_t b = rowptr[row], e = rowptr[row + 1];
+        for (uint64_t k = b + lane; k < e; k += 64) {
+            const uint32_t c = col[k];
+            for (uint32_t q = 0; q < nq; ++q) {
+                if (qv[q] == (uint32_t)row) scores[(uint64_t)q * n + c] = -2.0f;      // (src, other)
+                if (qv[q] == c) scores[(uint64_t)q * n + row] = -2.0f;                // (other, src)
+            }
+        }
+    }
+}
+
+// One block: the k best of its CHUNK elements of row q, descending, ties -> larger index.  idx_in == nullptr: the
+// element's position is its index (first level).  Output: out_score / out_index [q][block][k].
+__global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict__ score_in, const uint32_t *__restrict__ idx_in,
+                                                         uint64_t len, uint64_t stride_in, uint32_t k,
+                                                         float *__restrict__ out_score, uint32_t *__restrict__ out_index,
+                                                         uint64_t stride_out) {
+    __shared__ float sv[CHUNK];
+    __shared__ uint32_t si[CHUNK];
+    __shared__ float rv[4];
+    __shared__ uint32_t ri[4], rp[4];
+    const uint32_t q = blockIdx.y;
+    const uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int i = t; i < CHUNK; i += 256) {
+        const uint64_t p = base + i;
+        const bool ok = p < len;
+        sv[i] = ok ? score_in[q * stride_in + p] : -INFINITY;
+        si[i] = ok ? (idx_in ? idx_in[q * stride_in + p] : (uint32_t)p) : 0u;
+    }
+    __syncthreads();
+    float *os = out_score + q * stride_out + (uint64_t)blockIdx.x * k;
+    uint32_t *oi = out_index + q * stride_out + (uint64_t)blockIdx.x * k;
+    for (uint32_t round = 0; round < k; ++round) {
+        float bv = -INFINITY;
+        uint32_t bi = 0, bp = 0xffffffffu;
+        for (int i = t; i < CHUNK; i += 256) {
+            const float v = sv[i];
+            const uint32_t id = si[i];
+            // first live element, a larger score, or an equal score at a larger row index
+            if (v > -INFINITY && (bp == 0xffffffffu || v > bv || (v == bv && id > bi))) { bv = v; bi = id; bp = (uint32_t)i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const uint32_t oid = (uint32_t)__shfl_xor((int)bi, o, 64), op = (uint32_t)__shfl_xor((int)bp, o, 64);
+            const bool take = op != 0xffffffffu && (bp == 0xffffffffu || ov > bv || (ov == bv && oid > bi));
+            if (take) { bv = ov; bi = oid; bp = op; }
+        }
+        if (lane == 0) { rv[w] = bv; ri[w] = bi; rp[w] = bp; }
+        __syncthreads();
+        if (t == 0) {
+            float fv = rv[0];
+            uint32_t fi = ri[0], fp = rp[0];
+            for (int j = 1; j < 4; ++j) {
+                const bool take = rp[j] != 0xffffffffu && (fp == 0xffffffffu || rv[j] > fv || (rv[j] == fv && ri[j] > fi));
+                if (take) { fv = rv[j]; fi = ri[j]; fp = rp[j]; }
+            }
+            os[round] = fp == 0xffffffffu ? -INFINITY : fv;
+            oi[round] = fi;
+            if (fp != 0xffffffffu) sv[fp] = -INFINITY;       // taken: out of the next rounds
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+static inline uint64_t chunks_of(uint64_t len) { return (len + CHUNK - 1) / CHUNK; }
+
+// floats: scores [QB][n] + two candidate levels (score + index each)
+uint64_t topk_workspace_bytes(uint64_t n, uint32_t k) {
+    const uint64_t l1 = chunks_of(n) * k;
+    const uint64_t l2 = chunks_of(l1) * k;
+    return ((uint64_t)QB * n + 2 * (uint64_t)QB * l1 + 2 * (uint64_t)QB * l2) * 4 + 1024;
+}
+
+int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                       const uint32_t *queries_dev, uint32_t n_queries, uint32_t k, int exclude_self, int exclude_edges,
+                       uint32_t *out_index, float *out_score, void *workspace, hipStream_t stream) {
+    CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
+    CL_REQUIRE(x != nullptr && queries_dev != nullptr && out_index != nullptr && out_score != nullptr && workspace != nullptr,
+               "x / queries / out / workspace is NULL");
+    CL_REQUIRE(k >= 1 && k <= 1024 && (uint64_t)k <= n, "need 1 <= k <= min(n, 1024)");
+    CL_REQUIRE(n < (1ull << 32), "more than 2^32 rows");
+    CL_REQUIRE(!exclude_edges || (g != nullptr && g->n_rows == n && g->n_cols == n), "exclude_existing needs the square graph of X");
+    CL_REQUIRE((uint64_t)d * sizeof(float) * 1 <= 64 * 1024, "row too wide for the query staging (d <= 16384)");
+    if (n_queries == 0) return CLEORA_OK;
+    const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+    // queries per pass: as many as fit 64 KiB of LDS, at most QB
+    uint32_t per = (uint32_t)((64 * 1024) / ((uint64_t)d * sizeof(float)));
+    if (per > QB) per = QB;
+    float *scores = static_cast<float *>(workspace);
+    const uint64_t l1 = chunks_of(n) * k, l2 = chunks_of(l1) * k;
+    float *s1 = scores + (uint64_t)QB * n;
+    uint32_t *i1 = reinterpret_cast<uint32_t *>(s1 + (uint64_t)QB * l1);
+    float *s2 = reinterpret_cast<float *>(i1 + (uint64_t)QB * l1);
+    uint32_t *i2 = reinterpret_cast<uint32_t *>(s2 + (uint64_t)QB * l2);
+    const unsigned grid = (unsigned)((n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096);
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += per) {
+        const uint32_t nq = n_queries - q0 < per ? n_queries - q0 : per;
+        const size_t lds = (size_t)nq * d * sizeof(float);
+        if (w4)
+            hipLaunchKernelGGL(cosine_batch_kernel<true>, dim3(grid), dim3(256), lds, stream, x, ldx, n, d, queries_dev + q0, nq, scores);
+        else
+            hipLaunchKernelGGL(cosine_batch_kernel<false>, dim3(grid), dim3(256), lds, stream, x, ldx, n, d, queries_dev + q0, nq, scores);
+        if (exclude_self || exclude_edges)
+            hipLaunchKernelGGL(mask_kernel, dim3(grid), dim3(256), 0, stream, exclude_edges ? g->rowptr : nullptr,
+                               exclude_edges ? g->col : nullptr, exclude_edges ? g->n_rows : 0, n, queries_dev + q0, nq,
+                               exclude_self, exclude_edges, scores);
+        // selection: chunks of X rows -> chunk winners -> ... -> one block per query
+        const float *sin = scores;
+        const uint32_t *iin = nullptr;
+        uint64_t len = n, stride = n;
+        float *so = s1;
+        uint32_t *io = i1;
+        uint64_t ostride = l1;
+        for (int level = 0;; ++level) {
+            const uint64_t nb = chunks_of(len);
+            if (nb == 1) {   // final: straight into the caller's arrays
+                hipLaunchKernelGGL(topk_chunk_kernel, dim3(1, nq), dim3(256), 0, stream, sin, iin, len, stride, k,
+                                   out_score + (uint64_t)q0 * k, out_index + (uint64_t)q0 * k, (uint64_t)k);
+                break;
+            }
+            hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)nb, nq), dim3(256), 0, stream, sin, iin, len, stride, k, so, io, ostride);
+            sin = so;
+            iin = io;
+            len = nb * k;
+            stride = ostride;
+            // the two candidate buffers alternate (level 1 fits l2 again: it is smaller than level 0's output)
+            if (so == s1) { so = s2; io = i2; ostride = l2; } else { so = s1; io = i1; ostride = l1; }
+        }
+    }
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+}  // namespace cleora

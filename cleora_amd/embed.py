@@ -232,24 +232,27 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
 
 
 def find_most_similar(graph, embeddings, query_entity, top_k=10, exclude_self=True):
-    """Same contract as pycleora.find_most_similar (pycleora/__init__.py:753-781): cosine
-    similarity of every entity to the query, top_k as a list of dicts.  The normalise + GEMV runs
-    as one pass over X on the device; the top-k selection of the n scores stays on the host."""
+    """Same contract as pycleora.find_most_similar (pycleora/__init__.py:753-781): cosine similarity of every entity
+    to the query, top_k as a list of dicts.  Normalise + GEMV + selection in one device call
+    (cleora_topk_cosine_dev); only the top_k (index, score) pairs come back."""
     query_idx = graph.get_entity_index(query_entity)
     x = np.ascontiguousarray(embeddings, dtype=np.float32)
     n, d = x.shape
-    q = x[query_idx]
-    q = (q / max(float(np.linalg.norm(q)), 1e-10)).astype(np.float32)
-    L = _hip.lib()
-    dx, dq = _hip.DevArray.from_host(x), _hip.DevArray.from_host(q)
-    ds = _hip.DevArray((n,), np.float32)
-    _hip.check(L.cleora_cosine_scores_dev(dx.ptr, d, n, d, dq.ptr, ds.ptr, None))
-    _hip.check(L.cleora_stream_sync(None))
-    sims = ds.to_host()
-    if exclude_self:
-        sims[query_idx] = -1.0
     k = min(int(top_k), n)
-    part = np.argpartition(-sims, k - 1)[:k] if k < n else np.arange(n)
-    order = part[np.argsort(-sims[part], kind="stable")]
+    if k <= 0:
+        return []
+    L = _hip.lib()
+    dx = _hip.DevArray.from_host(x)
+    dq = _hip.DevArray.from_host(np.asarray([query_idx], dtype=np.uint32))
+    kk = k
+    oi, os_ = _hip.DevArray((1, kk), np.uint32), _hip.DevArray((1, kk), np.float32)
+    ws = _hip.DevArray((L.cleora_topk_workspace(n, kk),), np.uint8)
+    _hip.check(L.cleora_topk_cosine_dev(None, dx.ptr, d, n, d, dq.ptr, 1, kk, 1 if exclude_self else 0, 0, oi.ptr, os_.ptr,
+                                        ws.ptr, None))
+    _hip.check(L.cleora_stream_sync(None))
+    idx, sims = oi.to_host()[0], os_.to_host()[0]
     ids = graph.entity_ids
-    return [{"entity_id": ids[int(i)], "index": int(i), "similarity": float(sims[int(i)])} for i in order]
+    # the reference sets the query's own similarity to -1 (:768-769) and still lists it if it ranks; the device masks
+    # with -2: report -1 for it like the reference
+    return [{"entity_id": ids[int(i)], "index": int(i), "similarity": float(-1.0 if (exclude_self and int(i) == query_idx) else v)}
+            for i, v in zip(idx, sims)][:k]

@@ -183,42 +183,43 @@ def embed_edge_features(graph, edge_features, feature_dim=DEFAULT_FEATURE_DIM,
 
 
 def predict_links(graph, embeddings, top_k=10, exclude_existing=True, source_entities=None):
-    """(:636-681).  For every source entity: cosine similarity to all entities (one pass over the resident X
-    per source, cleora_cosine_scores_dev), the source itself and — optionally — its stored neighbours in either
-    direction masked with -2, the top_k of the rest; finally the top_k of all candidates by score."""
+    """(:636-681).  For every source entity: cosine similarity to all entities, the source itself and — optionally —
+    its stored neighbours in either direction masked with -2, the top_k of the rest; finally the top_k of all
+    candidates by score.  Scores, masks and the per-source selection run on the device for all sources in ONE call
+    (cleora_topk_cosine_dev: X is read once per 8 sources, one synchronisation at the end); only the
+    n_sources x top_k candidates come back."""
     x = np.ascontiguousarray(embeddings, dtype=np.float32)
     n, d = x.shape
     if source_entities is not None:
         source_indices = [graph.get_entity_index(eid) for eid in source_entities]
     else:
         source_indices = list(range(graph.num_entities))
+    top_k = int(top_k)
+    if not source_indices or top_k <= 0 or n == 0:
+        return []
+    idx, score = _topk_neighbours(graph, x, source_indices, min(top_k, n), True, bool(exclude_existing))
+    # candidates in the reference's append order: source by source, each source's list in descending score (ties: larger
+    # index first) without the masked ones (:663-664); then a STABLE sort by score, descending (:679), and the first top_k
+    src = np.repeat(np.asarray(source_indices, dtype=np.int64), idx.shape[1])
+    keep = score.ravel() > -2.0
+    src, tgt, sc = src[keep], idx.ravel()[keep].astype(np.int64), score.ravel()[keep]
+    order = np.argsort(-sc.astype(np.float64), kind="stable")[:top_k]
     ids = graph.entity_ids
-    rowptr = graph._arr["rowptr"].astype(np.int64)
-    col = graph._arr["col"].astype(np.int64)
-    reverse = None
-    if exclude_existing:                                                  # (other, src) edges: a CSC view
-        order = np.argsort(col, kind="stable")
-        rows = np.repeat(np.arange(graph.num_entities), np.diff(rowptr))
-        reverse = (np.concatenate([[0], np.cumsum(np.bincount(col, minlength=graph.num_entities))]), rows[order])
+    return [{"source": ids[int(src[i])], "target": ids[int(tgt[i])], "score": float(sc[i])} for i in order]
+
+
+def _topk_neighbours(graph, x, query_rows, k, exclude_self, exclude_existing):
+    """(index uint32[nq, k], score f32[nq, k]) of the k most cosine-similar rows of x for every query row."""
     L = _hip.lib()
-    normed = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)          # :643-645
-    dx = _hip.DevArray.from_host(np.ascontiguousarray(normed))
-    dq = _hip.DevArray((d,), np.float32)
-    ds = _hip.DevArray((n,), np.float32)
-    predictions = []
-    for src in source_indices:
-        _hip.check(L.cleora_memcpy_h2d(dq.ptr, _hip.ptr(np.ascontiguousarray(normed[src])), d * 4, None))
-        _hip.check(L.cleora_cosine_scores_dev(dx.ptr, d, n, d, dq.ptr, ds.ptr, None))
+    n, d = x.shape
+    nq = len(query_rows)
+    dx = _hip.DevArray.from_host(x)
+    dq = _hip.DevArray.from_host(np.asarray(query_rows, dtype=np.uint32))
+    oi, os_ = _hip.DevArray((nq, k), np.uint32), _hip.DevArray((nq, k), np.float32)
+    ws = _hip.DevArray((L.cleora_topk_workspace(n, k),), np.uint8)
+    with graph._lock:
+        g = graph._graph().handle if exclude_existing else None
+        _hip.check(L.cleora_topk_cosine_dev(g, dx.ptr, d, n, d, dq.ptr, nq, k, 1 if exclude_self else 0,
+                                            1 if exclude_existing else 0, oi.ptr, os_.ptr, ws.ptr, None))
         _hip.check(L.cleora_stream_sync(None))
-        sims = ds.to_host()
-        sims[src] = -2.0
-        if exclude_existing:
-            sims[col[rowptr[src]:rowptr[src + 1]]] = -2.0
-            cptr, crow = reverse
-            sims[crow[cptr[src]:cptr[src + 1]]] = -2.0
-        for tgt in np.argsort(sims)[::-1][:top_k]:
-            if sims[tgt] <= -2.0:
-                continue
-            predictions.append({"source": ids[src], "target": ids[int(tgt)], "score": float(sims[int(tgt)])})
-    predictions.sort(key=lambda p: p["score"], reverse=True)
-    return predictions[:top_k]
+    return oi.to_host(), os_.to_host()

@@ -290,6 +290,19 @@ int cleora_broadcast_dev(cleora_comm *c, void *buf, uint64_t bytes, int root, vo
  * whitening step of the column partition. */
 int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint64_t elems_per_rank, void *stream);
 
+/* The k nearest rows of X by cosine similarity for a batch of query ROWS of X, selected on the device: the
+ * `normed @ normed[src]`, the -2 masks and `argsort()[::-1][:top_k]` of predict_links / find_most_similar
+ * (pycleora/__init__.py:636-681, 753-781) without a launch, a sync and an n-float download per query.
+ *   score(q, r) = (x[r] . x[q]) / (max(||x[r]||, 1e-10) * max(||x[q]||, 1e-10))
+ *   exclude_self: score(q, q) = -2;  exclude_existing (needs the square graph of X): -2 for every r with a stored edge
+ *   (q, r) or (r, q) (:650-660).  out_index / out_score: [n_queries][k], descending score; ties: the larger row index
+ *   first (numpy's argsort()[::-1]); entries with score <= -2 are masked candidates the caller drops (:663-664).
+ * X is read once per 8 queries.  workspace: cleora_topk_workspace(n, k) BYTES.  1 <= k <= min(n, 1024). */
+uint64_t cleora_topk_workspace(uint64_t n, uint32_t k);
+int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
+                           const uint32_t *query_rows_dev, uint32_t n_queries, uint32_t k, int exclude_self,
+                           int exclude_existing, uint32_t *out_index_dev, float *out_score_dev, void *workspace, void *stream);
+
 /* ---- host-pointer entry points: what the PyO3 methods call ------------------------- */
 
 /* SparseMatrix::markov_propagate → NdArrayMatrix::multiply (src/lib.rs:29-47, src/embedding.rs:15-39).

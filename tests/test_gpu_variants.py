@@ -157,3 +157,44 @@ def test_predict_links(ref, tag, kw):
             assert (p["source"], p["target"]) in {(str(a), str(b)) for a, b in zip(want_s[close], want_t[close])}
     with pytest.raises(ValueError, match="not found"):
         variants.predict_links(g, k["embed_whiten_d16"], source_entities=["no-such-entity"])
+
+
+@pytest.mark.parametrize("n,d,k,nq", [(50_000, 64, 17, 11), (5000, 256, 5, 3), (3000, 20, 40, 9), (100, 8, 100, 2)])
+def test_topk_cosine_on_device_against_numpy(n, d, k, nq):
+    """cleora_topk_cosine_dev: scores, the -2 masks (self, both directions of stored edges) and the selection order of
+    numpy's `argsort()[::-1][:k]` (ties: larger index first), for a batch of query rows, several selection levels."""
+    import ctypes
+    from tests.graphs import random_csr
+    rng = np.random.default_rng(n + d)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[7] = x[3]                                   # exact ties
+    x[11] = 0.0                                   # zero row: norm clamp
+    rowptr, col, vl, vs = random_csr(n, 6, seed=n, empty_frac=0.05)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    queries = rng.choice(n, nq, replace=False).astype(np.uint32)
+    queries[0] = 3
+    L = _hip.lib()
+    dx, dq = _hip.DevArray.from_host(x), _hip.DevArray.from_host(queries)
+    oi, os_ = _hip.DevArray((nq, k), np.uint32), _hip.DevArray((nq, k), np.float32)
+    ws = _hip.DevArray((L.cleora_topk_workspace(n, k),), np.uint8)
+    normed = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)
+    rows = np.repeat(np.arange(n), np.diff(rowptr.astype(np.int64)))
+    for excl_edges in (1, 0):
+        _hip.check(L.cleora_topk_cosine_dev(g.handle if excl_edges else None, dx.ptr, d, n, d, dq.ptr, nq, k, 1, excl_edges,
+                                            oi.ptr, os_.ptr, ws.ptr, None))
+        _hip.check(L.cleora_stream_sync(None))
+        idx, sc = oi.to_host(), os_.to_host()
+        for qi, q in enumerate(queries):
+            sims = normed @ normed[q]
+            sims[q] = -2.0
+            if excl_edges:
+                sims[col[rows == q]] = -2.0
+                sims[rows[col == q]] = -2.0
+            want = np.argsort(sims)[::-1][:k]
+            np.testing.assert_allclose(sc[qi], sims[want], rtol=0, atol=3e-6)
+            assert (np.diff(sc[qi]) <= 0).all()                                     # descending
+            assert len(set(idx[qi].tolist())) == k                                    # no row twice
+            np.testing.assert_allclose(sims[idx[qi]], sc[qi], rtol=0, atol=3e-6)     # every index carries its own score
+            masked = sims[idx[qi]] <= -2.0
+            assert (sc[qi][masked] == -2.0).all()
+    g.close()

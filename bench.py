@@ -336,9 +336,22 @@ def run_whitened(args, g, x, dev, L, iters):
     mfma_tiles = tiles * 36 + (tiles * (tiles - 1) // 2) * 64
     gram_flops = 2.0 * n * mfma_tiles * 256
     proj_flops = 2.0 * n * d * d
+    # the product's loop for this path (cleora_embed_dev, what cleora_amd.embed.embed() runs): SpMM(t+1) beside Gram / eigh(t)
+    del mid, nxt, ws, m_, p_, n_
+    torch.cuda.empty_cache()
+    xo = x[:n].clone()
+    loops = {}
+    for label, thr in (("overlapped", 0.0), ("sequential", 1e-30)):      # a never-met threshold keeps the reference's order
+        xo.copy_(x[:n])
+        _hip.check(L.cleora_embed_dev(gr.handle, xo.data_ptr(), _hip.LEFT, d, iters, 0.0, thr, _hip.F_WHITEN, None))
+        loops[label] = L.cleora_last_embed_loop_ms() / iters
+    prev = xo
     cov = torch.cov(prev[: min(n, 2_000_000)].double().T)
     out = {
-        "ms_per_iter": el / iters * 1e3, "iterations": iters, "iterations_per_sec": iters / el,
+        "ms_per_iter": loops["overlapped"], "iterations": iters, "iterations_per_sec": 1e3 / loops["overlapped"],
+        "loop": "cleora_embed_dev + CLEORA_F_WHITEN: SpMM of iteration t+1 beside Gram / eigensolver of iteration t "
+                "(the SpMM taken before the projection); ms_per_iter = loop wall clock / iterations, incl. the final whitening",
+        "sequential_ms_per_iter": {"c_loop_reference_order": loops["sequential"], "python_driven_with_stage_events": el / iters * 1e3},
         "placement_launch_ms": {"untuned": round(place_ms[0], 3), "chosen": round(place_ms[1], 3)},
         "kernels_ms": {"spmm_l2": ms[1] / max(c, 1) + (ms[0] + ms[2]) / max(c, 1), "column_statistics": stats_ms,
                        "gram_f64_mfma": gram_ms, "eigensolver_transform": eigh_ms, "project_f32_mfma": proj_ms},

@@ -96,6 +96,8 @@ SIGNATURES = {
     "cleora_init": (c_int, [vp, c_u64, c_u32, c_i64, vp]),
     "cleora_embed": (c_int, [vp, vp, vp, c_int, c_u32, c_u64, c_i64, c_f32, c_f32, c_u32, vp,
                              ctypes.POINTER(c_u64)]),
+    "cleora_last_embed_loop_ms": (ctypes.c_double, []),
+    "cleora_embed_dev": (c_int, [vp, vp, c_int, c_u32, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),
 }
 
 _lib = None

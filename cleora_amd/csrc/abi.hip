@@ -2,6 +2,8 @@
 // argument checking, graph handles, and the host-pointer entry points that the
 // reference's PyO3 methods (src/lib.rs) would call through FFI.
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -11,6 +13,7 @@
 namespace cleora {
 
 static thread_local std::string g_last_error;
+static thread_local double g_last_loop_ms = 0.0;   // iteration loop of the last cleora_embed* on this thread
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 
@@ -160,6 +163,8 @@ extern "C" {
 int cleora_abi_version(void) { return CLEORA_ABI_VERSION; }
 
 const char *cleora_last_error(void) { return g_last_error.c_str(); }
+
+double cleora_last_embed_loop_ms(void) { return g_last_loop_ms; }
 
 int cleora_device_count(int *count) {
     CL_REQUIRE(count != nullptr, "count is NULL");
@@ -659,6 +664,94 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
 }
 
 namespace {
+// The default loop of pycleora.embed() — E <- whiten(normalise(A E)), pycleora/__init__.py:109-117 — with the SpMM of
+// iteration t+1 running BESIDE the statistics and the eigensolver of iteration t.
+//
+// In the reference's order every step waits for the previous one: SpMM (HBM-bound) -> normalise -> Gram (MFMA-bound)
+// -> eigh (latency-bound) -> projection.  The SpMM is linear, so it can be taken before the projection:
+//     E' = (Y - 1 mu^T) T            the whitened iterate (Y = the normalised rows, mu / T their mean / transform)
+//     A E' = (A Y - s mu^T) T        with s = A 1 (the stored row sums; 1 for a row-stochastic left Markov matrix)
+// i.e. Z = A Y needs only Y and runs on its own stream while Gram(Y) and eigh produce mu and T on another; the
+// projection then takes the operand  alpha (Z - s mu^T) + rw (Y - 1 mu^T)  (the residual blend, :114-115, is linear too)
+// and its output rows are normalised: that is Y of the next iteration.  E itself is only formed at the end.
+// Same operations as the reference, one of them moved across a linear step: results agree to f32 rounding (the f32
+// GEMM sees Z instead of A's input; tests carry the same tolerances as for the sequential loop).  Used when nobody
+// needs the intermediate whitened iterates (no convergence test here; the Python driver keeps callbacks sequential).
+//   b0 = the SpMM's destination in every launch (cleora_alloc_iterates' bufs[0]); b1 / b2 hold Y in turn.
+int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float *b2, int markov_type, uint32_t d,
+                              uint64_t iterations, float rw, uint32_t flags, float **result) {
+    const uint64_t n = g->n_rows;
+    const uint32_t norm = (flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM;
+    const uint32_t fast = flags & CLEORA_F_FASTNORM;
+    const bool blend = rw > 0.0f;                                          // the Python loop: any rw > 0 (:111-115)
+    int rc;
+    if (iterations == 0) { *result = b0; return CLEORA_OK; }
+    DevBuf ws, rowsum;
+    if ((rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK) return rc;
+    if ((rc = rowsum.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
+    struct Streams {
+        hipStream_t a = nullptr, b = nullptr;
+        hipEvent_t ya = nullptr, fb = nullptr;
+        ~Streams() {
+            if (a) (void)hipStreamDestroy(a);
+            if (b) (void)hipStreamDestroy(b);
+            if (ya) (void)hipEventDestroy(ya);
+            if (fb) (void)hipEventDestroy(fb);
+        }
+    } st;
+    CL_HIP(hipStreamCreateWithFlags(&st.a, hipStreamNonBlocking));
+    CL_HIP(hipStreamCreateWithFlags(&st.b, hipStreamNonBlocking));
+    CL_HIP(hipEventCreateWithFlags(&st.ya, hipEventDisableTiming));
+    CL_HIP(hipEventCreateWithFlags(&st.fb, hipEventDisableTiming));
+    CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
+    const auto t_loop = std::chrono::steady_clock::now();
+    if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a)) != CLEORA_OK) return rc;
+    // Y_0 = normalise(A E_0 [+ blend]): the ordinary fused launch
+    if ((rc = launch_propagate(g, markov_type, b0, d, d, b1, d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, b0,
+                               nullptr, nullptr, st.a)) != CLEORA_OK)
+        return rc;
+    float *y = b1, *ynext = b2;
+    const float *mean32, *transform;
+    whiten_fit_result(ws.p, n, d, &mean32, &transform);
+    for (uint64_t it = 0; it + 1 < iterations; ++it) {
+        CL_HIP(hipEventRecord(st.ya, st.a));                               // Y is complete
+        CL_HIP(hipStreamWaitEvent(st.b, st.ya, 0));
+        // stream b: mean, covariance, eigensolver of Y (MFMA / latency bound) ...
+        if (n > 1 && (rc = launch_whiten_fit(y, d, n, d, d, ws.p, nullptr, st.b)) != CLEORA_OK) return rc;
+        CL_HIP(hipEventRecord(st.fb, st.b));
+        // ... stream a, at the same time: Z = A Y (HBM bound), no epilogue
+        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+        CL_HIP(hipStreamWaitEvent(st.a, st.fb, 0));
+        if (n > 1) {
+            // P = (alpha (Z - s mu^T) + rw (Y - mu)) T, then the row normalisation: Y of the next iteration
+            rc = launch_project(b0, d, n, d, mean32, transform, d, ynext, d, st.a, rowsum.as<float>(), blend ? y : nullptr, d,
+                                1.0f - rw, rw);
+            if (rc != CLEORA_OK) return rc;
+            if ((rc = launch_rowops(ynext, d, n, d, ynext, d, norm | fast, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+        } else {
+            // one entity: whiten_embeddings returns its input (:132-133), so E' = Y and the next Y = normalise(A Y [+ blend])
+            if ((rc = launch_rowops(b0, d, n, d, ynext, d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, y, nullptr, nullptr, st.a)) != CLEORA_OK)
+                return rc;
+        }
+        std::swap(y, ynext);
+    }
+    // E_T = whiten(Y_{T-1})
+    if ((rc = launch_whiten(y, d, n, d, d, b0, d, ws.p, nullptr, st.a)) != CLEORA_OK) return rc;
+    CL_HIP(hipStreamSynchronize(st.a));
+    CL_HIP(hipStreamSynchronize(st.b));
+    g_last_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
+    if (n > 1) {
+        int info = 0;
+        CL_HIP(hipMemcpy(&info, whiten_info(ws.p, n, d), sizeof(int), hipMemcpyDeviceToHost));
+        if (info != 0) {
+            set_error("the eigensolver did not converge (dsyevd info = " + std::to_string(info) + ")");
+            return CLEORA_E_HIP;
+        }
+    }
+    *result = b0;
+    return CLEORA_OK;
+}
+
 // The default path of pycleora.embed() (pycleora/__init__.py:97-127): propagate, residual, _normalize,
 // whiten_embeddings, f64 RMSE between whitened iterates.  Three buffers rotate: prev -> (SpMM + L2) -> mid
 // -> (whiten) -> next.
@@ -676,6 +769,8 @@ int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int mark
         return rc;
     float *prev = a, *mid = b, *next = c;
     uint64_t actual = max_iterations;
+    CL_HIP(hipDeviceSynchronize());
+    const auto t_loop = std::chrono::steady_clock::now();
     // the Python loop blends for any rw > 0 (pycleora/__init__.py:111-115) and normalises with `normalization`
     const uint32_t base = ((flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM) | CLEORA_F_RESIDUAL |
                           CLEORA_F_BLEND_ANY | (flags & CLEORA_F_FASTNORM);
@@ -697,6 +792,8 @@ int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int mark
         }
         std::swap(prev, next);
     }
+    CL_HIP(hipDeviceSynchronize());
+    g_last_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     if (n > 1 && max_iterations > 0) {
         int info = 0;
         CL_HIP(hipMemcpy(&info, whiten_info(ws.p, n, d), sizeof(int), hipMemcpyDeviceToHost));
@@ -711,16 +808,26 @@ int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int mark
 }
 }  // namespace
 
-int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
-                 int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
-                 float residual_weight, float convergence_threshold, uint32_t flags,
-                 float *out_host, uint64_t *iterations_run) {
+}  // extern "C"
+
+// The loops behind cleora_embed (host arrays) and cleora_embed_dev (x_dev: E_0 in, result out, device memory).
+static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host, float *x_dev,
+                      int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
+                      float residual_weight, float convergence_threshold, uint32_t flags,
+                      float *out_host, uint64_t *iterations_run) {
     CL_REQUIRE(g != nullptr, "graph handle is NULL");
     CL_REQUIRE(g->n_rows == g->n_cols, "cleora_embed needs the whole (square) graph on one device");
-    CL_REQUIRE(out_host != nullptr, "out is NULL");
-    CL_REQUIRE(entity_hash_host != nullptr || x0_host != nullptr, "need entity hashes or x0");
+    CL_REQUIRE(out_host != nullptr || x_dev != nullptr, "out is NULL");
+    CL_REQUIRE(entity_hash_host != nullptr || x0_host != nullptr || x_dev != nullptr, "need entity hashes or x0");
     CL_REQUIRE(d > 0, "d must be positive");
     CL_HIP(hipSetDevice(g->device));
+    auto emit = [&](const float *result, uint64_t nbytes) -> int {
+        if (x_dev) {
+            CL_HIP(hipMemcpy(x_dev, result, nbytes, hipMemcpyDeviceToDevice));
+            return CLEORA_OK;
+        }
+        return staged_d2h(out_host, result, nbytes, nullptr);
+    };
     const uint64_t n = g->n_rows;
     const uint64_t bytes = n * (uint64_t)d * sizeof(float);
     const bool check = convergence_threshold > 0.0f;  // embedding.rs:150
@@ -738,19 +845,32 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
     } else if ((rc = a.alloc(bytes)) != CLEORA_OK || (rc = b.alloc(bytes)) != CLEORA_OK) {
         return rc;
     }
-    if (x0_host) {
-        if ((rc = staged_h2d(a.p, x0_host, bytes, nullptr)) != CLEORA_OK) return rc;
+    // nobody looks at the intermediate whitened iterates when there is no convergence test: SpMM(t+1) beside Gram /
+    // eigh(t) (embed_whitened_overlapped).  That loop wants E_0 in the SpMM-side buffer bufs[0] = `b`.
+    static const bool sequential_only = std::getenv("CLEORA_WHITEN_SEQUENTIAL") != nullptr;   // A/B switch
+    const bool overlapped = whitened && !check && !sequential_only;
+    float *e_init = overlapped ? b.as<float>() : a.as<float>();
+    if (x_dev) {
+        CL_HIP(hipMemcpy(e_init, x_dev, bytes, hipMemcpyDeviceToDevice));
+    } else if (x0_host) {
+        if ((rc = staged_h2d(e_init, x0_host, bytes, nullptr)) != CLEORA_OK) return rc;
     } else {
         if ((rc = h.alloc(n * sizeof(uint64_t))) != CLEORA_OK) return rc;
         CL_HIP(hipMemcpy(h.p, entity_hash_host, n * sizeof(uint64_t), hipMemcpyHostToDevice));
-        if ((rc = launch_init(h.as<uint64_t>(), n, d, seed, a.as<float>(), d, nullptr)) != CLEORA_OK) return rc;
+        if ((rc = launch_init(h.as<uint64_t>(), n, d, seed, e_init, d, nullptr)) != CLEORA_OK) return rc;
     }
     if (whitened) {
         float *result = nullptr;
-        rc = embed_whitened(g, a.as<float>(), b.as<float>(), c.as<float>(), markov_type, d, max_iterations,
-                            residual_weight, convergence_threshold, flags, &result, iterations_run);
+        if (overlapped) {
+            rc = embed_whitened_overlapped(g, b.as<float>(), a.as<float>(), c.as<float>(), markov_type, d, max_iterations,
+                                           residual_weight, flags, &result);
+            if (rc == CLEORA_OK && iterations_run) *iterations_run = max_iterations;
+        } else {
+            rc = embed_whitened(g, a.as<float>(), b.as<float>(), c.as<float>(), markov_type, d, max_iterations,
+                                residual_weight, convergence_threshold, flags, &result, iterations_run);
+        }
         if (rc != CLEORA_OK) return rc;
-        return staged_d2h(out_host, result, bytes, nullptr);
+        return emit(result, bytes);
     }
     if (check) {
         if ((rc = sq.alloc(n * sizeof(double))) != CLEORA_OK ||
@@ -784,6 +904,8 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
     float *src = fixed, *dst = partner;
     uint64_t actual = max_iterations;
     const uint32_t base = CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | (flags & CLEORA_F_FASTNORM);
+    CL_HIP(hipDeviceSynchronize());
+    const auto t_loop = std::chrono::steady_clock::now();
     for (uint64_t it = 0; it < max_iterations; ++it) {
         const bool test = check && it > 0;  // embedding.rs:169
         if (tuning) CL_HIP(hipEventRecord(ev0, nullptr));
@@ -851,8 +973,29 @@ int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const 
             dst = partner;
         }
     }
+    CL_HIP(hipDeviceSynchronize());
+    g_last_loop_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count();
     if (iterations_run) *iterations_run = actual;
-    return staged_d2h(out_host, src, bytes, nullptr);
+    return emit(src, bytes);
+}
+
+extern "C" {
+
+int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
+                 int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
+                 float residual_weight, float convergence_threshold, uint32_t flags,
+                 float *out_host, uint64_t *iterations_run) {
+    CL_REQUIRE(out_host != nullptr, "out is NULL");
+    CL_REQUIRE(entity_hash_host != nullptr || x0_host != nullptr, "need entity hashes or x0");
+    return embed_impl(g, entity_hash_host, x0_host, nullptr, markov_type, d, max_iterations, seed, residual_weight,
+                      convergence_threshold, flags, out_host, iterations_run);
+}
+
+int cleora_embed_dev(const cleora_graph *g, float *x_dev, int markov_type, uint32_t d, uint64_t max_iterations,
+                     float residual_weight, float convergence_threshold, uint32_t flags, uint64_t *iterations_run) {
+    CL_REQUIRE(x_dev != nullptr, "x is NULL");
+    return embed_impl(g, nullptr, nullptr, x_dev, markov_type, d, max_iterations, 0, residual_weight, convergence_threshold,
+                      flags, nullptr, iterations_run);
 }
 
 }  // extern "C"

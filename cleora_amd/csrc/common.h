@@ -111,6 +111,7 @@ int launch_reduce_sum(const double *v, uint64_t n, double *ws, double *out, hipS
 uint64_t colsum_workspace(uint64_t n, uint32_t d);
 int launch_colsum(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *ws, double *out,
                   hipStream_t stream);
+int launch_csr_rowsum(const cleora_graph *g, int kind, float *out, hipStream_t stream);
 int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *q, float *scores,
                   hipStream_t stream);
 // whiten.hip
@@ -118,8 +119,11 @@ uint64_t gram_workspace(uint64_t n, uint32_t d);
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
                 double *ws, double *gram, hipStream_t stream, double *mean_out64 = nullptr,
                 float *mean_out32 = nullptr);   // outputs given: `mean` is only a shift, the exact mean is produced
+// out = (alpha * (x - rowscale (x) mean) + beta * (x2 - mean)) @ t; rowscale / x2 == nullptr: the plain (x - mean) @ t
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
-                   const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream);
+                   const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
+                   const float *rowscale = nullptr, const float *x2 = nullptr, uint64_t ldx2 = 0, float alpha = 1.0f,
+                   float beta = 0.0f);
 
 // similarity.hip
 uint64_t topk_workspace_bytes(uint64_t n, uint32_t k);
@@ -145,5 +149,10 @@ int whiten_set_timing(bool enable);
 int whiten_get_timing(double ms[4], uint64_t *calls);
 int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
                   void *workspace, double *eigenvalues, hipStream_t stream);
+// the two halves of launch_whiten: statistics + eigensolver (leaves mean32 and the d x k transform in the workspace) ...
+int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
+                      double *eigenvalues, hipStream_t stream);
+// ... and their location, for a projection launched separately (launch_project)
+void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform);
 
 }  // namespace cleora

@@ -261,20 +261,10 @@ const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
     return carve_transform(w.eigh, d).info;
 }
 
-int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
-                  void *workspace, double *eigenvalues, hipStream_t stream) {
-    CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
-    if (n == 0) return CLEORA_OK;
-    CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
-    CL_REQUIRE((const void *)x != (const void *)y, "x and y must not alias");
-    if (n == 1) {                                 // `if n <= 1: return embeddings.copy()`   (:132-133)
-        CL_REQUIRE(ldy >= d, "one row is returned unchanged: y needs d columns");
-        CL_HIP(hipMemcpyAsync(y, x, (uint64_t)d * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        return CLEORA_OK;
-    }
-    if (k == 0 || k > d) k = d;                   // n_components=None, or >= d             (:151)
-    CL_REQUIRE(ldy >= k, "bad output leading dimension");
-    CL_REQUIRE(workspace != nullptr, "workspace is NULL");
+int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
+                      double *eigenvalues, hipStream_t stream) {
+    CL_REQUIRE(d > 0 && ldx >= d && n >= 2 && k >= 1 && k <= d, "bad shape");
+    CL_REQUIRE(x != nullptr && workspace != nullptr, "x / workspace is NULL");
     WhitenWs w;
     whiten_ws_layout(n, d, workspace, &w);
     int rc;
@@ -291,7 +281,35 @@ int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t
     wt_mark(stream);
     if ((rc = launch_whiten_transform(w.gram, n, d, k, w.transform, eigenvalues, w.eigh, stream)) != CLEORA_OK) return rc;
     wt_mark(stream);
-    rc = launch_project(x, ldx, n, d, w.mean32, w.transform, k, y, ldy, stream);
+    return CLEORA_OK;
+}
+
+void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform) {
+    WhitenWs w;
+    whiten_ws_layout(n, d, workspace, &w);
+    *mean32 = w.mean32;
+    *transform = w.transform;
+}
+
+int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,
+                  void *workspace, double *eigenvalues, hipStream_t stream) {
+    CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
+    if (n == 0) return CLEORA_OK;
+    CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
+    CL_REQUIRE((const void *)x != (const void *)y, "x and y must not alias");
+    if (n == 1) {                                 // `if n <= 1: return embeddings.copy()`   (:132-133)
+        CL_REQUIRE(ldy >= d, "one row is returned unchanged: y needs d columns");
+        CL_HIP(hipMemcpyAsync(y, x, (uint64_t)d * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        return CLEORA_OK;
+    }
+    if (k == 0 || k > d) k = d;                   // n_components=None, or >= d             (:151)
+    CL_REQUIRE(ldy >= k, "bad output leading dimension");
+    CL_REQUIRE(workspace != nullptr, "workspace is NULL");
+    int rc = launch_whiten_fit(x, ldx, n, d, k, workspace, eigenvalues, stream);
+    if (rc != CLEORA_OK) return rc;
+    const float *mean32, *transform;
+    whiten_fit_result(workspace, n, d, &mean32, &transform);
+    rc = launch_project(x, ldx, n, d, mean32, transform, k, y, ldy, stream);
     wt_mark(stream);
     return rc;
 }

@@ -324,7 +324,18 @@ struct ProjArgs {
     uint32_t nb_n;    // column blocks
     uint64_t n_blocks;
     int w4x, w4t;
+    // generalised centring (the propagate-before-project form of the embed loop, abi.hip): the operand row is
+    //   alpha * (x[r] - rowscale[r] * mean) + beta * (x2[r] - mean)
+    // rowscale == nullptr: scale 1; x2 == nullptr: no second term (alpha is then 1): the plain (x - mean).
+    const float *rowscale;
+    const float *x2;
+    uint64_t ldx2;
+    float alpha, beta;
 };
+
+__device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
+    return scaled ? __fsub_rn(v, __fmul_rn(s, mu)) : __fsub_rn(v, mu);
+}
 
 __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     __shared__ __attribute__((aligned(16))) float As[PM][PLA];
@@ -349,14 +360,23 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     // loader roles
     const int ac4 = t & 7, ar = t >> 3;    // A: cols ac4*4.., rows ar + 32 i
     const int bc4 = t & 31, br = t >> 5;   // B: cols bc4*4.., rows br + 8 i
-    float4 pa[4], pb[4];
+    float4 pa[4], pb[4], pa2[4];
     bool aok[4];
+    float rs[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.rowscale) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t r = m0 + ar + 32 * i;
+            rs[i] = r < a.n ? a.rowscale[r] : 1.f;
+        }
+    }
     auto prefetch = [&](uint32_t k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint64_t r = m0 + ar + 32 * i;
             aok[i] = r < a.n;
             pa[i] = load4(a.x + r * a.ldx, k0 + ac4 * 4, a.d, aok[i], a.w4x);
+            if (a.x2) pa2[i] = load4(a.x2 + r * a.ldx2, k0 + ac4 * 4, a.d, aok[i], a.w4x);
             const uint32_t kr = k0 + br + 8 * i;
             pb[i] = load4(a.t + (uint64_t)kr * a.k, n0 + bc4 * 4, a.k, kr < a.d, a.w4t);
         }
@@ -371,11 +391,14 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v[4] = {pa[i].x, pa[i].y, pa[i].z, pa[i].w};
+            const float v2[4] = {pa2[i].x, pa2[i].y, pa2[i].z, pa2[i].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t c = k0 + ac4 * 4 + q;
                 // block = embeddings[i:end] - mean_f32   (f32)          (pycleora/__init__.py:161)
-                As[ar + 32 * i][ac4 * 4 + q] = (aok[i] && c < a.d) ? __fsub_rn(v[q], mu[q]) : 0.f;
+                float o = centre(v[q], mu[q], rs[i], a.rowscale != nullptr);
+                if (a.x2) o = __fadd_rn(__fmul_rn(a.alpha, o), __fmul_rn(a.beta, __fsub_rn(v2[q], mu[q])));
+                As[ar + 32 * i][ac4 * 4 + q] = (aok[i] && c < a.d) ? o : 0.f;
             }
             *reinterpret_cast<float4 *>(&Bs[br + 8 * i][bc4 * 4]) = pb[i];
         }
@@ -448,19 +471,33 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
             float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c0 + c < d) mu = *reinterpret_cast<const float4 *>(a.mean + c0 + c);
             for (int r = w; r < RM; r += 4 * 4) {
-                float4 v[4];
+                float4 v[4], v2[4];
+                float s[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint64_t row = m0 + r + 4 * u;
-                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row < a.n && c0 + c < d && r + 4 * u < RM) v[u] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + c0 + c);
+                    const bool ok = row < a.n && c0 + c < d && r + 4 * u < RM;
+                    v[u] = v2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    s[u] = 1.f;
+                    if (ok) v[u] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + c0 + c);
+                    if (ok && a.x2) v2[u] = *reinterpret_cast<const float4 *>(a.x2 + row * a.ldx2 + c0 + c);
+                    if (ok && a.rowscale) s[u] = a.rowscale[row];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint64_t row = m0 + r + 4 * u;
                     if (c0 + c < d && r + 4 * u < RM) {
                         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row < a.n) o = make_float4(__fsub_rn(v[u].x, mu.x), __fsub_rn(v[u].y, mu.y), __fsub_rn(v[u].z, mu.z), __fsub_rn(v[u].w, mu.w));
+                        if (row < a.n) {
+                            const bool sc = a.rowscale != nullptr;
+                            o = make_float4(centre(v[u].x, mu.x, s[u], sc), centre(v[u].y, mu.y, s[u], sc),
+                                            centre(v[u].z, mu.z, s[u], sc), centre(v[u].w, mu.w, s[u], sc));
+                            if (a.x2)
+                                o = make_float4(__fadd_rn(__fmul_rn(a.alpha, o.x), __fmul_rn(a.beta, __fsub_rn(v2[u].x, mu.x))),
+                                                __fadd_rn(__fmul_rn(a.alpha, o.y), __fmul_rn(a.beta, __fsub_rn(v2[u].y, mu.y))),
+                                                __fadd_rn(__fmul_rn(a.alpha, o.z), __fmul_rn(a.beta, __fsub_rn(v2[u].z, mu.z))),
+                                                __fadd_rn(__fmul_rn(a.alpha, o.w), __fmul_rn(a.beta, __fsub_rn(v2[u].w, mu.w))));
+                        }
                         *reinterpret_cast<float4 *>(&xs[(r + 4 * u) * lds + c0 + c]) = o;
                     }
                 }
@@ -604,13 +641,20 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 }
 
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
-                   const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream) {
+                   const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
+                   const float *rowscale, const float *x2, uint64_t ldx2, float alpha, float beta) {
     CL_REQUIRE(d > 0 && k > 0 && ldx >= d && ldo >= k, "bad d / k / leading dimension");
     CL_REQUIRE(x != nullptr && mean != nullptr && t != nullptr && out != nullptr,
                "x / mean / transform / out is NULL");
-    CL_REQUIRE((const void *)x != (const void *)out, "x and out must not alias");
+    CL_REQUIRE((const void *)x != (const void *)out && (const void *)x2 != (const void *)out, "x and out must not alias");
+    CL_REQUIRE(x2 == nullptr || ldx2 >= d, "bad leading dimension of the second operand");
     if (n == 0) return CLEORA_OK;
     ProjArgs a{};
+    a.rowscale = rowscale;
+    a.x2 = x2;
+    a.ldx2 = ldx2;
+    a.alpha = x2 ? alpha : 1.0f;
+    a.beta = beta;
     a.x = x;
     a.ldx = ldx;
     a.n = n;
@@ -621,7 +665,7 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.out = out;
     a.ldo = ldo;
     a.nb_n = (k + PN - 1) / PN;
-    a.w4x = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
+    a.w4x = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && (!x2 || (ldx2 % 4 == 0 && aligned16(x2)));
     a.w4t = (k % 4 == 0) && aligned16(t);
     // rows-in-LDS form: whole rows as float4, reduction index in groups of 8, the X tile within the LDS budget
     static const bool first_form_only = std::getenv("CLEORA_PROJECT_TILED") != nullptr;   // A/B switch for profiling

@@ -137,6 +137,18 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
     if n == 0 or d == 0 or num_iterations <= 0:
         return x0
 
+    if whiten and callback is None and normalization in ("l2", "l1"):
+        # the default loop as ONE C-ABI call (cleora_embed + CLEORA_F_WHITEN): nobody looks at the intermediate
+        # iterates, so the library may run the SpMM of iteration t+1 beside the Gram / eigensolver of iteration t
+        out = np.empty((n, d), np.float32)
+        ran = ctypes.c_uint64(0)
+        flags = _hip.F_WHITEN | (_hip.F_L1NORM if normalization == "l1" else 0)
+        with graph._lock:
+            _hip.check(L.cleora_embed(graph._graph().handle, None, _hip.ptr(x0), kind, d, int(num_iterations), 0,
+                                      float(residual_weight), float(max(convergence_threshold, 0.0)), flags,
+                                      _hip.ptr(out), ctypes.byref(ran)))
+        return out
+
     with graph._lock:
         return _device_loop(graph._graph(), n, x0, kind, int(num_iterations), normalization, callback,
                             float(residual_weight), float(convergence_threshold), whiten)

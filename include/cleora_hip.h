@@ -326,14 +326,27 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
  * Device-resident loop: init (or x0_host if non-NULL), `max_iterations` x (SpMM, residual for
  * 0 < rw < 1, L2), optional RMSE early stop (threshold > 0, from iteration 1).
  * The graph must be square (n_rows == n_cols).  out_host: n x d.  iterations_run may be NULL.
+ * The iterate buffers are placed for the SpMM (cleora_alloc_iterates; the plain loop searches on its own iterations).
  * With CLEORA_F_WHITEN in `flags` the loop is the default path of pycleora.embed() instead
  * (pycleora/__init__.py:97-127 with _postprocess_iteration :963-971): every iteration is SpMM, residual blend for
  * ANY rw > 0 (:111-115 — unlike the Rust loop's 0 < rw < 1), L2 normalise (L1 with CLEORA_F_L1NORM), THEN
- * whiten_embeddings; the RMSE of the early stop is taken between whitened iterates in f64 (:122-125, :974-976). */
+ * whiten_embeddings; the RMSE of the early stop is taken between whitened iterates in f64 (:122-125, :974-976).
+ * Without a convergence test nobody sees the intermediate whitened iterates, and the SpMM of iteration t+1 runs BESIDE
+ * the Gram matrix and eigensolver of iteration t on a second stream: the SpMM is linear, so A ((Y - 1 mu^T) T) is taken as
+ * (A Y - (A 1) mu^T) T — the same operations with one of them moved across a linear step; results agree with the
+ * sequential order to f32 rounding (CLEORA_WHITEN_SEQUENTIAL=1 in the environment keeps the sequential order). */
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,
                  float *out_host, uint64_t *iterations_run);
+
+/* The same loops on a DEVICE-resident iterate: x_dev (n x d, ld = d) holds the initial embeddings on entry and the
+ * result on return; nothing crosses PCIe.  Synchronous (returns when the result is in place). */
+/* Wall-clock milliseconds of the ITERATION LOOP of the last cleora_embed / cleora_embed_dev on the calling thread —
+ * without the allocations, the placement search and the copies around it (for throughput reporting). */
+double cleora_last_embed_loop_ms(void);
+int cleora_embed_dev(const cleora_graph *g, float *x_dev, int markov_type, uint32_t d, uint64_t max_iterations,
+                     float residual_weight, float convergence_threshold, uint32_t flags, uint64_t *iterations_run);
 
 #ifdef __cplusplus
 }

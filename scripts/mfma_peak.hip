@@ -83,6 +83,38 @@ __global__ __launch_bounds__(256) void k_f64_clock(double *out, int iters, doubl
     if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = w1 - w0; }
 }
 
+// Do the f64 matrix instruction and the f64 vector FMA share one datapath?  512-thread blocks, one per CU: waves 0-3
+// run the MFMA loop, waves 4-7 the v_fma_f64 loop (both halves land on all four SIMDs), each for a fixed number of
+// instructions; flops of both halves over the kernel's duration.
+__global__ __launch_bounds__(512) void k_mixed64(double *out, int it_mfma, int it_valu, double a0, double b0) {
+    const int w = threadIdx.x >> 6;
+    double s = 0;
+    if (w < 4) {
+        d4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (d4){0, 0, 0, 0};
+        const double a = a0 + threadIdx.x * 1e-9, b = b0;
+        for (int it = 0; it < it_mfma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-3 + i;
+        const double a = 1.0000001 + threadIdx.x * 1e-9, b = b0 * 1e-3;
+        for (int it = 0; it < it_valu; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[i];
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <class K, class T>
 double run(K kernel, int blocks, int iters, T *out, T a, T b) {
     hipEvent_t e0, e1;
@@ -137,6 +169,28 @@ int main() {
                mf * 2048.0 / (ms16 * 1e-3) / 1e12, mf * 2048.0 / (ms4 * 1e-3) / 1e12);
         const double msv = run(k_valu64<16>, blocks, iters * 4, (double *)buf, 1.0000001, 0.5);
         printf("f64 v_fma    %d wave(s)/SIMD: %7.2f TFLOP/s\n", bpc, (double)blocks * 256 * iters * 4 * 16 * 2.0 / (msv * 1e-3) / 1e12);
+    }
+    {
+        // each half sized to ~the same time when alone (47 TF vs 58 TF): mfma 8192 flops / (4 acc) per iteration per wave,
+        // valu 64 lanes * 16 * 2 = 2048 flops per iteration per wave
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int mode = 0; mode < 3; ++mode) {
+            const int itm = mode == 1 ? 0 : 40000, itv = mode == 0 ? 0 : 200000;
+            hipLaunchKernelGGL(k_mixed64, dim3(cus), dim3(512), 0, 0, (double *)buf, itm / 8, itv / 8, 1.0, 0.5);
+            hipDeviceSynchronize();
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_mixed64, dim3(cus), dim3(512), 0, 0, (double *)buf, itm, itv, 1.0, 0.5);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double fm = (double)cus * 4 * itm * 4 * 2048.0, fv = (double)cus * 4 * 64 * itv * 16 * 2.0;
+            printf("f64 mixed (%s): %8.3f ms   mfma %6.2f + v_fma %6.2f = %6.2f TFLOP/s\n",
+                   mode == 0 ? "mfma half only" : mode == 1 ? "v_fma half only" : "both halves", ms, fm / (ms * 1e-3) / 1e12,
+                   fv / (ms * 1e-3) / 1e12, (fm + fv) / (ms * 1e-3) / 1e12);
+        }
     }
     unsigned long long *ticks;
     hipMalloc(&ticks, 16);

@@ -180,3 +180,42 @@ def test_cleora_whiten_errors_and_single_row():
     ws = _hip.DevArray((L.cleora_whiten_workspace(4, 8),), np.uint8)
     with pytest.raises(ValueError, match="alias"):
         _hip.check(L.cleora_whiten_dev(dx.ptr, 8, 4, 8, 0, dx.ptr, 8, ws.ptr, None, None))
+
+
+@pytest.mark.parametrize("n,d,iters,rw,kind", [(20_000, 64, 6, 0.0, 0), (6000, 256, 4, 0.3, 1), (3000, 32, 5, 1.5, 0)])
+def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, kind):
+    """cleora_embed + CLEORA_F_WHITEN without a convergence test runs SpMM(t+1) beside Gram / eigh(t), taking the SpMM
+    before the projection (A ((Y - mu) T) = (A Y - (A 1) mu^T) T).  With a (never met) convergence threshold the same
+    call keeps the reference's sequential order: both must agree to f32 rounding — columns up to sign, 2e-3 relative
+    after several whitenings, and the pairwise cosines of a row sample to 1e-4.  Also against the numpy oracle loop."""
+    import ctypes
+    from tests.graphs import random_csr
+    import oracle
+    rowptr, col, vl, vs = random_csr(n, 9, seed=n + d, empty_frac=0.02, hubs=[(13, 1400)])
+    g = _hip.Graph.from_host(rowptr, col, vl, vs)
+    x0 = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+    L = _hip.lib()
+    outs = []
+    for thr in (0.0, 1e-30):
+        out = np.empty((n, d), np.float32)
+        ran = ctypes.c_uint64(0)
+        _hip.check(L.cleora_embed(g.handle, None, _hip.ptr(x0), kind, d, iters, 0, rw, thr, _hip.F_WHITEN, _hip.ptr(out),
+                                  ctypes.byref(ran)))
+        assert ran.value == iters
+        outs.append(out)
+    a, b = outs
+    assert np.isfinite(a).all()
+    a = sign_align(a, b)
+    assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max()
+    rows = np.random.default_rng(1).choice(n, 400, replace=False)
+    cos = lambda e: (lambda u: u @ u.T)(e[rows].astype(np.float64) / np.linalg.norm(e[rows].astype(np.float64), axis=1, keepdims=True))
+    assert np.abs(cos(a) - cos(b)).max() < 1e-4
+    # the same loop through the device-pointer entry point
+    dx = _hip.DevArray.from_host(x0)
+    _hip.check(L.cleora_embed_dev(g.handle, dx.ptr, kind, d, iters, rw, 0.0, _hip.F_WHITEN, None))
+    np.testing.assert_array_equal(dx.to_host(), outs[0])
+    if rw < 1.0 and rw == 0.0:
+        val = vl if kind == 0 else vs
+        want, _ = ow.embed_slow(lambda v: oracle.spmm(rowptr, col, val, v), x0, iters, whiten=True)
+        assert np.abs(cos(outs[0]) - cos(want)).max() < 1e-3
+    g.close()

@@ -99,3 +99,57 @@ def test_c_host_whitened_loop(tmp_path):
     got, want = read_tsv(out)[1], dev_embed.embed(g, 8, 4)
     got = got * np.sign((got * want).sum(axis=0))
     assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max()
+
+
+SHARDED = os.path.join(ROOT, "examples", "sharded_embed")
+
+
+def _graph_file(tmp_path, seed):
+    edges = tmp_path / "edges.tsv"
+    rng = np.random.default_rng(seed)
+    lines = LINES + [" ".join(f"n{int(v)}" for v in rng.integers(0, 200, rng.integers(2, 6))) for _ in range(900)]
+    edges.write_text("\n".join(lines) + "\n")
+    return edges
+
+
+@pytest.mark.gpu
+def test_c_host_row_partitioned_loop_world1(tmp_path):
+    """examples/sharded_embed.c: north_star's row-partitioned loop (row blocks, replicas of X, in-place all-gather over
+    the C-ABI communicator, communication stream beside the compute stream) from plain C — one rank here, so RCCL,
+    the streams and the block arithmetic run for real on the one GPU; equals embed_fast bit for bit."""
+    from cleora_amd.pycleora import SparseMatrix
+    build_example()
+    edges = _graph_file(tmp_path, 10)
+    g = SparseMatrix.from_files([str(edges)], "complex::reflexive::n")
+    env = {k: v for k, v in os.environ.items() if k not in ("CLEORA_ROCSOLVER", "CLEORA_RCCL")}
+    out = tmp_path / "o.tsv"
+    r = subprocess.run([SHARDED, "0", "1", str(tmp_path / "id"), "complex::reflexive::n", "32", "5", str(out), str(edges)],
+                       env=env, capture_output=True, text=True)
+    if r.returncode == 3:
+        pytest.skip("C host could not use the device / RCCL from a torch-free process: " + r.stderr.strip().splitlines()[-1])
+    assert r.returncode == 0, r.stderr
+    ids, got = read_tsv(out)
+    assert ids == g.entity_ids
+    np.testing.assert_array_equal(got, g.embed_fast(32, 5))
+
+
+@pytest.mark.gpu
+def test_c_host_row_partitioned_loop_two_gpus(tmp_path):
+    """Two processes, two GPUs, RCCL over the C ABI, the unique id through a file: equals the single-GPU result."""
+    from cleora_amd import _hip
+    from cleora_amd.pycleora import SparseMatrix
+    if _hip.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    build_example()
+    edges = _graph_file(tmp_path, 11)
+    g = SparseMatrix.from_files([str(edges)], "complex::reflexive::n")
+    env = {k: v for k, v in os.environ.items() if k not in ("CLEORA_ROCSOLVER", "CLEORA_RCCL")}
+    out = tmp_path / "o.tsv"
+    procs = [subprocess.Popen([SHARDED, str(r), "2", str(tmp_path / "id"), "complex::reflexive::n", "64", "6", str(out), str(edges)],
+                              env=env, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err
+    ids, got = read_tsv(out)
+    assert ids == g.entity_ids
+    np.testing.assert_array_equal(got, g.embed_fast(64, 6))

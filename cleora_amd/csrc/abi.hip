@@ -699,8 +699,14 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
             if (fb) (void)hipEventDestroy(fb);
         }
     } st;
-    CL_HIP(hipStreamCreateWithFlags(&st.a, hipStreamNonBlocking));
-    CL_HIP(hipStreamCreateWithFlags(&st.b, hipStreamNonBlocking));
+    // the statistics stream gets the higher priority (its few hundred resident blocks are dispatched at once; the SpMM's
+    // millions of short blocks fill what is left), and the Gram runs ONE block per CU there: at two it takes ~410 of
+    // the 512 registers of every SIMD and the SpMM beside it is left with a quarter of its occupancy
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    static const int co_blocks = std::getenv("CLEORA_GRAM_CO_BLOCKS") ? std::atoi(std::getenv("CLEORA_GRAM_CO_BLOCKS")) : 1;
+    CL_HIP(hipStreamCreateWithPriority(&st.a, hipStreamNonBlocking, prio_lo));
+    CL_HIP(hipStreamCreateWithPriority(&st.b, hipStreamNonBlocking, prio_hi));
     CL_HIP(hipEventCreateWithFlags(&st.ya, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&st.fb, hipEventDisableTiming));
     CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
@@ -717,7 +723,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
         CL_HIP(hipEventRecord(st.ya, st.a));                               // Y is complete
         CL_HIP(hipStreamWaitEvent(st.b, st.ya, 0));
         // stream b: mean, covariance, eigensolver of Y (MFMA / latency bound) ...
-        if (n > 1 && (rc = launch_whiten_fit(y, d, n, d, d, ws.p, nullptr, st.b)) != CLEORA_OK) return rc;
+        if (n > 1 && (rc = launch_whiten_fit(y, d, n, d, d, ws.p, nullptr, st.b, co_blocks)) != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(st.fb, st.b));
         // ... stream a, at the same time: Z = A Y (HBM bound), no epilogue
         if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;

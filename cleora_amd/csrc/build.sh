@@ -10,7 +10,10 @@ mkdir -p obj
 pids=()
 for f in spmm rowops whiten eigh hot attention comm stager similarity abi; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ ../../include/cleora_hip.h -nt obj/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o obj/$f.o &
+    # whiten.hip: MFMA accumulators in the VGPR form — hipcc otherwise parks loop-carried accumulators in VGPRs and copies
+    # them to AGPRs and back around every chunk of MFMAs (256 v_accvgpr moves per 64 MFMAs in the Gram kernel)
+    extra=""; [ $f = whiten ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+    hipcc $FLAGS $extra -c $f.hip -o obj/$f.o &
     pids+=($!)
   fi
 done

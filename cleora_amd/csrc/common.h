@@ -118,7 +118,8 @@ int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const fl
 uint64_t gram_workspace(uint64_t n, uint32_t d);
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
                 double *ws, double *gram, hipStream_t stream, double *mean_out64 = nullptr,
-                float *mean_out32 = nullptr);   // outputs given: `mean` is only a shift, the exact mean is produced
+                float *mean_out32 = nullptr,    // outputs given: `mean` is only a shift, the exact mean is produced
+                int blocks_per_cu = 2);
 // out = (alpha * (x - rowscale (x) mean) + beta * (x2 - mean)) @ t; rowscale / x2 == nullptr: the plain (x - mean) @ t
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
@@ -151,7 +152,7 @@ int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t
                   void *workspace, double *eigenvalues, hipStream_t stream);
 // the two halves of launch_whiten: statistics + eigensolver (leaves mean32 and the d x k transform in the workspace) ...
 int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
-                      double *eigenvalues, hipStream_t stream);
+                      double *eigenvalues, hipStream_t stream, int gram_blocks_per_cu = 2);
 // ... and their location, for a projection launched separately (launch_project)
 void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform);
 

@@ -262,7 +262,7 @@ const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
 }
 
 int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
-                      double *eigenvalues, hipStream_t stream) {
+                      double *eigenvalues, hipStream_t stream, int gram_blocks_per_cu) {
     CL_REQUIRE(d > 0 && ldx >= d && n >= 2 && k >= 1 && k <= d, "bad shape");
     CL_REQUIRE(x != nullptr && workspace != nullptr, "x / workspace is NULL");
     WhitenWs w;
@@ -277,7 +277,7 @@ int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint
     if ((rc = launch_colsum(x, ldx * stride, m, d, w.colsum_ws, w.colsum, stream)) != CLEORA_OK) return rc;
     if ((rc = launch_mean(w.colsum, m, d, w.shift64, w.mean32, stream)) != CLEORA_OK) return rc;
     wt_mark(stream);
-    if ((rc = launch_gram(x, ldx, n, d, w.shift64, w.gram_ws, w.gram, stream, w.mean64, w.mean32)) != CLEORA_OK) return rc;
+    if ((rc = launch_gram(x, ldx, n, d, w.shift64, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu)) != CLEORA_OK) return rc;
     wt_mark(stream);
     if ((rc = launch_whiten_transform(w.gram, n, d, k, w.transform, eigenvalues, w.eigh, stream)) != CLEORA_OK) return rc;
     wt_mark(stream);

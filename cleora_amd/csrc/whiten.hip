@@ -76,7 +76,10 @@ __constant__ unsigned char kDiagTiles[4][9][2] = {
     {{2, 5}, {2, 6}, {2, 7}, {3, 3}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {4, 4}},
     {{4, 5}, {4, 6}, {4, 7}, {5, 5}, {5, 6}, {5, 7}, {6, 6}, {6, 7}, {7, 7}}};
 
-template <bool DIAG>
+// FAST: d is a multiple of the 128-column tile and rows are float4-aligned — the loads carry no column checks and no
+// branches (rows past the slice are read from a clamped address and zeroed when staged), so the compiler keeps the
+// prefetch in flight behind counted waits instead of `s_waitcnt vmcnt(0)` after every guarded load.
+template <bool DIAG, bool FAST>
 __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DIAG ? 1 : 2][GKC][GLD],
                                           uint32_t bi, uint32_t bj, uint32_t pair) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -123,9 +126,15 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
         for (int h = 0; h < 2; ++h) {
             const uint64_t r = row0 + lr + 8 * h;
             ok[h] = r < r_end;
-            const float *rp = a.x + r * a.ldx;
-            pa[h] = load4(rp, colA, a.d, ok[h], a.w4);
-            if (!DIAG) pb[h] = load4(rp, colB, a.d, ok[h], a.w4);
+            if constexpr (FAST) {
+                const float *rp = a.x + (ok[h] ? r : r_begin) * a.ldx;      // always a valid row: no branch
+                pa[h] = *reinterpret_cast<const float4 *>(rp + colA);
+                if (!DIAG) pb[h] = *reinterpret_cast<const float4 *>(rp + colB);
+            } else {
+                const float *rp = a.x + r * a.ldx;
+                pa[h] = load4(rp, colA, a.d, ok[h], a.w4);
+                if (!DIAG) pb[h] = load4(rp, colB, a.d, ok[h], a.w4);
+            }
         }
     };
     auto stage = [&](int buf) {
@@ -138,9 +147,9 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // centre in f64: block.astype(float64) - mean          (pycleora/__init__.py:141)
-                da[q] = (ok[h] && colA + q < a.d) ? (double)va[q] - mA[q] : 0.0;
+                da[q] = (ok[h] && (FAST || colA + q < a.d)) ? (double)va[q] - mA[q] : 0.0;
                 if constexpr (DIAG) cs[q] += da[q];
-                if constexpr (!DIAG) db[q] = (ok[h] && colB + q < a.d) ? (double)vb[q] - mB[q] : 0.0;
+                if constexpr (!DIAG) db[q] = (ok[h] && (FAST || colB + q < a.d)) ? (double)vb[q] - mB[q] : 0.0;
             }
         }
     };
@@ -220,7 +229,7 @@ __device__ __forceinline__ uint32_t pair_index(uint32_t bi, uint32_t bj, uint32_
 
 // Two launches so each body gets its own register budget (2 waves/SIMD each):
 // DIAG: blockIdx.x = diagonal tile; off-diagonal: blockIdx.x enumerates the pairs bi < bj.
-template <bool DIAG>
+template <bool DIAG, bool FAST>
 __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
     __shared__ __attribute__((aligned(16))) double lds[2][DIAG ? 1 : 2][GKC][GLD];
     uint32_t bi, bj;
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
         while (q >= rowlen) { q -= rowlen; ++bi; --rowlen; }
         bj = bi + 1 + q;
     }
-    gram_body<DIAG>(a, lds, bi, bj, pair_index(bi, bj, a.tiles));
+    gram_body<DIAG, FAST>(a, lds, bi, bj, pair_index(bi, bj, a.tiles));
 }
 
 // One-pass form: the Gram was centred with a shift c near the mean.  delta = sum_r (x_r - c) / n (slices added in
@@ -280,13 +289,14 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
 // Row slices per launch: the grid is sized to ONE resident round (2 blocks per CU) so there is no
 // partial last round — with 1-3 block tiles per launch at d = 256 a generic "many blocks" grid left
 // a third of the chip idle in its tail.  `group` = block tiles in the launch.
-inline uint32_t gram_slices(uint64_t n, uint32_t group) {
-    static int resident = 0;
-    if (!resident) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        resident = 2 * (cus > 0 ? cus : 256);
+inline uint32_t gram_slices(uint64_t n, uint32_t group, int per_cu = 2) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = c > 0 ? c : 256;
     }
+    const int resident = per_cu * cus;
     uint64_t s = group ? (uint64_t)resident / group : 1;
     const uint64_t cap = (n + GKC - 1) / GKC;   // at least one chunk of rows per slice
     if (s > cap) s = cap;
@@ -295,12 +305,12 @@ inline uint32_t gram_slices(uint64_t n, uint32_t group) {
 
 struct GramPlan { uint32_t tiles, pairs, s_diag, s_off, s_max; };
 
-inline GramPlan gram_plan(uint64_t n, uint32_t d) {
+inline GramPlan gram_plan(uint64_t n, uint32_t d, int per_cu = 2) {
     GramPlan p;
     p.tiles = (d + GT - 1) / GT;
     p.pairs = p.tiles * (p.tiles + 1) / 2;
-    p.s_diag = gram_slices(n, p.tiles);
-    p.s_off = p.tiles > 1 ? gram_slices(n, p.pairs - p.tiles) : 0;
+    p.s_diag = gram_slices(n, p.tiles, per_cu);
+    p.s_off = p.tiles > 1 ? gram_slices(n, p.pairs - p.tiles, per_cu) : 0;
     p.s_max = p.s_diag > p.s_off ? p.s_diag : p.s_off;
     return p;
 }
@@ -599,13 +609,15 @@ uint64_t gram_workspace(uint64_t n, uint32_t d) {
 
 // mean_out64 / mean_out32 == nullptr: `mean` is the exact mean (two-pass form, pycleora/__init__.py:136-143 literally).
 // Otherwise `mean` is a shift near the mean; the exact mean comes out of the same pass over X (gram_mean_kernel).
+// blocks_per_cu: 2 fills the chip (2 waves per SIMD, ~206 registers each); 1 leaves half of every register file to a
+// kernel running beside it (the SpMM of the overlapped whitened loop needs its occupancy to keep HBM busy).
 int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const double *mean,
-                double *ws, double *gram, hipStream_t stream, double *mean_out64, float *mean_out32) {
+                double *ws, double *gram, hipStream_t stream, double *mean_out64, float *mean_out32, int blocks_per_cu) {
     CL_REQUIRE(d > 0 && ldx >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && mean != nullptr && ws != nullptr && gram != nullptr,
                "x / mean / workspace / gram is NULL");
     CL_REQUIRE((mean_out64 == nullptr) == (mean_out32 == nullptr), "mean outputs come in pairs");
-    const GramPlan p = gram_plan(n, d);
+    const GramPlan p = gram_plan(n, d, blocks_per_cu == 1 ? 1 : 2);     // (the workspace is sized for 2: enough for 1)
     GramArgs a{};
     a.colsum = ws + (uint64_t)p.s_max * p.pairs * GT * GT;
     double *delta = a.colsum + (uint64_t)p.s_diag * p.tiles * GT;
@@ -625,11 +637,14 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
     };
     CL_REQUIRE(p.s_max <= 65535, "internal: too many Gram slices");
     // quadrants that are never computed are skipped by the reducer, so no memset is needed
+    const bool fast = a.w4 && d % GT == 0 && n > 0;
     a.rows_per_slice = rows_per_slice(p.s_diag);
-    hipLaunchKernelGGL(gram_kernel<true>, dim3(p.tiles, p.s_diag), dim3(256), 0, stream, a);
+    if (fast) hipLaunchKernelGGL((gram_kernel<true, true>), dim3(p.tiles, p.s_diag), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((gram_kernel<true, false>), dim3(p.tiles, p.s_diag), dim3(256), 0, stream, a);
     if (p.tiles > 1) {
         a.rows_per_slice = rows_per_slice(p.s_off);
-        hipLaunchKernelGGL(gram_kernel<false>, dim3(p.pairs - p.tiles, p.s_off), dim3(256), 0, stream, a);
+        if (fast) hipLaunchKernelGGL((gram_kernel<false, true>), dim3(p.pairs - p.tiles, p.s_off), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gram_kernel<false, false>), dim3(p.pairs - p.tiles, p.s_off), dim3(256), 0, stream, a);
     }
     if (mean_out64)
         hipLaunchKernelGGL(gram_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, a.colsum, p.s_diag, p.tiles, d, n,

@@ -8,8 +8,9 @@
 //
 // One wavefront per row: the row's edges are visited once for the scores (one gathered X row per edge —
 // the same traffic as an SpMM), then three lane-parallel passes over the row's scores do the softmax
-// arithmetic in f64 like the reference.  Not a headline kernel: rows are not split, so a hub row is
-// served by a single wavefront.
+// arithmetic in f64 like the reference.  Two forms: edge_attention_vec_kernel (aligned rows of up to 2048 floats:
+// 16-byte gathers, 8 rows in flight, scores in registers — below) and the scalar edge_attention_kernel for
+// every other shape.  Rows are not split: a hub row is served by a single wavefront.
 #include "common.h"
 
 namespace cleora {
@@ -76,7 +77,126 @@ __global__ __launch_bounds__(256) void edge_attention_kernel(const uint64_t *__r
         out[e] = (float)(exp(score(e) - mx) / se * (double)adj[e] / sw);
 }
 
+// ---- the form for aligned rows of up to 2048 floats: whole 16-byte gathers, 8 in flight, scores in registers ------------
+// One wavefront per row, lane l holding elements [4(l + 64v), +4) of every embedding row it touches (V float4 per lane).
+// Row norms come from one streaming pass (row_norm_kernel) instead of a second wave reduction per edge.  The row's own
+// vector stays in registers; its edges are visited 64 at a time (one coalesced load of col / adj per chunk, column
+// indices broadcast with v_readlane), 8 neighbour rows in flight; lane k of the chunk keeps edge k's score in a
+// register, RC chunks deep — rows of up to 64*RC edges never touch memory for the softmax.  Longer rows keep their
+// scores in `out` as before (the wave re-reads its own writes after a device-scope fence).
+constexpr int RC = 8;
+
+__global__ __launch_bounds__(256) void row_norm_kernel(const float *__restrict__ x, uint64_t ldx, uint64_t n, uint32_t d,
+                                                       float *__restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + row * ldx;
+    float sq = 0.f;
+    for (uint32_t c = lane * 4; c < d; c += 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(xr + c);
+        sq += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) norm[row] = fmaxf(sqrtf(sq), 1e-10f);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void edge_attention_vec_kernel(const uint64_t *__restrict__ rowptr,
+                                                                 const uint32_t *__restrict__ col,
+                                                                 const float *__restrict__ adj,
+                                                                 const float *__restrict__ x, uint64_t ldx, uint32_t d,
+                                                                 const float *__restrict__ norm, uint64_t n_rows,
+                                                                 float temperature, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const uint64_t beg = rowptr[row], end = rowptr[row + 1];
+    if (beg == end) return;
+    float4 xr[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const uint32_t c = (uint32_t)(v * 64 + lane) * 4;
+        xr[v] = c < d ? *reinterpret_cast<const float4 *>(x + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float nr = norm[row];
+    const bool in_regs = end - beg <= (uint64_t)64 * RC;
+    float keep[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) keep[c] = -INFINITY;
+    double mx = -INFINITY;
+    int chunk = 0;
+    for (uint64_t e0 = beg; e0 < end; e0 += 64, ++chunk) {
+        const uint32_t cnt = end - e0 < 64 ? (uint32_t)(end - e0) : 64u;
+        const uint32_t cv = (uint32_t)lane < cnt ? col[e0 + lane] : 0u;
+        float mine = -INFINITY;                                   // score of edge e0 + lane
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
+            float4 g[8][V];
+            float dot[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)(k0 + u < cnt ? k0 + u : k0));
+#pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const uint32_t cc = (uint32_t)(v * 64 + lane) * 4;
+                    g[u][v] = cc < d ? *reinterpret_cast<const float4 *>(x + (uint64_t)c * ldx + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < V; ++v) s += xr[v].x * g[u][v].x + xr[v].y * g[u][v].y + xr[v].z * g[u][v].z + xr[v].w * g[u][v].w;
+                dot[u] = s;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < cnt) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)(k0 + u));
+                    const float s = dot[u] / (nr * norm[c]) / temperature;      // (:243-248)
+                    if ((uint32_t)lane == k0 + u) mine = s;
+                }
+        }
+        mx = fmax(mx, (double)mine);
+        if (in_regs) {
+#pragma unroll
+            for (int c = 0; c < RC; ++c)
+                if (c == chunk) keep[c] = mine;
+        } else if ((uint32_t)lane < cnt) {
+            out[e0 + lane] = mine;
+        }
+    }
+    mx = wave_max(mx);
+    if (!in_regs) __threadfence();          // this wave re-reads its scores from `out` through device-scope loads below
+    auto score = [&](int c, uint64_t e) -> double {
+        if (in_regs) {
+            float v = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < RC; ++k)
+                if (k == c) v = keep[k];
+            return (double)v;
+        }
+        return (double)__hip_atomic_load(out + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    double se = 0.0;
+    chunk = 0;
+    for (uint64_t e = beg + lane; e < end; e += 64, ++chunk) se += exp(score(chunk, e) - mx);
+    se = fmax(wave_sum(se), 1e-10);                                   // softmax over the row's edges (:250-262)
+    double sw = 0.0;
+    chunk = 0;
+    for (uint64_t e = beg + lane; e < end; e += 64, ++chunk) sw += exp(score(chunk, e) - mx) / se * (double)adj[e];
+    sw = fmax(wave_sum(sw), 1e-10);                                   // re-weighted and row-normalised (:264-267)
+    chunk = 0;
+    for (uint64_t e = beg + lane; e < end; e += 64, ++chunk)
+        out[e] = (float)(exp(score(chunk, e) - mx) / se * (double)adj[e] / sw);
+}
+
 }  // namespace
+
 
 int launch_edge_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                           float temperature, float *vals_out, hipStream_t stream) {
@@ -89,6 +209,23 @@ int launch_edge_attention(const cleora_graph *g, int kind, const float *x, uint6
     CL_REQUIRE(temperature > 0.0f, "attention_temperature must be positive");
     if (g->n_rows == 0 || g->nnz == 0) return CLEORA_OK;
     CL_HIP(hipSetDevice(g->device));
+    const bool vec = d % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && d <= 2048;
+    if (vec) {
+        float *norm = nullptr;                  // n floats of scratch, stream-ordered
+        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&norm), g->n_rows * sizeof(float), stream));
+        const dim3 grid = grid_1d_as_2d((g->n_rows + 3) / 4);
+        hipLaunchKernelGGL(row_norm_kernel, grid, dim3(256), 0, stream, x, ldx, g->n_rows, d, norm);
+        switch ((d + 255) / 256) {
+            case 1: hipLaunchKernelGGL(edge_attention_vec_kernel<1>, grid, dim3(256), 0, stream, g->rowptr, g->col, g->val[kind], x, ldx, d, norm, g->n_rows, temperature, vals_out); break;
+            case 2: hipLaunchKernelGGL(edge_attention_vec_kernel<2>, grid, dim3(256), 0, stream, g->rowptr, g->col, g->val[kind], x, ldx, d, norm, g->n_rows, temperature, vals_out); break;
+            case 3: case 4: hipLaunchKernelGGL(edge_attention_vec_kernel<4>, grid, dim3(256), 0, stream, g->rowptr, g->col, g->val[kind], x, ldx, d, norm, g->n_rows, temperature, vals_out); break;
+            default: hipLaunchKernelGGL(edge_attention_vec_kernel<8>, grid, dim3(256), 0, stream, g->rowptr, g->col, g->val[kind], x, ldx, d, norm, g->n_rows, temperature, vals_out); break;
+        }
+        const hipError_t le = hipGetLastError();
+        CL_HIP(hipFreeAsync(norm, stream));
+        CL_HIP(le);
+        return CLEORA_OK;
+    }
     hipLaunchKernelGGL(edge_attention_kernel, grid_1d_as_2d((g->n_rows + 3) / 4), dim3(256), 0, stream, g->rowptr,
                        g->col, g->val[kind], x, ldx, d, g->n_rows, temperature, vals_out);
     CL_HIP(hipGetLastError());

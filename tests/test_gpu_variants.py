@@ -198,3 +198,35 @@ def test_topk_cosine_on_device_against_numpy(n, d, k, nq):
             masked = sims[idx[qi]] <= -2.0
             assert (sc[qi][masked] == -2.0).all()
     g.close()
+
+
+@pytest.mark.parametrize("n,d", [(6000, 256), (3000, 512), (2000, 260), (1500, 30)])
+def test_edge_attention_kernels_on_random_graphs(n, d):
+    """Both forms of the attention kernel (16-byte gathers with the scores in registers; the scalar one for widths that
+    are not a multiple of 4) against the numpy restatement of pycleora/__init__.py:241-268: rows of every length class —
+    empty, a few edges, > 64 (several chunks), > 512 (scores through `out`) — weights to 2e-5 relative, rows sum to 1."""
+    from tests.graphs import random_csr
+    rowptr, col, vl, vs = random_csr(n, 10, seed=n + d, empty_frac=0.05, hubs=[(3, 700), (40, 130)])
+    rowptr64, col64, adj = rowptr.astype(np.int64), col.astype(np.int64), vl.astype(np.float64)
+    x = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+    temp = 0.8
+    rows = np.repeat(np.arange(n), np.diff(rowptr64))
+    xn = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)
+    score = np.sum(xn[rows].astype(np.float64) * xn[col64], axis=1) / temp
+    mx = np.full(n, -np.inf)
+    np.maximum.at(mx, rows, score)
+    ex = np.exp(score - mx[rows])
+    a = ex / np.maximum(np.bincount(rows, weights=ex, minlength=n), 1e-10)[rows] * adj
+    want = a / np.maximum(np.bincount(rows, weights=a, minlength=n), 1e-10)[rows]
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    L = _hip.lib()
+    dx = _hip.DevArray.from_host(x)
+    dv = _hip.DevArray((col.shape[0],), np.float32)
+    _hip.check(L.cleora_edge_attention_dev(g.handle, _hip.LEFT, dx.ptr, d, d, temp, dv.ptr, None))
+    _hip.check(L.cleora_stream_sync(None))
+    got = dv.to_host()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9)
+    sums = np.bincount(rows, weights=got, minlength=n)
+    nonempty = np.diff(rowptr64) > 0
+    np.testing.assert_allclose(sums[nonempty], 1.0, atol=2e-6)
+    g.close()

@@ -722,11 +722,12 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     for (uint64_t it = 0; it + 1 < iterations; ++it) {
         CL_HIP(hipEventRecord(st.ya, st.a));                               // Y is complete
         CL_HIP(hipStreamWaitEvent(st.b, st.ya, 0));
-        // stream b: mean, covariance, eigensolver of Y (MFMA / latency bound) ...
+        // stream a: Z = A Y (HBM bound), no epilogue — enqueued FIRST: rocSOLVER synchronises with the host inside
+        // dsyevd, so whatever is launched after the fit would only start when the Gram is done
+        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+        // stream b, at the same time: mean, covariance, eigensolver of Y (MFMA / latency bound)
         if (n > 1 && (rc = launch_whiten_fit(y, d, n, d, d, ws.p, nullptr, st.b, co_blocks)) != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(st.fb, st.b));
-        // ... stream a, at the same time: Z = A Y (HBM bound), no epilogue
-        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
         CL_HIP(hipStreamWaitEvent(st.a, st.fb, 0));
         if (n > 1) {
             // P = (alpha (Z - s mu^T) + rw (Y - mu)) T, then the row normalisation: Y of the next iteration

@@ -341,6 +341,7 @@ struct ProjArgs {
     const float *x2;
     uint64_t ldx2;
     float alpha, beta;
+    int dbg;          // profiling only (CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = no X loads (LDS tile of ones)
 };
 
 __device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
                     const bool ok = row < a.n && c0 + c < d && r + 4 * u < RM;
                     v[u] = v2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     s[u] = 1.f;
-                    if (ok) v[u] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + c0 + c);
+                    if (ok && !(a.dbg & 2)) v[u] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + c0 + c);
                     if (ok && a.x2) v2[u] = *reinterpret_cast<const float4 *>(a.x2 + row * a.ldx2 + c0 + c);
                     if (ok && a.rowscale) s[u] = a.rowscale[row];
                 }
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
                 // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
                 const uint64_t row = m0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
                 const uint32_t col = n0 + j * 32 + (lane & 31);
-                if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[i][j][reg];
+                if (row < a.n && col < a.k && (!(a.dbg & 1) || acc[i][j][reg] == 12345.678f)) a.out[row * a.ldo + col] = acc[i][j][reg];
             }
 }
 
@@ -670,6 +671,8 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.ldx2 = ldx2;
     a.alpha = x2 ? alpha : 1.0f;
     a.beta = beta;
+    static const int dbg = std::getenv("CLEORA_PROJECT_DEBUG") ? std::atoi(std::getenv("CLEORA_PROJECT_DEBUG")) : 0;
+    a.dbg = dbg;
     a.x = x;
     a.ldx = ldx;
     a.n = n;

@@ -684,6 +684,8 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     const uint32_t norm = (flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM;
     const uint32_t fast = flags & CLEORA_F_FASTNORM;
     const bool blend = rw > 0.0f;                                          // the Python loop: any rw > 0 (:111-115)
+    static const bool pca_always = std::getenv("CLEORA_WHITEN_PCA_ALWAYS") != nullptr;   // A/B switch
+    const bool any_whitening = norm == CLEORA_F_L2NORM && !pca_always;    // rotation invariance needs the L2 norm
     int rc;
     if (iterations == 0) { *result = b0; return CLEORA_OK; }
     DevBuf ws, rowsum;
@@ -722,19 +724,25 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     for (uint64_t it = 0; it + 1 < iterations; ++it) {
         CL_HIP(hipEventRecord(st.ya, st.a));                               // Y is complete
         CL_HIP(hipStreamWaitEvent(st.b, st.ya, 0));
-        // stream a: Z = A Y (HBM bound), no epilogue — enqueued FIRST: rocSOLVER synchronises with the host inside
-        // dsyevd, so whatever is launched after the fit would only start when the Gram is done
+        // Order of the launches matters twice.  (1) The Gram blocks (few, ~206 registers a wave) must be handed to the
+        // dispatcher BEFORE the SpMM's millions of small blocks: behind them they starve, the SpMM refills every hole.
+        // (2) rocSOLVER synchronises with the host inside dsyevd: whatever is launched after it starts only then.
+        // So: statistics (stream b) -> SpMM (stream a) -> eigensolver (stream b, the host blocks here while both run).
+        static const int gram_first = std::getenv("CLEORA_GRAM_FIRST") ? std::atoi(std::getenv("CLEORA_GRAM_FIRST")) : 1;
+        if (gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks)) != CLEORA_OK) return rc;
         if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
-        // stream b, at the same time: mean, covariance, eigensolver of Y (MFMA / latency bound)
-        if (n > 1 && (rc = launch_whiten_fit(y, d, n, d, d, ws.p, nullptr, st.b, co_blocks)) != CLEORA_OK) return rc;
+        if (!gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks)) != CLEORA_OK) return rc;
+        // intermediate iterations of the L2-normalised loop may take ANY whitening transform (eigh.hip): Cholesky
+        if (n > 1 && (rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, any_whitening)) != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(st.fb, st.b));
         CL_HIP(hipStreamWaitEvent(st.a, st.fb, 0));
         if (n > 1) {
             // P = (alpha (Z - s mu^T) + rw (Y - mu)) T, then the row normalisation: Y of the next iteration
+            bool normed = false;
             rc = launch_project(b0, d, n, d, mean32, transform, d, ynext, d, st.a, rowsum.as<float>(), blend ? y : nullptr, d,
-                                1.0f - rw, rw);
+                                1.0f - rw, rw, norm == CLEORA_F_L1NORM ? 2 : 1, &normed);
             if (rc != CLEORA_OK) return rc;
-            if ((rc = launch_rowops(ynext, d, n, d, ynext, d, norm | fast, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+            if (!normed && (rc = launch_rowops(ynext, d, n, d, ynext, d, norm | fast, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
         } else {
             // one entity: whiten_embeddings returns its input (:132-133), so E' = Y and the next Y = normalise(A Y [+ blend])
             if ((rc = launch_rowops(b0, d, n, d, ynext, d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, y, nullptr, nullptr, st.a)) != CLEORA_OK)

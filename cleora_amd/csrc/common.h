@@ -124,7 +124,8 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
                    const float *rowscale = nullptr, const float *x2 = nullptr, uint64_t ldx2 = 0, float alpha = 1.0f,
-                   float beta = 0.0f);
+                   float beta = 0.0f, int norm = 0,           // norm: 1 = L2-, 2 = L1-normalise the output rows in the epilogue ...
+                   bool *norm_done = nullptr);                // ... if the shape allows (reported here); else the caller runs rowops
 
 // similarity.hip
 uint64_t topk_workspace_bytes(uint64_t n, uint32_t k);
@@ -153,6 +154,12 @@ int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t
 // the two halves of launch_whiten: statistics + eigensolver (leaves mean32 and the d x k transform in the workspace) ...
 int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
                       double *eigenvalues, hipStream_t stream, int gram_blocks_per_cu = 2);
+int launch_whiten_fit_stats(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, hipStream_t stream,
+                            int gram_blocks_per_cu = 2);
+// any_whitening: the caller only needs SOME W with W^T cov W = I (intermediate iterations of the L2-normalised loop):
+// Cholesky (potrf + trtri) instead of the eigensolver, falling back to it when the covariance is near-singular
+int launch_whiten_fit_solve(uint64_t n, uint32_t d, uint32_t k, void *workspace, double *eigenvalues, hipStream_t stream,
+                            bool any_whitening = false);
 // ... and their location, for a projection launched separately (launch_project)
 void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform);
 

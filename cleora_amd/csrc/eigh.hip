@@ -24,6 +24,8 @@ struct Solver {
     decltype(&rocblas_destroy_handle) destroy = nullptr;
     decltype(&rocblas_set_stream) set_stream = nullptr;
     decltype(&rocsolver_dsyevd) dsyevd = nullptr;
+    decltype(&rocsolver_dpotrf) dpotrf = nullptr;
+    decltype(&rocsolver_dtrtri) dtrtri = nullptr;
     std::string error;
     std::mutex mu;                               // one eigenproblem at a time per process
     std::map<int, rocblas_handle> handles;       // one rocBLAS handle per device, created on demand
@@ -47,7 +49,9 @@ Solver &solver() {
         s.destroy = reinterpret_cast<decltype(s.destroy)>(dlsym(s.lib, "rocblas_destroy_handle"));
         s.set_stream = reinterpret_cast<decltype(s.set_stream)>(dlsym(s.lib, "rocblas_set_stream"));
         s.dsyevd = reinterpret_cast<decltype(s.dsyevd)>(dlsym(s.lib, "rocsolver_dsyevd"));
-        if (!s.create || !s.destroy || !s.set_stream || !s.dsyevd) {
+        s.dpotrf = reinterpret_cast<decltype(s.dpotrf)>(dlsym(s.lib, "rocsolver_dpotrf"));
+        s.dtrtri = reinterpret_cast<decltype(s.dtrtri)>(dlsym(s.lib, "rocsolver_dtrtri"));
+        if (!s.create || !s.destroy || !s.set_stream || !s.dsyevd || !s.dpotrf || !s.dtrtri) {
             s.error = "rocSOLVER / rocBLAS entry points not found in the loaded library";
             s.lib = nullptr;
         }
@@ -86,6 +90,33 @@ __global__ __launch_bounds__(256) void transform_kernel(const double *__restrict
     t[idx] = (float)(v[(uint64_t)i + (uint64_t)src * d] * scale);
 }
 
+// Cholesky whitening (the rotation-equivalent transform of the intermediate iterations, launch_whiten_transform below):
+// smallest squared pivot of the factor (a lower bound test for near-singularity) ...
+__global__ __launch_bounds__(256) void min_pivot_kernel(const double *__restrict__ l, uint32_t d, double *__restrict__ out) {
+    __shared__ double sm[256];
+    double m = INFINITY;
+    for (uint32_t i = threadIdx.x; i < d; i += 256) {
+        const double p = l[(uint64_t)i * d + i];
+        m = fmin(m, p * p);
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sm[threadIdx.x] = fmin(sm[threadIdx.x], sm[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+// ... and the transform T = L^-T as f32: rocSOLVER worked on the column-major LOWER triangle, whose memory read row-major
+// is the upper triangle of L^-T; the other triangle still holds the covariance and is zeroed here.
+__global__ __launch_bounds__(256) void tri_transform_kernel(const double *__restrict__ linv, uint32_t d, float *__restrict__ t) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (uint64_t)d * d) return;
+    const uint32_t i = (uint32_t)(idx / d), j = (uint32_t)(idx % d);
+    t[idx] = j >= i ? (float)linv[idx] : 0.0f;
+}
+
 inline uint64_t align256(uint64_t b) { return (b + 255) / 256 * 256; }
 
 struct TransformWs {      // carved out of the caller's workspace
@@ -113,6 +144,64 @@ int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, fl
     CL_REQUIRE(colsum != nullptr && mean64 != nullptr && mean32 != nullptr, "colsum / mean is NULL");
     CL_REQUIRE(n > 0 && d > 0, "n and d must be positive");
     hipLaunchKernelGGL(mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, colsum, n, d, mean64, mean32);
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+// Any W with W^T cov W = I whitens; the PCA form (eigenvectors, :145-156) is what the reference RETURNS, but inside the
+// loop E <- whiten(l2_normalise(A E)) every such W leads to the same final result: two whitenings differ by an orthogonal
+// factor R on the right, the SpMM and the row-wise L2 normalisation commute with R, and the PCA whitening of the last
+// iteration removes it.  The Cholesky form W = L^-T (cov = L L^T) costs potrf + trtri — a handful of launches — instead
+// of dsyevd's ~d dependent steps (6 ms at d = 256, two thirds of a whitening at |V| = 1M).  Returns 1 (not an error) when
+// the covariance is too close to singular for that (pivot^2 < 1e-8, near the reference's 1e-10 eigenvalue clamp, or potrf
+// reports a non-positive pivot): the caller then takes the eigenvector form, which reproduces the clamp.
+int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d, float *transform, void *workspace,
+                                     hipStream_t stream) {
+    CL_REQUIRE(gram != nullptr && transform != nullptr && workspace != nullptr, "gram / transform / workspace is NULL");
+    CL_REQUIRE(n >= 2 && d > 0 && d <= (1u << 15), "bad shape");
+    Solver &s = solver();
+    if (!s.lib) {
+        set_error("whitening needs rocSOLVER (dlopen failed: " + s.error + "); set CLEORA_ROCSOLVER to its path");
+        return CLEORA_E_HIP;
+    }
+    int device = 0;
+    CL_HIP(hipGetDevice(&device));
+    const TransformWs w = carve_transform(workspace, d);
+    const uint64_t elems = (uint64_t)d * d;
+    hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, gram, elems,
+                       1.0 / (double)(n - 1), w.cov);
+    CL_HIP(hipGetLastError());
+    int info_potrf = 0;
+    double min_pivot2 = 0.0;
+    {
+        std::lock_guard<std::mutex> lock(s.mu);
+        rocblas_handle &h = s.handles[device];
+        if (!h && s.create(&h) != rocblas_status_success) {
+            h = nullptr;
+            set_error("rocblas_create_handle failed");
+            return CLEORA_E_HIP;
+        }
+        if (s.set_stream(h, stream) != rocblas_status_success) {
+            set_error("rocblas_set_stream failed");
+            return CLEORA_E_HIP;
+        }
+        if (s.dpotrf(h, rocblas_fill_lower, (rocblas_int)d, w.cov, (rocblas_int)d, w.info) != rocblas_status_success) {
+            set_error("rocsolver_dpotrf failed");
+            return CLEORA_E_HIP;
+        }
+        hipLaunchKernelGGL(min_pivot_kernel, dim3(1), dim3(256), 0, stream, w.cov, d, w.w);
+        CL_HIP(hipMemcpyAsync(&info_potrf, w.info, sizeof(int), hipMemcpyDeviceToHost, stream));
+        CL_HIP(hipMemcpyAsync(&min_pivot2, w.w, sizeof(double), hipMemcpyDeviceToHost, stream));
+        CL_HIP(hipStreamSynchronize(stream));
+        if (info_potrf != 0 || !(min_pivot2 >= 1e-8)) return 1;              // not safely positive definite
+        if (s.dtrtri(h, rocblas_fill_lower, rocblas_diagonal_non_unit, (rocblas_int)d, w.cov, (rocblas_int)d, w.info) !=
+            rocblas_status_success) {
+            set_error("rocsolver_dtrtri failed");
+            return CLEORA_E_HIP;
+        }
+    }
+    hipLaunchKernelGGL(tri_transform_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, w.cov, d, transform);
+    // (w.info was overwritten by trtri with 0: whiten_info() keeps reporting success for this workspace)
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }
@@ -261,9 +350,11 @@ const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
     return carve_transform(w.eigh, d).info;
 }
 
-int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
-                      double *eigenvalues, hipStream_t stream, int gram_blocks_per_cu) {
-    CL_REQUIRE(d > 0 && ldx >= d && n >= 2 && k >= 1 && k <= d, "bad shape");
+// The fit in two halves, so that a caller can slip other launches between the MFMA-bound statistics and the
+// eigensolver (whose library call synchronises with the host): launch_whiten_fit = stats + solve.
+int launch_whiten_fit_stats(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, hipStream_t stream,
+                            int gram_blocks_per_cu) {
+    CL_REQUIRE(d > 0 && ldx >= d && n >= 2, "bad shape");
     CL_REQUIRE(x != nullptr && workspace != nullptr, "x / workspace is NULL");
     WhitenWs w;
     whiten_ws_layout(n, d, workspace, &w);
@@ -279,9 +370,30 @@ int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint
     wt_mark(stream);
     if ((rc = launch_gram(x, ldx, n, d, w.shift64, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu)) != CLEORA_OK) return rc;
     wt_mark(stream);
-    if ((rc = launch_whiten_transform(w.gram, n, d, k, w.transform, eigenvalues, w.eigh, stream)) != CLEORA_OK) return rc;
+    return CLEORA_OK;
+}
+
+int launch_whiten_fit_solve(uint64_t n, uint32_t d, uint32_t k, void *workspace, double *eigenvalues, hipStream_t stream,
+                            bool any_whitening) {
+    CL_REQUIRE(k >= 1 && k <= d && workspace != nullptr, "bad shape");
+    WhitenWs w;
+    whiten_ws_layout(n, d, workspace, &w);
+    int rc = 1;
+    if (any_whitening && k == d) {            // the cheap transform where the result does not depend on which one
+        rc = launch_whiten_transform_cholesky(w.gram, n, d, w.transform, w.eigh, stream);
+        if (rc < 0) return rc;
+    }
+    if (rc == 1) rc = launch_whiten_transform(w.gram, n, d, k, w.transform, eigenvalues, w.eigh, stream);
+    if (rc != CLEORA_OK) return rc;
     wt_mark(stream);
     return CLEORA_OK;
+}
+
+int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, void *workspace,
+                      double *eigenvalues, hipStream_t stream, int gram_blocks_per_cu) {
+    const int rc = launch_whiten_fit_stats(x, ldx, n, d, workspace, stream, gram_blocks_per_cu);
+    if (rc != CLEORA_OK) return rc;
+    return launch_whiten_fit_solve(n, d, k, workspace, eigenvalues, stream);
 }
 
 void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform) {

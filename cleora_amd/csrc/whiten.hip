@@ -342,6 +342,7 @@ struct ProjArgs {
     uint64_t ldx2;
     float alpha, beta;
     int dbg;          // profiling only (CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = no X loads (LDS tile of ones)
+    int norm;         // rows-in-LDS form, k <= 256: 1 = L2-normalise, 2 = L1-normalise every output row in the epilogue
 };
 
 __device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
         }
     }
     __syncthreads();
-    if (n0 >= a.k) return;                                             // (after the barrier: this wave has no columns)
+    if (n0 >= a.k && !a.norm) return;                                  // (after the barrier: this wave has no columns)
 
     f16v acc[2][WN];
 #pragma unroll
@@ -570,6 +571,57 @@ __global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, 
             af[0] = an[0];
             af[1] = an[1];
         }
+    }
+
+    if (a.norm) {
+        // Row normalisation on the accumulators (the block holds whole output rows: 4 waves x 64 columns >= k): the
+        // next iterate of the overlapped whitened loop is normalise(projection), and doing it here saves a pass over
+        // the n x k matrix.  Per lane: the partial of its 32 row slots over its 2 column tiles; a 32-lane butterfly
+        // inside each half-wave; the four waves' partials meet in LDS (the X tile is dead once every wave is here).
+        float p[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float t = 0.f;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) t += a.norm == 1 ? acc[i][j][reg] * acc[i][j][reg] : fabsf(acc[i][j][reg]);
+                p[i][reg] = t;
+            }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) p[i][reg] += __shfl_xor(p[i][reg], o, 64);
+        __syncthreads();                                   // every wave has left the main loop: xs is free
+        float *red = xs;                                   // [4 waves][64 rows] partials, then [64] factors
+        const int nl = lane & 31, h = lane >> 5;
+        float mine = 0.f;                                  // lane nl of half h publishes row slot nl of that half
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (nl == i * 16 + reg) mine = p[i][reg];
+        {
+            const int i = nl >> 4, reg = nl & 15;
+            red[w * RM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = mine;
+        }
+        __syncthreads();
+        if (t < RM) {
+            const float s = red[t] + red[RM + t] + red[2 * RM + t] + red[3 * RM + t];
+            // L2: v * (1 / max(sqrt(s), 1e-10)) like src/embedding.rs:98-102; L1: v / max(s, 1e-10) (pycleora/__init__.py:947-950)
+            red[4 * RM + t] = a.norm == 1 ? 1.0f / fmaxf(sqrtf(s), 1e-10f) : fmaxf(s, 1e-10f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float f = red[4 * RM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j][reg] = a.norm == 1 ? acc[i][j][reg] * f : acc[i][j][reg] / f;
+            }
     }
 
 #pragma unroll
@@ -658,7 +710,9 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
-                   const float *rowscale, const float *x2, uint64_t ldx2, float alpha, float beta) {
+                   const float *rowscale, const float *x2, uint64_t ldx2, float alpha, float beta, int norm,
+                   bool *norm_done) {
+    if (norm_done) *norm_done = false;
     CL_REQUIRE(d > 0 && k > 0 && ldx >= d && ldo >= k, "bad d / k / leading dimension");
     CL_REQUIRE(x != nullptr && mean != nullptr && t != nullptr && out != nullptr,
                "x / mean / transform / out is NULL");
@@ -703,6 +757,8 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         }
         const uint64_t row_blocks = (n + RM - 1) / RM;
         CL_REQUIRE(row_blocks < (1ull << 31), "internal: too many row blocks");
+        a.norm = (norm && col_tiles == 8) ? norm : 0;                     // whole rows inside one block only
+        if (norm_done) *norm_done = a.norm != 0;
         hipLaunchKernelGGL(project_rows_kernel<2>, dim3((unsigned)row_blocks, col_tiles / 8), dim3(256), lds_bytes,
                            stream, a, tp, col_tiles);
         const hipError_t le = hipGetLastError();

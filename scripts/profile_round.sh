@@ -8,15 +8,15 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python "$root/bench.py" --no-cpu-baseline > "$out/bench_stats.log" 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wstats" -o whiten -- python "$root/scripts/whiten_probe.py" > "$out/whiten_stats.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python "$root/bench.py" --no-cpu-baseline --whiten-iters 0 > "$out/bench_stats.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wstats" -o whiten -- python "$root/scripts/whiten_stage_probe.py" 2 > "$out/whiten_stats.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/write.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/fetch_nohot.log" 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/hit.log" 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/hit_nohot.log" 2>&1
 # whitening kernels: MFMA pipe occupancy (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, GRBM_GUI_ACTIVE per XCD)
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/wpmc" -o pmc -- python "$root/scripts/whiten_probe.py" > "$out/wpmc.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/wpmc" -o pmc -- python "$root/scripts/whiten_stage_probe.py" 2 > "$out/wpmc.log" 2>&1
 # BASELINE config 2 (bipartite 1M / 20M, d = 256): kernel time and HBM bytes of the same kernel
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c2_stats" -o c2 -- python "$root/scripts/pmc_probe.py" --graph c2 --iters 40 > "$out/c2_stats.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/c2_fetch" -o pmc -- python "$root/scripts/pmc_probe.py" --graph c2 > "$out/c2_fetch.log" 2>&1

@@ -104,7 +104,14 @@ if policy:
     out["gather_cache_policy"] = policy
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 dom = sorted((k for k in out["kernels"] if k.startswith("spmm_rows_kernel")), key=lambda k: out["kernels"][k]["launches"])[-1]
-json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"profiles/{tag}_pmc.json",
+# stamp: bench.py only trusts this figure for the build of the kernel it was measured on (run this script right after
+# the profile, before touching the kernel sources)
+import hashlib
+_h = hashlib.sha256()
+for rel in ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h"):
+    _h.update(open(os.path.join(os.path.dirname(dst), rel), "rb").read())
+json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"{tag}_pmc.json",
+           "kernel_source_sha16": _h.hexdigest()[:16],
            "bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"]},
           open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
@@ -115,15 +122,22 @@ wp = os.path.join(src, "wpmc", "pmc_counter_collection.csv")
 if os.path.exists(wp):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(wp)):
-        if "cleora" in r["Kernel_Name"] and ("gram_kernel" in r["Kernel_Name"] or "project_kernel" in r["Kernel_Name"]):
+        if "cleora" in r["Kernel_Name"] and ("gram_kernel" in r["Kernel_Name"] or "project_kernel" in r["Kernel_Name"]
+                                             or "project_rows_kernel" in r["Kernel_Name"]):
             acc[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     wout = {"formula": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)  [8 XCDs, 1024 SIMDs]", "kernels": []}
     for (name, grid), c in sorted(acc.items()):
         busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
         act = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
-        wout["kernels"].append({"kernel": name, "grid_size": int(grid), "launches": len(c["GRBM_GUI_ACTIVE"]),
-                                "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": act,
-                                "mfma_busy": busy / (act / 8 * 1024)})
+        rec = {"kernel": name, "grid_size": int(grid), "launches": len(c["GRBM_GUI_ACTIVE"]),
+               "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE": act, "mfma_busy": busy / (act / 8 * 1024)}
+        for extra in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES"):
+            if extra in c:
+                rec[extra] = sum(c[extra]) / len(c[extra])
+        if "SQ_WAVE_CYCLES" in rec:
+            rec["wait_inst_share_of_wave_cycles"] = rec.get("SQ_WAIT_INST_ANY", 0.0) / rec["SQ_WAVE_CYCLES"]
+            rec["waves_per_simd"] = rec["SQ_WAVE_CYCLES"] * 4 / (act / 8 * 1024)
+        wout["kernels"].append(rec)
     json.dump(wout, open(os.path.join(dst, f"{tag}_whiten_pmc.json"), "w"), indent=1)
 
 # 4. BASELINE config 2 on one GPU: kernel time (rocprofv3 stats) and HBM bytes (PMC) of the same SpMM kernel

@@ -331,10 +331,14 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
  * (pycleora/__init__.py:97-127 with _postprocess_iteration :963-971): every iteration is SpMM, residual blend for
  * ANY rw > 0 (:111-115 — unlike the Rust loop's 0 < rw < 1), L2 normalise (L1 with CLEORA_F_L1NORM), THEN
  * whiten_embeddings; the RMSE of the early stop is taken between whitened iterates in f64 (:122-125, :974-976).
- * Without a convergence test nobody sees the intermediate whitened iterates, and the SpMM of iteration t+1 runs BESIDE
- * the Gram matrix and eigensolver of iteration t on a second stream: the SpMM is linear, so A ((Y - 1 mu^T) T) is taken as
- * (A Y - (A 1) mu^T) T — the same operations with one of them moved across a linear step; results agree with the
- * sequential order to f32 rounding (CLEORA_WHITEN_SEQUENTIAL=1 in the environment keeps the sequential order). */
+ * Without a convergence test nobody sees the intermediate whitened iterates, and the loop is reorganised without changing
+ * what it computes: (1) the SpMM is linear, so A ((Y - 1 mu^T) T) is taken as (A Y - (A 1) mu^T) T — the
+ * SpMM of the next iteration is enqueued beside the Gram matrix / d x d step of this one, and the projection normalises its
+ * output rows in its own epilogue; (2) with the L2 norm, intermediate iterations may use ANY whitening transform (two differ by
+ * an orthogonal factor that the linear steps, the rotation-invariant norm and the final PCA whitening remove): Cholesky
+ * (potrf + trtri) instead of the eigensolver, falling back to it when the covariance is near-singular; the last iteration is
+ * always the PCA form.  Results agree with the sequential order to f32 rounding.  Environment switches for A/B:
+ * CLEORA_WHITEN_SEQUENTIAL=1 (the reference's order), CLEORA_WHITEN_PCA_ALWAYS=1 (eigensolver in every iteration). */
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,

@@ -117,6 +117,104 @@ __global__ __launch_bounds__(256) void tri_transform_kernel(const double *__rest
     t[idx] = j >= i ? (float)linv[idx] : 0.0f;
 }
 
+// ---- Cholesky whitening transform for d <= 256 in ONE launch, no library, no host synchronisation inside -------------
+// cov = gram / (n-1) = L L^T ;  transform = L^-T as f32 (row-major d x d, upper triangular).
+// One workgroup of 512 threads keeps the lower triangle of the matrix in REGISTERS (d (d+1)/2 <= 32 896 values; 512 KiB
+// of f64 would not fit the LDS).  Ownership is by ROW PAIRS so that a slot's (i, k) costs one compare instead of a stored
+// index: rows r and d-1-r together hold d+1 elements, four threads share a pair, thread `sub` of the four owns positions
+// sub, sub+4, ... of the pair's concatenated rows — at most 65 values per thread.  The factorisation is right-looking
+// with one barrier per column: the still-unscaled column j+1 is published to LDS by its owners at the end of step j,
+// every thread reads the pivot from it and folds the scaling into its update, a -= c_i c_k / pivot.  L then goes to
+// global scratch and thread j < d solves L m = e_j forward (column j of L^-1), writing it as row j of the transform.
+// meta[0] = 0 ok / 1 a pivot was not positive, meta[1] = smallest pivot (= squared diagonal of L).
+constexpr int kCholSlots = 65, kCholThreads = 512;
+
+__global__ __launch_bounds__(kCholThreads) void cholesky_whiten_kernel(const double *__restrict__ gram, double inv_nm1,
+                                                                       uint32_t d, double *__restrict__ lfull,
+                                                                       float *__restrict__ transform,
+                                                                       double *__restrict__ meta) {
+    __shared__ double col[2][256];
+    __shared__ int failed;
+    const uint32_t t = threadIdx.x, pair = t >> 2, sub = t & 3;
+    const uint32_t r0 = pair, r1 = d - 1 - pair;                   // r0 <= r1 for the pairs that exist
+    const uint32_t len0 = r0 + 1;                                  // row r0 holds k = 0..r0
+    const uint32_t len = pair < (d + 1) / 2 ? (r0 == r1 ? len0 : d + 1) : 0;
+    double a[kCholSlots];
+#pragma unroll
+    for (int s = 0; s < kCholSlots; ++s) {
+        const uint32_t p = (uint32_t)s * 4 + sub;
+        const bool second = p >= len0;
+        const uint32_t i = second ? r1 : r0, k = second ? p - len0 : p;
+        a[s] = p < len ? gram[(uint64_t)i * d + k] * inv_nm1 : 0.0;
+    }
+    if (t == 0) failed = 0;
+    if (len != 0 && sub == 0) {                                    // column 0 = position 0 of each row
+        col[0][r0] = a[0];
+        if (r1 != r0) col[0][r1] = gram[(uint64_t)r1 * d] * inv_nm1;
+    }
+    double min_pivot = INFINITY;
+    for (uint32_t j = 0; j < d; ++j) {
+        __syncthreads();
+        const double *c = col[j & 1];
+        double *cn = col[(j + 1) & 1];
+        const double pivot = c[j];
+        if (!(pivot > 0.0)) {                                      // uniform: every thread reads the same value
+            if (t == 0) failed = 1;
+            break;
+        }
+        min_pivot = fmin(min_pivot, pivot);
+        const double inv = 1.0 / pivot, rs = 1.0 / sqrt(pivot);
+        const double ci0 = len != 0 ? c[r0] * inv : 0.0, ci1 = len != 0 ? c[r1] * inv : 0.0;
+        // the slot coordinates are two instructions each; opaque copies keep the compiler from hoisting 65 sets of them
+        // (and their predicate masks) out of the column loop, which spilled 350 registers
+        uint32_t sub_j = sub, len_j = len, len0_j = len0;
+        asm volatile("" : "+v"(sub_j), "+v"(len_j), "+v"(len0_j));
+#pragma unroll
+        for (int s = 0; s < kCholSlots; ++s) {
+            const uint32_t p = (uint32_t)s * 4 + sub_j;
+            if (p >= len_j) continue;
+            const bool second = p >= len0_j;
+            const uint32_t k = second ? p - len0_j : p;
+            if (k == j) {
+                a[s] = a[s] * rs;                                  // final: L[i][j] (the diagonal becomes sqrt(pivot))
+            } else if (k > j) {
+                a[s] -= (second ? ci1 : ci0) * c[k];
+                if (k == j + 1) cn[second ? r1 : r0] = a[s];       // the next column, still unscaled
+            }
+        }
+    }
+    __syncthreads();
+    const bool bad = failed != 0;
+#pragma unroll
+    for (int s = 0; s < kCholSlots; ++s) {
+        const uint32_t p = (uint32_t)s * 4 + sub;
+        const bool second = p >= len0;
+        if (p < len) lfull[(uint64_t)(second ? r1 : r0) * d + (second ? p - len0 : p)] = a[s];
+    }
+    for (uint32_t e = t; e < d * d; e += kCholThreads) transform[e] = 0.0f;
+    if (t == 0) {
+        meta[0] = bad ? 1.0 : 0.0;
+        meta[1] = min_pivot;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (bad || t >= d) return;
+    // Column t of M = L^-1 by forward substitution, M[i] = -(sum_{t <= k < i} L[i][k] M[k]) / L[i][i] for i > t.  The
+    // column is parked in the unused upper triangle, row t of lfull (this thread is its only reader and writer, program
+    // order suffices), and leaves as row t of the transform: T[t][i] = (L^-T)[t][i] = M[i][t].
+    double *m = lfull + (uint64_t)t * d;
+    const double m_tt = 1.0 / lfull[(uint64_t)t * d + t];
+    transform[(uint64_t)t * d + t] = (float)m_tt;
+    for (uint32_t i = t + 1; i < d; ++i) {
+        const double *li = lfull + (uint64_t)i * d;
+        double sum = li[t] * m_tt;
+        for (uint32_t k = t + 1; k < i; ++k) sum += li[k] * m[k];
+        const double v = -sum / li[i];
+        m[i] = v;
+        transform[(uint64_t)t * d + i] = (float)v;
+    }
+}
+
 inline uint64_t align256(uint64_t b) { return (b + 255) / 256 * 256; }
 
 struct TransformWs {      // carved out of the caller's workspace
@@ -159,15 +257,27 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
                                      hipStream_t stream) {
     CL_REQUIRE(gram != nullptr && transform != nullptr && workspace != nullptr, "gram / transform / workspace is NULL");
     CL_REQUIRE(n >= 2 && d > 0 && d <= (1u << 15), "bad shape");
+    int device = 0;
+    CL_HIP(hipGetDevice(&device));
+    const TransformWs w = carve_transform(workspace, d);
+    const uint64_t elems = (uint64_t)d * d;
+    if (d <= 256) {
+        // our own single-launch kernel: no rocBLAS underneath (whose first use in a process loads its whole kernel
+        // library — minutes on a cold box), nothing that synchronises with the host except the 16-byte verdict
+        hipLaunchKernelGGL(cholesky_whiten_kernel, dim3(1), dim3(kCholThreads), 0, stream, gram, 1.0 / (double)(n - 1), d, w.cov,
+                           transform, w.w);
+        CL_HIP(hipGetLastError());
+        double meta[2] = {1.0, 0.0};
+        CL_HIP(hipMemcpyAsync(meta, w.w, sizeof(meta), hipMemcpyDeviceToHost, stream));
+        CL_HIP(hipStreamSynchronize(stream));
+        CL_HIP(hipMemsetAsync(w.info, 0, sizeof(int), stream));            // whiten_info(): nothing failed to converge
+        return (meta[0] != 0.0 || !(meta[1] >= 1e-8)) ? 1 : CLEORA_OK;
+    }
     Solver &s = solver();
     if (!s.lib) {
         set_error("whitening needs rocSOLVER (dlopen failed: " + s.error + "); set CLEORA_ROCSOLVER to its path");
         return CLEORA_E_HIP;
     }
-    int device = 0;
-    CL_HIP(hipGetDevice(&device));
-    const TransformWs w = carve_transform(workspace, d);
-    const uint64_t elems = (uint64_t)d * d;
     hipLaunchKernelGGL(cov_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, gram, elems,
                        1.0 / (double)(n - 1), w.cov);
     CL_HIP(hipGetLastError());

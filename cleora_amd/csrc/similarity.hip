@@ -206,7 +206,7 @@ int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint
         float *so = s1;
         uint32_t *io = i1;
         uint64_t ostride = l1;
-        for (int level = 0;; ++level) {
+        for (;;) {
             const uint64_t nb = chunks_of(len);
             if (nb == 1) {   // final: straight into the caller's arrays
                 hipLaunchKernelGGL(topk_chunk_kernel, dim3(1, nq), dim3(256), 0, stream, sin, iin, len, stride, k,

@@ -16,6 +16,10 @@ x0 = torch.empty((n, d), device=dev)
 _hip.check(L.cleora_init_dev(synth.entity_hashes(n, 0, dev).data_ptr(), n, d, 0, x0.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
 iters = 10
+# the plain loop (embed_fast: SpMM + fused L2, the partner buffer searched on its own iterations) for comparison with bench.py's step
+x = x0.clone()
+_hip.check(L.cleora_embed_dev(gr.handle, x.data_ptr(), 0, d, 40, 0.0, 0.0, 0, None))
+print(f"{'C2' if c2 else 'C3'} plain embed loop, 40 iterations incl. the placement search on the way: {L.cleora_last_embed_loop_ms() / 40:.2f} ms/iter", flush=True)
 for label, thr in (("overlapped", 0.0), ("sequential+rmse", 1e-30), ("overlapped", 0.0)):
     x = x0.clone()
     _hip.check(L.cleora_embed_dev(gr.handle, x.data_ptr(), 0, d, iters, 0.0, thr, _hip.F_WHITEN, None))

@@ -182,7 +182,11 @@ def test_cleora_whiten_errors_and_single_row():
         _hip.check(L.cleora_whiten_dev(dx.ptr, 8, 4, 8, 0, dx.ptr, 8, ws.ptr, None, None))
 
 
-@pytest.mark.parametrize("n,d,iters,rw,kind", [(20_000, 64, 6, 0.0, 0), (6000, 256, 4, 0.3, 1), (3000, 32, 5, 1.5, 0)])
+@pytest.mark.parametrize("n,d,iters,rw,kind", [(20_000, 64, 6, 0.0, 0), (6000, 256, 4, 0.3, 1), (3000, 32, 5, 1.5, 0),
+                                               # the in-house Cholesky kernel (d <= 256): tiny, odd, one below the limit;
+                                               # 320 takes rocSOLVER's potrf / trtri
+                                               (500, 8, 4, 0.0, 0), (4000, 33, 4, 0.0, 0), (3000, 255, 3, 0.0, 1),
+                                               (2500, 1, 3, 0.0, 0), (3000, 320, 3, 0.0, 0)])
 def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, kind):
     """cleora_embed + CLEORA_F_WHITEN without a convergence test runs SpMM(t+1) beside Gram / eigh(t), taking the SpMM
     before the projection (A ((Y - mu) T) = (A Y - (A 1) mu^T) T).  With a (never met) convergence threshold the same

@@ -119,99 +119,192 @@ __global__ __launch_bounds__(256) void tri_transform_kernel(const double *__rest
 
 // ---- Cholesky whitening transform for d <= 256 in ONE launch, no library, no host synchronisation inside -------------
 // cov = gram / (n-1) = L L^T ;  transform = L^-T as f32 (row-major d x d, upper triangular).
-// One workgroup of 512 threads keeps the lower triangle of the matrix in REGISTERS (d (d+1)/2 <= 32 896 values; 512 KiB
-// of f64 would not fit the LDS).  Ownership is by ROW PAIRS so that a slot's (i, k) costs one compare instead of a stored
-// index: rows r and d-1-r together hold d+1 elements, four threads share a pair, thread `sub` of the four owns positions
-// sub, sub+4, ... of the pair's concatenated rows — at most 65 values per thread.  The factorisation is right-looking
-// with one barrier per column: the still-unscaled column j+1 is published to LDS by its owners at the end of step j,
-// every thread reads the pivot from it and folds the scaling into its update, a -= c_i c_k / pivot.  L then goes to
-// global scratch and thread j < d solves L m = e_j forward (column j of L^-1), writing it as row j of the transform.
-// meta[0] = 0 ok / 1 a pivot was not positive, meta[1] = smallest pivot (= squared diagonal of L).
-constexpr int kCholSlots = 65, kCholThreads = 512;
+// One workgroup of 512 threads keeps a triangle of the matrix in REGISTERS (d (d+1)/2 <= 32 896 values; 512 KiB of f64
+// would not fit the LDS) and runs two right-looking eliminations with one barrier per step:
+//   phase 1, the factorisation.  Ownership by COLUMN pairs: columns q and d-1-q hold d+1 entries together; the four threads
+//     of pair q own positions sub, sub+4, ... of the two columns laid end to end — at most 65 values per thread, and a
+//     slot's coordinates cost one compare.  Step j: everyone reads the still-unscaled column j from LDS (published at
+//     the end of step j-1 by its owners, one wave), a(i,k) -= c_i c_k / pivot with c_k / pivot hoisted (two per thread);
+//     the owners of column j scale it (it is final: L[:, j]); the owners of column j+1 publish theirs.  Threads whose
+//     columns are both final skip the step (whole waves retire as j advances).
+//   phase 2, M = L^-1 by the same scheme on rows: M starts as I; step j: row j of M is final after / L[j][j], and
+//     m(i,k) -= (L[i][j] / L[j][j]) m_j(k) for i > j.  Ownership by ROW pairs (rows q and d-1-q), the multiplier is per
+//     row (two per thread), row j of M travels through LDS, column j of L is prefetched a step ahead from the
+//     transposed copy phase 1 left in global scratch.  T[k][i] = M[i][k] leaves as f32.
+// meta[0] = 0 ok / 1 a pivot was not positive, meta[1] = smallest pivot (= squared diagonal of L).  The ownership and
+// update order were checked against numpy in an index-exact emulation before this was written (d = 1 ... 256).
+constexpr int kCholSlots = 65, kCholThreads = 512, kCholPad = 8;
 
 __global__ __launch_bounds__(kCholThreads) void cholesky_whiten_kernel(const double *__restrict__ gram, double inv_nm1,
-                                                                       uint32_t d, double *__restrict__ lfull,
+                                                                       uint32_t d, double *__restrict__ lt,
                                                                        float *__restrict__ transform,
                                                                        double *__restrict__ meta) {
-    __shared__ double col[2][256];
+    // vb: phase 1, column j of the trailing matrix, unscaled; phase 2, row j of M, unscaled.  Padded on both sides so that a
+    // slot's read address is one of two per-thread bases plus a constant (32 s) with no clamp: indices -8 .. 519 exist.
+    __shared__ double vb_store[2][kCholPad + 520];
+    __shared__ double lb[2][256];      // phase 2: column j of L
+    double *const vb0 = vb_store[0] + kCholPad, *const vb1 = vb_store[1] + kCholPad;
     __shared__ int failed;
-    const uint32_t t = threadIdx.x, pair = t >> 2, sub = t & 3;
-    const uint32_t r0 = pair, r1 = d - 1 - pair;                   // r0 <= r1 for the pairs that exist
-    const uint32_t len0 = r0 + 1;                                  // row r0 holds k = 0..r0
-    const uint32_t len = pair < (d + 1) / 2 ? (r0 == r1 ? len0 : d + 1) : 0;
+    const uint32_t t = threadIdx.x, q = t >> 2, sub = t & 3;
+    __builtin_amdgcn_s_setprio(3);                                 // one latency-bound workgroup beside a chip full of SpMM waves
+    const bool active = q < (d + 1) / 2;
+    const uint32_t l0 = q, l1 = d - 1 - q;                         // the two lines (columns, then rows) of this thread
     double a[kCholSlots];
+
+    // ------------------------------------------------ phase 1: L ------------------------------------------------
+    uint32_t len0 = d - l0;                                        // column l0 holds rows l0..d-1; then column l1, rows l1..
+    uint32_t len_all = active ? (l0 == l1 ? len0 : d + 1) : 0u;   // an odd d leaves the middle line unpaired
 #pragma unroll
     for (int s = 0; s < kCholSlots; ++s) {
         const uint32_t p = (uint32_t)s * 4 + sub;
         const bool second = p >= len0;
-        const uint32_t i = second ? r1 : r0, k = second ? p - len0 : p;
-        a[s] = p < len ? gram[(uint64_t)i * d + k] * inv_nm1 : 0.0;
+        const uint32_t i = second ? p - 1 : l0 + p, k = second ? l1 : l0;
+        a[s] = p < len_all ? gram[(uint64_t)i * d + k] * inv_nm1 : 0.0;
     }
+    for (uint32_t e = t; e < d * d; e += kCholThreads) transform[e] = 0.0f;
     if (t == 0) failed = 0;
-    if (len != 0 && sub == 0) {                                    // column 0 = position 0 of each row
-        col[0][r0] = a[0];
-        if (r1 != r0) col[0][r1] = gram[(uint64_t)r1 * d] * inv_nm1;
+    for (uint32_t e = t; e < kCholPad + 520; e += kCholThreads) vb_store[0][e] = vb_store[1][e] = 0.0;   // finite everywhere:
+    if (t < 256) lb[0][t] = lb[1][t] = 0.0;                                                              // retired slots use 0 x it
+    __syncthreads();
+    if (active && l0 == 0) {                                       // column 0
+#pragma unroll
+        for (int s = 0; s < kCholSlots; ++s) {
+            const uint32_t p = (uint32_t)s * 4 + sub;
+            if (p < len_all && p < len0) vb0[p] = a[s];
+        }
     }
     double min_pivot = INFINITY;
     for (uint32_t j = 0; j < d; ++j) {
         __syncthreads();
-        const double *c = col[j & 1];
-        double *cn = col[(j + 1) & 1];
+        const double *c = (j & 1) ? vb1 : vb0;
+        double *cn = (j & 1) ? vb0 : vb1;
         const double pivot = c[j];
-        if (!(pivot > 0.0)) {                                      // uniform: every thread reads the same value
-            if (t == 0) failed = 1;
-            break;
-        }
+        if (!(pivot > 0.0) && t == 0) failed = 1;                  // no early exit (a second loop exit made the compiler copy
+                                                                   // all 65 values every step): the NaNs that follow are discarded
         min_pivot = fmin(min_pivot, pivot);
         const double inv = 1.0 / pivot, rs = 1.0 / sqrt(pivot);
-        const double ci0 = len != 0 ? c[r0] * inv : 0.0, ci1 = len != 0 ? c[r1] * inv : 0.0;
-        // the slot coordinates are two instructions each; opaque copies keep the compiler from hoisting 65 sets of them
-        // (and their predicate masks) out of the column loop, which spilled 350 registers
-        uint32_t sub_j = sub, len_j = len, len0_j = len0;
-        asm volatile("" : "+v"(sub_j), "+v"(len_j), "+v"(len0_j));
+        // opaque copies keep the compiler from hoisting 65 sets of slot coordinates (and their predicate masks) out of
+        // the step loop, which spilled 350 registers
+        uint32_t sub_j = sub, len0_j = len0, l0_j = l0, len_j = len_all;
+        asm volatile("" : "+v"(sub_j), "+v"(len0_j), "+v"(l0_j), "+v"(len_j));
+        // a wave-uniform branch (lanes whose columns are final run with multipliers 0): a divergent one made the compiler
+        // keep two copies of the 65 values across it
+        const bool go = active && l1 > j;
+        if (__builtin_amdgcn_ballot_w64(go) != 0) {
+            const double m0 = (go && l0 > j) ? c[l0] * inv : 0.0, m1 = go ? c[l1] * inv : 0.0;
+            // LDS reads in batches of 13 (5 x 13 = 65): issued back to back, then consumed — left alone the compiler
+            // waits for every single read before its multiply, ~100 cycles x 65 per step.  Address = one of two bases
+            // (first column: row l0 + p, second: row p - 1) + the constant 4 s: compare, select, read.
+            const int c0 = (int)(l0_j + sub_j), c1 = (int)sub_j - 1;
 #pragma unroll
-        for (int s = 0; s < kCholSlots; ++s) {
-            const uint32_t p = (uint32_t)s * 4 + sub_j;
-            if (p >= len_j) continue;
-            const bool second = p >= len0_j;
-            const uint32_t k = second ? p - len0_j : p;
-            if (k == j) {
-                a[s] = a[s] * rs;                                  // final: L[i][j] (the diagonal becomes sqrt(pivot))
-            } else if (k > j) {
-                a[s] -= (second ? ci1 : ci0) * c[k];
-                if (k == j + 1) cn[second ? r1 : r0] = a[s];       // the next column, still unscaled
+            for (int s0 = 0; s0 < kCholSlots; s0 += 13) {
+                double cv[13];
+#pragma unroll
+                for (int u = 0; u < 13; ++u) cv[u] = c[((uint32_t)(4 * (s0 + u)) + sub_j >= len0_j ? c1 : c0) + 4 * (s0 + u)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 13; ++u)
+                    a[s0 + u] = __builtin_fma(-((uint32_t)(4 * (s0 + u)) + sub_j >= len0_j ? m1 : m0), cv[u], a[s0 + u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (active && (l0 == j || l1 == j)) {                      // column j is final: scale it
+            const bool which = l0 != j;
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s) {
+                const uint32_t p = (uint32_t)s * 4 + sub_j;
+                if (p < len_j && (p >= len0_j) == which) a[s] *= rs;
+            }
+        }
+        if (active && (l0 == j + 1 || l1 == j + 1)) {              // publish column j+1, updated and unscaled
+            const bool which = l0 != j + 1;
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s) {
+                const uint32_t p = (uint32_t)s * 4 + sub_j;
+                const bool second = p >= len0_j;
+                if (p < len_j && second == which) cn[second ? p - 1 : l0_j + p] = a[s];
             }
         }
     }
     __syncthreads();
     const bool bad = failed != 0;
 #pragma unroll
-    for (int s = 0; s < kCholSlots; ++s) {
+    for (int s = 0; s < kCholSlots; ++s) {                         // lt[k][i] = L[i][k]: column k of L is contiguous
         const uint32_t p = (uint32_t)s * 4 + sub;
         const bool second = p >= len0;
-        if (p < len) lfull[(uint64_t)(second ? r1 : r0) * d + (second ? p - len0 : p)] = a[s];
+        if (p < len_all) lt[(uint64_t)(second ? l1 : l0) * d + (second ? p - 1 : l0 + p)] = a[s];
     }
-    for (uint32_t e = t; e < d * d; e += kCholThreads) transform[e] = 0.0f;
     if (t == 0) {
         meta[0] = bad ? 1.0 : 0.0;
         meta[1] = min_pivot;
     }
     __threadfence_block();
     __syncthreads();
-    if (bad || t >= d) return;
-    // Column t of M = L^-1 by forward substitution, M[i] = -(sum_{t <= k < i} L[i][k] M[k]) / L[i][i] for i > t.  The
-    // column is parked in the unused upper triangle, row t of lfull (this thread is its only reader and writer, program
-    // order suffices), and leaves as row t of the transform: T[t][i] = (L^-T)[t][i] = M[i][t].
-    double *m = lfull + (uint64_t)t * d;
-    const double m_tt = 1.0 / lfull[(uint64_t)t * d + t];
-    transform[(uint64_t)t * d + t] = (float)m_tt;
-    for (uint32_t i = t + 1; i < d; ++i) {
-        const double *li = lfull + (uint64_t)i * d;
-        double sum = li[t] * m_tt;
-        for (uint32_t k = t + 1; k < i; ++k) sum += li[k] * m[k];
-        const double v = -sum / li[i];
-        m[i] = v;
-        transform[(uint64_t)t * d + i] = (float)v;
+    if (bad) return;
+
+    // ---------------------------------------------- phase 2: M = L^-1 ----------------------------------------------
+    len0 = l0 + 1;                                                 // row l0 holds columns 0..l0; then row l1, columns 0..l1
+    len_all = active ? (l0 == l1 ? len0 : d + 1) : 0u;
+#pragma unroll
+    for (int s = 0; s < kCholSlots; ++s) {
+        const uint32_t p = (uint32_t)s * 4 + sub;
+        const bool second = p >= len0;
+        a[s] = (p < len_all && (second ? p - len0 : p) == (second ? l1 : l0)) ? 1.0 : 0.0;
+    }
+    for (uint32_t e = t; e < kCholPad + 520; e += kCholThreads) vb_store[0][e] = vb_store[1][e] = 0.0;
+    if (t < 256) lb[0][t] = t < d ? lt[t] : 0.0;                   // column 0 of L
+    __syncthreads();
+    if (t == 0) vb0[0] = 1.0;                                      // row 0 of M (unscaled) = e_0
+    for (uint32_t j = 0; j < d; ++j) {
+        __syncthreads();
+        const double *r = (j & 1) ? vb1 : vb0, *lc = lb[j & 1];
+        double *rn = (j & 1) ? vb0 : vb1, *lcn = lb[(j + 1) & 1];
+        const double l_next = (t < d && j + 1 < d) ? lt[(uint64_t)(j + 1) * d + t] : 0.0;   // consumed at the end of the step
+        const double rinv = 1.0 / lc[j];
+        uint32_t sub_j = sub, len0_j = len0, len_j = len_all;
+        asm volatile("" : "+v"(sub_j), "+v"(len0_j), "+v"(len_j));
+        const bool go = active && l1 > j;
+        if (__builtin_amdgcn_ballot_w64(go) != 0) {
+            const double m0 = (go && l0 > j) ? lc[l0] * rinv : 0.0, m1 = go ? lc[l1] * rinv : 0.0;
+            const int r0 = (int)sub_j, r1 = (int)sub_j - (int)len0_j;  // first row: column p, second: column p - len0
+#pragma unroll
+            for (int s0 = 0; s0 < kCholSlots; s0 += 13) {
+                double rv[13];
+#pragma unroll
+                for (int u = 0; u < 13; ++u) rv[u] = r[((uint32_t)(4 * (s0 + u)) + sub_j >= len0_j ? r1 : r0) + 4 * (s0 + u)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 13; ++u)
+                    a[s0 + u] = __builtin_fma(-((uint32_t)(4 * (s0 + u)) + sub_j >= len0_j ? m1 : m0), rv[u], a[s0 + u]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (active && (l0 == j || l1 == j)) {                      // row j is final
+            const bool which = l0 != j;
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s) {
+                const uint32_t p = (uint32_t)s * 4 + sub_j;
+                if (p < len_j && (p >= len0_j) == which) a[s] *= rinv;
+            }
+        }
+        if (active && (l0 == j + 1 || l1 == j + 1)) {              // publish row j+1
+            const bool which = l0 != j + 1;
+#pragma unroll
+            for (int s = 0; s < kCholSlots; ++s) {
+                const uint32_t p = (uint32_t)s * 4 + sub_j;
+                const bool second = p >= len0_j;
+                if (p < len_j && second == which) rn[second ? p - len0_j : p] = a[s];
+            }
+        }
+        if (t < 256) lcn[t] = l_next;
+    }
+    uint32_t sub_e = sub, len0_e = len0, len_e = len_all;          // opaque again: 65 store addresses computed ahead of the
+    asm volatile("" : "+v"(sub_e), "+v"(len0_e), "+v"(len_e));     // loop would live across it in scratch
+#pragma unroll
+    for (int s = 0; s < kCholSlots; ++s) {                         // T[k][i] = M[i][k]
+        const uint32_t p = (uint32_t)s * 4 + sub_e;
+        const bool second = p >= len0_e;
+        if (p < len_e) transform[(uint64_t)(second ? p - len0_e : p) * d + (second ? l1 : l0)] = (float)a[s];
     }
 }
 
@@ -261,7 +354,8 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
     CL_HIP(hipGetDevice(&device));
     const TransformWs w = carve_transform(workspace, d);
     const uint64_t elems = (uint64_t)d * d;
-    if (d <= 256) {
+    static const bool library_route = std::getenv("CLEORA_CHOLESKY_LIBRARY") != nullptr;   // A/B switch
+    if (d <= 256 && !library_route) {
         // our own single-launch kernel: no rocBLAS underneath (whose first use in a process loads its whole kernel
         // library — minutes on a cold box), nothing that synchronises with the host except the 16-byte verdict
         hipLaunchKernelGGL(cholesky_whiten_kernel, dim3(1), dim3(kCholThreads), 0, stream, gram, 1.0 / (double)(n - 1), d, w.cov,

@@ -12,9 +12,10 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wstats" -o whiten -- python "$root/scripts/whiten_stage_probe.py" 2 > "$out/whiten_stats.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/write.log" 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/fetch_nohot.log" 2>&1
+# cross-check of FETCH_SIZE against the raw L2 -> fabric request counters it derives from (and how many of them go to DRAM
+# rather than to a peer / the host); round 1 also ran the policy-off passes (fetch_nohot, hit_nohot: profiles/r01_pmc.json)
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d "$out/ea" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/ea.log" 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/hit.log" 2>&1
-timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit_nohot" -o pmc -- python "$root/scripts/pmc_probe.py" --hot 0 > "$out/hit_nohot.log" 2>&1
 # whitening kernels: MFMA pipe occupancy (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, GRBM_GUI_ACTIVE per XCD)
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/wpmc" -o pmc -- python "$root/scripts/whiten_stage_probe.py" 2 > "$out/wpmc.log" 2>&1
 # BASELINE config 2 (bipartite 1M / 20M, d = 256): kernel time and HBM bytes of the same kernel
@@ -23,7 +24,7 @@ timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/c2_fetch" -o
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/c2_write" -o pmc -- python "$root/scripts/pmc_probe.py" --graph c2 > "$out/c2_write.log" 2>&1
 timeout 600 python "$root/bench.py" > "$out/bench_plain.log" 2>&1
 tail -1 "$out/bench_plain.log"
-for f in fetch write fetch_nohot hit hit_nohot wpmc c2_stats c2_fetch c2_write; do tail -1 "$out/$f.log" | cut -c1-200; done
+for f in fetch write ea hit wpmc c2_stats c2_fetch c2_write; do tail -1 "$out/$f.log" | cut -c1-200; done
 # keep the merge under the gpurun_out size limit: only the summaries that summarize_profile.py reads
 find "$out" -type f ! -name "*_kernel_stats.csv" ! -name "pmc_counter_collection.csv" ! -name "*.log" -delete
 find "$out" -type f -size +8M -exec sh -c 'grep cleora "$1" > "$1.tmp"; head -1 "$1" | cat - "$1.tmp" > "$1.f"; mv "$1.f" "$1"; rm "$1.tmp"' _ {} \;

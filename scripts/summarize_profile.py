@@ -102,6 +102,15 @@ for sub, key in (("hit", "policy_on"), ("hit_nohot", "policy_off")):
         policy[f"l2_requests_{key}"] = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
 if policy:
     out["gather_cache_policy"] = policy
+ea = spmm_counters("ea")
+if ea:
+    # FETCH_SIZE is derived from these; 64-B requests unless flagged 32B.  "_DRAM" = destined for the memory controller (as
+    # opposed to a peer GPU or the host) — still counted on the L2 side of the Infinity Cache.
+    rd, rd32, dram = ea.get("TCC_EA0_RDREQ_sum", 0.0), ea.get("TCC_EA0_RDREQ_32B_sum", 0.0), ea.get("TCC_EA0_RDREQ_DRAM_sum", 0.0)
+    out["ea_read_requests"] = {"kernel": "spmm_rows_kernel<64, 1, 4, true, true>", "TCC_EA0_RDREQ": rd, "TCC_EA0_RDREQ_32B": rd32,
+                               "TCC_EA0_RDREQ_DRAM": dram, "bytes_at_64B": (rd - rd32) * 64 + rd32 * 32,
+                               "bytes_at_64B_x_fetch_correction": ((rd - rd32) * 64 + rd32 * 32) * fetch_corr,
+                               "dram_fraction_of_requests": dram / rd if rd else None}
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
 dom = sorted((k for k in out["kernels"] if k.startswith("spmm_rows_kernel")), key=lambda k: out["kernels"][k]["launches"])[-1]
 # stamp: bench.py only trusts this figure for the build of the kernel it was measured on (run this script right after

@@ -8,9 +8,11 @@
 // bound lazily with dlopen on the first whitening call, so the propagation path has no dependency
 // on it and hosts that never whiten never load it.  CLEORA_ROCSOLVER=<path> overrides the name.
 #include <dlfcn.h>
+#include <link.h>
 #include <rocsolver/rocsolver.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <map>
 
 #include "common.h"
@@ -27,6 +29,7 @@ struct Solver {
     decltype(&rocsolver_dpotrf) dpotrf = nullptr;
     decltype(&rocsolver_dtrtri) dtrtri = nullptr;
     std::string error;
+    bool rocblas_was_resident = false;           // rocBLAS already mapped by the host before we loaded anything (see below)
     std::mutex mu;                               // one eigenproblem at a time per process
     std::map<int, rocblas_handle> handles;       // one rocBLAS handle per device, created on demand
 };
@@ -35,6 +38,12 @@ Solver &solver() {
     static Solver s;
     static std::once_flag once;
     std::call_once(once, [] {
+        dl_iterate_phdr(
+            [](dl_phdr_info *info, size_t, void *found) {
+                if (info->dlpi_name && std::strstr(info->dlpi_name, "librocblas")) *static_cast<bool *>(found) = true;
+                return 0;
+            },
+            &s.rocblas_was_resident);
         const char *env = std::getenv("CLEORA_ROCSOLVER");
         const char *names[] = {env, "librocsolver.so.0", "librocsolver.so"};
         for (const char *name : names) {
@@ -354,10 +363,17 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
     CL_HIP(hipGetDevice(&device));
     const TransformWs w = carve_transform(workspace, d);
     const uint64_t elems = (uint64_t)d * d;
-    static const bool library_route = std::getenv("CLEORA_CHOLESKY_LIBRARY") != nullptr;   // A/B switch
+    // Two routes to the same transform for d <= 256 (larger d: rocSOLVER only).
+    //   "library": rocSOLVER's potrf + trtri — many small launches that slip in beside the SpMM of the overlapped loop
+    //     (7.96 ms / 53.3 ms per whitened iteration at BASELINE configs 2 / 3), but they sit on rocBLAS, whose first use in
+    //     a process loads its kernel library: seconds when warm, 6 minutes measured in a torch-free C host on a cold box.
+    //   "kernel": the single launch above — no rocBLAS, but it needs a whole CU's registers and therefore starts only
+    //     when the SpMM beside it drains (9.9 ms / 54.7 ms).
+    // Default: the library where the host process had rocBLAS mapped already (a PyTorch host), the kernel elsewhere.
+    // CLEORA_CHOLESKY=library|kernel overrides (read per call).
+    bool library_route = solver().rocblas_was_resident;
+    if (const char *env = std::getenv("CLEORA_CHOLESKY")) library_route = std::strcmp(env, "kernel") != 0;
     if (d <= 256 && !library_route) {
-        // our own single-launch kernel: no rocBLAS underneath (whose first use in a process loads its whole kernel
-        // library — minutes on a cold box), nothing that synchronises with the host except the 16-byte verdict
         hipLaunchKernelGGL(cholesky_whiten_kernel, dim3(1), dim3(kCholThreads), 0, stream, gram, 1.0 / (double)(n - 1), d, w.cov,
                            transform, w.w);
         CL_HIP(hipGetLastError());

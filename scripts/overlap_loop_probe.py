@@ -23,4 +23,4 @@ print(f"{'C2' if c2 else 'C3'} plain embed loop, 40 iterations incl. the placeme
 for label, thr in (("overlapped", 0.0), ("sequential+rmse", 1e-30), ("overlapped", 0.0)):
     x = x0.clone()
     _hip.check(L.cleora_embed_dev(gr.handle, x.data_ptr(), 0, d, iters, 0.0, thr, _hip.F_WHITEN, None))
-    print(f"{'C2' if c2 else 'C3'} {label}: {L.cleora_last_embed_loop_ms() / iters:.2f} ms/iter  (co_blocks={os.environ.get('CLEORA_GRAM_CO_BLOCKS', '1')})", flush=True)
+    print(f"{'C2' if c2 else 'C3'} {label}: {L.cleora_last_embed_loop_ms() / iters:.2f} ms/iter  (Cholesky route: {os.environ.get('CLEORA_CHOLESKY', 'default')})", flush=True)

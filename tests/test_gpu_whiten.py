@@ -182,12 +182,14 @@ def test_cleora_whiten_errors_and_single_row():
         _hip.check(L.cleora_whiten_dev(dx.ptr, 8, 4, 8, 0, dx.ptr, 8, ws.ptr, None, None))
 
 
-@pytest.mark.parametrize("n,d,iters,rw,kind", [(20_000, 64, 6, 0.0, 0), (6000, 256, 4, 0.3, 1), (3000, 32, 5, 1.5, 0),
-                                               # the in-house Cholesky kernel (d <= 256): tiny, odd, one below the limit;
-                                               # 320 takes rocSOLVER's potrf / trtri
-                                               (500, 8, 4, 0.0, 0), (4000, 33, 4, 0.0, 0), (3000, 255, 3, 0.0, 1),
-                                               (2500, 1, 3, 0.0, 0), (3000, 320, 3, 0.0, 0)])
-def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, kind):
+@pytest.mark.parametrize("n,d,iters,rw,kind,route", [
+    (20_000, 64, 6, 0.0, 0, "library"), (6000, 256, 4, 0.3, 1, "library"), (3000, 32, 5, 1.5, 0, "library"),
+    (3000, 320, 3, 0.0, 0, "library"),                       # d > 256: rocSOLVER's potrf / trtri whatever the switch says
+    # the in-house Cholesky kernel (d <= 256): tiny, odd, one below the limit, the limit
+    (20_000, 64, 6, 0.0, 0, "kernel"), (6000, 256, 4, 0.3, 1, "kernel"), (500, 8, 4, 0.0, 0, "kernel"),
+    (4000, 33, 4, 0.0, 0, "kernel"), (3000, 255, 3, 0.0, 1, "kernel"), (2500, 1, 3, 0.0, 0, "kernel"),
+    (3000, 130, 3, 0.0, 0, None)])                           # None: the library's own choice for this process
+def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, kind, route, monkeypatch):
     """cleora_embed + CLEORA_F_WHITEN without a convergence test runs SpMM(t+1) beside Gram / eigh(t), taking the SpMM
     before the projection (A ((Y - mu) T) = (A Y - (A 1) mu^T) T).  With a (never met) convergence threshold the same
     call keeps the reference's sequential order: both must agree to f32 rounding — columns up to sign, 2e-3 relative
@@ -195,6 +197,10 @@ def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, k
     import ctypes
     from tests.graphs import random_csr
     import oracle
+    if route:
+        monkeypatch.setenv("CLEORA_CHOLESKY", route)         # read per call by the library
+    else:
+        monkeypatch.delenv("CLEORA_CHOLESKY", raising=False)
     rowptr, col, vl, vs = random_csr(n, 9, seed=n + d, empty_frac=0.02, hubs=[(13, 1400)])
     g = _hip.Graph.from_host(rowptr, col, vl, vs)
     x0 = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)

@@ -341,6 +341,8 @@ def run_whitened(args, g, x, dev, L, iters):
     torch.cuda.empty_cache()
     xo = x[:n].clone()
     loops = {}
+    # untimed two-iteration call first: the first Cholesky / eigensolver call of a process initialises rocSOLVER and rocBLAS
+    _hip.check(L.cleora_embed_dev(gr.handle, xo.data_ptr(), _hip.LEFT, d, 2, 0.0, 0.0, _hip.F_WHITEN, None))
     for label, thr in (("overlapped", 0.0), ("sequential", 1e-30)):      # a never-met threshold keeps the reference's order
         xo.copy_(x[:n])
         _hip.check(L.cleora_embed_dev(gr.handle, xo.data_ptr(), _hip.LEFT, d, iters, 0.0, thr, _hip.F_WHITEN, None))
@@ -350,7 +352,7 @@ def run_whitened(args, g, x, dev, L, iters):
     out = {
         "ms_per_iter": loops["overlapped"], "iterations": iters, "iterations_per_sec": 1e3 / loops["overlapped"],
         "loop": "cleora_embed_dev + CLEORA_F_WHITEN: SpMM of iteration t+1 beside Gram / eigensolver of iteration t "
-                "(the SpMM taken before the projection); ms_per_iter = loop wall clock / iterations, incl. the final whitening",
+                "(the SpMM taken before the projection); ms_per_iter = loop wall clock / iterations, incl. the final whitening, after an untimed 2-iteration call",
         "sequential_ms_per_iter": {"c_loop_reference_order": loops["sequential"], "python_driven_with_stage_events": el / iters * 1e3},
         "placement_launch_ms": {"untuned": round(place_ms[0], 3), "chosen": round(place_ms[1], 3)},
         "kernels_ms": {"spmm_l2": ms[1] / max(c, 1) + (ms[0] + ms[2]) / max(c, 1), "column_statistics": stats_ms,

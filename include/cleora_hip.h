@@ -338,7 +338,9 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
  * an orthogonal factor that the linear steps, the rotation-invariant norm and the final PCA whitening remove): Cholesky
  * (potrf + trtri) instead of the eigensolver, falling back to it when the covariance is near-singular; the last iteration is
  * always the PCA form.  Results agree with the sequential order to f32 rounding.  Environment switches for A/B:
- * CLEORA_WHITEN_SEQUENTIAL=1 (the reference's order), CLEORA_WHITEN_PCA_ALWAYS=1 (eigensolver in every iteration). */
+ * CLEORA_WHITEN_SEQUENTIAL=1 (the reference's order), CLEORA_WHITEN_PCA_ALWAYS=1 (eigensolver in every iteration),
+ * CLEORA_CHOLESKY=library|kernel (d <= 256: rocSOLVER potrf/trtri, or the in-house single-launch kernel that needs no
+ * rocBLAS; default: the library where the host process already had rocBLAS mapped, the kernel elsewhere). */
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,

@@ -140,6 +140,41 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
     return out, checks
 
 
+def rccl_comm_or_fallback(local_rank, dev, rank, world):
+    """The C-ABI communicator, checked with one small all-reduce before anything depends on it.  If it cannot be created
+    or gives a wrong sum on ANY rank (every rank learns so over the gloo launcher group), all ranks fall back to RCCL through
+    torch.distributed's nccl backend and the bench line says so in config.collectives — a scaling run should not be
+    lost to a communicator bootstrap problem on a node this code has never seen."""
+    err = ""
+    comm = None
+    try:
+        comm = comm_mod.RcclComm.from_torch_distributed(local_rank)
+        probe = torch.full((1024,), float(rank + 1), device=dev)
+        comm.allreduce(probe)
+        torch.cuda.synchronize()
+        if not bool((probe == world * (world + 1) / 2).all()):
+            err = f"all-reduce probe gave {float(probe[0])}, expected {world * (world + 1) / 2}"
+    except Exception as e:                    # noqa: BLE001 - reported below, on every rank
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) == 1:
+        return comm, "RCCL via the C ABI (csrc/comm.hip)"
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    if rank == 0:
+        print(f"bench.py: C-ABI communicator unusable ({[e for e in errs if e]}); falling back to torch.distributed nccl",
+              file=sys.stderr, flush=True)
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:                     # noqa: BLE001
+            pass
+    group = dist.new_group(backend="nccl")
+    first = next(e for e in errs if e)
+    return comm_mod.TorchComm(group), f"RCCL via torch.distributed nccl (fallback; C-ABI communicator: {first[:200]})"
+
+
 class Launcher:
     """torch.distributed as the launcher only: barrier and max-over-ranks of host timings (gloo, CPU tensors)."""
 
@@ -416,10 +451,13 @@ def main():
     dev = torch.device("cuda", local_rank)
     L = _hip.lib()
     launcher = Launcher(world)
+    collectives = None
     if world > 1:
         dist.init_process_group("gloo")       # the launcher; the data path's collectives are the C ABI's (RCCL)
-        comm = (comm_mod.RcclComm.from_torch_distributed(local_rank) if args.backend == "rccl"
-                else comm_mod.TorchComm())
+        if args.backend == "rccl":
+            comm, collectives = rccl_comm_or_fallback(local_rank, dev, rank, world)
+        else:
+            comm, collectives = comm_mod.TorchComm(), "torch.distributed/gloo (developer mode)"
     else:
         comm = comm_mod.LocalComm()
 
@@ -501,8 +539,7 @@ def main():
                                    f"(BASELINE config 3): n={n}, nnz={nnz}, d={d}, left Markov; one step = SpMM + fused L2 norm"
                                    + ("" if world == 1 else " + the partition's exchange step"),
                        "n": n, "nnz": nnz, "d": d, "parallelism": r["parallelism"], "partition": best, "seed": 2,
-                       "collectives": None if world == 1 else ("RCCL via the C ABI (csrc/comm.hip)" if args.backend == "rccl"
-                                                                else "torch.distributed/gloo (developer mode)")},
+                       "collectives": collectives},
             "roofline": r["roofline"], "checks": r["checks"], "placement_tuning": r["placement_tuning"],
             "cpu_baseline": cpu,
         }

@@ -3,6 +3,7 @@
 // reference's PyO3 methods (src/lib.rs) would call through FFI.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -504,8 +505,12 @@ int cleora_alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, voi
     }
     // The same SpMM launch is up to 12-20 % slower when the buffer it reads and the buffer it writes fall into the
     // same (physical) placement class.  bufs[0] is fixed; every partner is found by timing the real
-    // kernel on candidates drawn behind spacer allocations of varying size (which is what moves the physical placement;
-    // the spacer is freed at once), until one is >= 5 % faster than the slowest seen.  One launch per candidate.
+    // kernel on candidates, one launch each, until one is >= 5 % faster than the slowest seen.  Rejected candidates stay
+    // allocated until the slot is settled — a freed buffer would be handed straight back, and what moves the next candidate
+    // to another placement is the memory in front of it.  Round 2 measured what the earlier scheme (a spacer of 6-45 % of
+    // the free memory in front of every candidate, freed at once) costs: freeing memory is ~30 ms per GB on this driver
+    // (10 GB: 290 ms) and the next hipMalloc can stall behind it for seconds — 0.2 to 15 s per call.  Now: no spacers,
+    // at most 6 candidates, and no new candidate once CLEORA_PLACEMENT_BUDGET_MS (default 1500) of wall clock are spent.
     hipLaunchKernelGGL(fill_pattern_kernel, dim3(8192), dim3(256), 0, nullptr, static_cast<float *>(bufs[0]), rows * (uint64_t)d);
     {   // arm the gather cache policy now (automatic mode waits for the third launch): candidates must be compared alike
         std::lock_guard<std::mutex> lock(g->mu);
@@ -529,21 +534,20 @@ int cleora_alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, voi
         CL_HIP(hipEventElapsedTime(out_ms, e0, e1));
         return CLEORA_OK;
     };
-    static const double kSpacer[] = {0.0, 0.20, 0.30, 0.45, 0.12, 0.38, 0.26, 0.06};   // fraction of the free memory
+    double budget_ms = 1500.0;
+    if (const char *env = std::getenv("CLEORA_PLACEMENT_BUDGET_MS")) budget_ms = std::atof(env);
+    const auto t_search = std::chrono::steady_clock::now();
     int rc = CLEORA_OK;
     bool warmed = false;
     for (uint32_t slot = 1; slot < count && rc == CLEORA_OK; ++slot) {
         void *best = nullptr;
         float best_ms = 0.f, worst_ms = 0.f, first_ms = 0.f;
-        for (int trial = 0; trial < 8; ++trial) {
-            size_t free_b = 0, total_b = 0;
-            (void)hipMemGetInfo(&free_b, &total_b);
-            void *spacer = nullptr, *cand = nullptr;
-            const uint64_t want = (uint64_t)(kSpacer[trial] * (double)free_b);
-            if (want > bytes && free_b > want + 2 * bytes && hipMalloc(&spacer, want) != hipSuccess) { spacer = nullptr; (void)hipGetLastError(); }
-            const hipError_t ce = hipMalloc(&cand, bytes);
-            if (spacer) (void)hipFree(spacer);
-            if (ce != hipSuccess) { (void)hipGetLastError(); break; }      // no room for another candidate: keep the best so far
+        std::vector<void *> rejected;
+        for (int trial = 0; trial < 6; ++trial) {
+            const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search).count();
+            if (trial >= 1 && spent > budget_ms) break;
+            void *cand = nullptr;
+            if (hipMalloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }   // no room for another candidate: keep the best so far
             if (!warmed) {                                                  // scratch, hot marks, caches: not part of any timing
                 float dummy;
                 rc = time_pair(cand, &dummy);
@@ -558,10 +562,11 @@ int cleora_alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, voi
             (void)hipEventRecord(e1, nullptr);
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) { (void)hipFree(cand); rc = CLEORA_E_HIP; set_error("event timing failed"); break; }
             if (trial == 0) first_ms = t;
-            if (!best || t < best_ms) { if (best) (void)hipFree(best); best = cand; best_ms = t; } else { (void)hipFree(cand); }
+            if (!best || t < best_ms) { if (best) rejected.push_back(best); best = cand; best_ms = t; } else { rejected.push_back(cand); }
             if (t > worst_ms) worst_ms = t;
             if (trial >= 1 && best_ms < 0.95f * worst_ms) break;          // both classes seen: keep the fast one
         }
+        for (void *p : rejected) (void)hipFree(p);
         if (!best && rc == CLEORA_OK) { set_error("out of device memory for the iterates"); rc = CLEORA_E_OOM; }
         bufs[slot] = best;
         if (ms && slot == 1) { ms[0] = first_ms; ms[1] = best_ms; }
@@ -958,11 +963,18 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
             }
             const bool found = trials.size() >= 2 && lo < 0.95f * hi;
             bool more = !(found || n_tried == 4 || it + 8 > max_iterations);
+            static const bool trace = std::getenv("CLEORA_TUNE_TRACE") != nullptr;
+            if (trace) std::fprintf(stderr, "[cleora tune] it=%llu pair=%.2f ms lo=%.2f hi=%.2f tried=%d more=%d\n",
+                                    (unsigned long long)it, trials.back().ms, lo, hi, n_tried, (int)more);
             if (more) {
                 // draw the next candidate while the rejected ones still hold their memory (a freed buffer would be
                 // handed straight back: same placement), then free every candidate but the best so far
                 DevBuf cand;
-                if (cand.alloc(bytes) == CLEORA_OK) {
+                const auto t_alloc = std::chrono::steady_clock::now();
+                const int alloc_rc = cand.alloc(bytes);
+                if (trace) std::fprintf(stderr, "[cleora tune] hipMalloc(%llu MiB) %.1f ms\n", (unsigned long long)(bytes >> 20),
+                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count());
+                if (alloc_rc == CLEORA_OK) {
                     ++n_tried;
                 } else {
                     // out of memory for another candidate (typical at C4 scale): keep the best so far.  The failed
@@ -972,8 +984,11 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
                     more = false;
                 }
                 const Trial keep = trials[best];
+                const auto t_free = std::chrono::steady_clock::now();
                 for (DevBuf &e : extra)
                     if (e.p && e.p != keep.buf) e.release();
+                if (trace) std::fprintf(stderr, "[cleora tune] release %.1f ms\n",
+                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());
                 trials.assign(1, keep);
                 if (more) {
                     for (DevBuf &e : extra)

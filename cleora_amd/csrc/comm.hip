@@ -219,14 +219,18 @@ int cleora_allgatherv_f32_dev(cleora_comm *c, float *buf, const uint64_t *offset
     if (c->allgather_algo == CLEORA_ALLGATHER_P2P) {
         // direct exchange over the fully connected xGMI mesh: every rank sends its shard to each peer and
         // receives each peer's shard, one message per link and direction
+        // (a failed call inside a group must still close the group, or every later collective on this communicator hangs)
+        ncclResult_t first = ncclSuccess;
+        auto note = [&first](ncclResult_t e) { if (first == ncclSuccess) first = e; };
         CL_RCCL(*r, r->group_start());
         for (int k = 1; k < P; ++k) {
             const int to = (me + k) % P, from = (me - k + P) % P;
             const uint64_t mine = offsets[me + 1] - offsets[me], theirs = offsets[from + 1] - offsets[from];
-            if (mine) CL_RCCL(*r, r->send(buf + offsets[me], mine, ncclFloat, to, c->comm, S(stream)));
-            if (theirs) CL_RCCL(*r, r->recv(buf + offsets[from], theirs, ncclFloat, from, c->comm, S(stream)));
+            if (mine) note(r->send(buf + offsets[me], mine, ncclFloat, to, c->comm, S(stream)));
+            if (theirs) note(r->recv(buf + offsets[from], theirs, ncclFloat, from, c->comm, S(stream)));
         }
-        CL_RCCL(*r, r->group_end());
+        note(r->group_end());
+        if (first != ncclSuccess) return rccl_fail(*r, first, "all-gather (send/recv mesh)");
         return CLEORA_OK;
     }
     if (equal) {
@@ -235,13 +239,15 @@ int cleora_allgatherv_f32_dev(cleora_comm *c, float *buf, const uint64_t *offset
             CL_RCCL(*r, r->all_gather(buf + offsets[me], buf + offsets[0], count, ncclFloat, c->comm, S(stream)));
         return CLEORA_OK;
     }
+    ncclResult_t first = ncclSuccess;
+    auto note = [&first](ncclResult_t e) { if (first == ncclSuccess) first = e; };
     CL_RCCL(*r, r->group_start());
     for (int root = 0; root < P; ++root) {
         const uint64_t count = offsets[root + 1] - offsets[root];
-        if (count)
-            CL_RCCL(*r, r->broadcast(buf + offsets[root], buf + offsets[root], count, ncclFloat, root, c->comm, S(stream)));
+        if (count) note(r->broadcast(buf + offsets[root], buf + offsets[root], count, ncclFloat, root, c->comm, S(stream)));
     }
-    CL_RCCL(*r, r->group_end());
+    note(r->group_end());
+    if (first != ncclSuccess) return rccl_fail(*r, first, "all-gather-v (grouped broadcasts)");
     return CLEORA_OK;
 }
 
@@ -306,13 +312,16 @@ int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint
     const int P = c->world, me = c->rank;
     CL_HIP(hipMemcpyAsync(recv + (uint64_t)me * elems_per_rank, send + (uint64_t)me * elems_per_rank,
                           elems_per_rank * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
+    ncclResult_t first = ncclSuccess;
+    auto note = [&first](ncclResult_t e) { if (first == ncclSuccess) first = e; };
     CL_RCCL(*r, r->group_start());
     for (int k = 1; k < P; ++k) {
         const int to = (me + k) % P, from = (me - k + P) % P;
-        CL_RCCL(*r, r->send(send + (uint64_t)to * elems_per_rank, elems_per_rank, ncclFloat, to, c->comm, S(stream)));
-        CL_RCCL(*r, r->recv(recv + (uint64_t)from * elems_per_rank, elems_per_rank, ncclFloat, from, c->comm, S(stream)));
+        note(r->send(send + (uint64_t)to * elems_per_rank, elems_per_rank, ncclFloat, to, c->comm, S(stream)));
+        note(r->recv(recv + (uint64_t)from * elems_per_rank, elems_per_rank, ncclFloat, from, c->comm, S(stream)));
     }
-    CL_RCCL(*r, r->group_end());
+    note(r->group_end());
+    if (first != ncclSuccess) return rccl_fail(*r, first, "all-to-all");
     return CLEORA_OK;
 }
 

@@ -429,7 +429,9 @@ int cleora_cosine_scores_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t 
     return launch_cosine(x, ldx, n, d, query_dev, scores_dev, S(stream));
 }
 
-uint64_t cleora_topk_workspace(uint64_t n, uint32_t k) { return topk_workspace_bytes(n, k); }
+uint64_t cleora_topk_workspace(uint64_t n, uint32_t k) { return topk_workspace_bytes(n, k, ~0u); }   // any batch size
+
+uint64_t cleora_topk_workspace_for(uint64_t n, uint32_t k, uint32_t n_queries) { return topk_workspace_bytes(n, k, n_queries); }
 
 int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                            const uint32_t *query_rows_dev, uint32_t n_queries, uint32_t k, int exclude_self,

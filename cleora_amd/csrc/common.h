@@ -128,7 +128,7 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
                    bool *norm_done = nullptr);                // ... if the shape allows (reported here); else the caller runs rowops
 
 // similarity.hip
-uint64_t topk_workspace_bytes(uint64_t n, uint32_t k);
+uint64_t topk_workspace_bytes(uint64_t n, uint32_t k, uint32_t n_queries);
 int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                        const uint32_t *queries_dev, uint32_t n_queries, uint32_t k, int exclude_self, int exclude_edges,
                        uint32_t *out_index, float *out_score, void *workspace, hipStream_t stream);

@@ -2,8 +2,10 @@
 // `argsort()[::-1][:top_k]` of predict_links / find_most_similar (pycleora/__init__.py:636-681, 753-781) for a BATCH of
 // query rows per pass over X, with the selection on the device: no per-query launch + sync + n-float download.
 //
-//   scores   one wavefront per row of X, up to 8 queries at once (query rows normalised into LDS): X is read once
-//            per batch — HBM-bound;
+//   scores   up to 8 queries: one wavefront per row of X, the query rows normalised into LDS, X read once per batch
+//            (HBM-bound for one query, VALU-bound at 8);  more than 8 queries: the batch IS a GEMM — the normalised
+//            query rows packed as a d x q matrix and X . Q on the f32 matrix cores through the projection kernel of
+//            whiten.hip (up to 64 queries per pass over X), then one row-scale pass by 1 / ||x_r||;
 //   mask     the query itself and, optionally, every r with a stored edge (q, r) or (r, q) get -2 like the reference
 //            (one pass over the CSR per batch);
 //   top-k    per 2048-element chunk k rounds of a block-wide arg-max in LDS (ties: the LARGER row index first, which
@@ -15,7 +17,9 @@
 namespace cleora {
 namespace {
 
-constexpr int QB = 8;           // queries per pass
+constexpr int QB = 8;           // queries per pass, VALU form (scores laid out [query][row])
+constexpr int QM = 256;         // queries per pass at most, MFMA form (scores laid out [row][query]); 64 for batches <= 64
+constexpr float kMasked = -3.0e38f;   // what mask_kernel writes; the selection turns it into the reference's -2
 constexpr int CHUNK = 2048;     // elements per selection block
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -77,51 +81,101 @@ __global__ __launch_bounds__(256) void cosine_batch_kernel(const float *__restri
     }
 }
 
-// -2 for the query itself and for both directions of every stored edge that touches it (:650-660)
+// One bit per row of X: is it a query of this pass?  (Lets mask_kernel test an edge with one load instead of nq compares.)
+__global__ void mark_queries_kernel(const uint32_t *__restrict__ queries, uint32_t nq, uint32_t *__restrict__ bits) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nq) atomicOr(&bits[queries[j] >> 5], 1u << (queries[j] & 31));
+}
+
+// Masked (the reference's -2, written as kMasked and turned into -2 by the selection): the query itself and both directions
+// of every stored edge that touches it (:650-660).  Element (query q, row r) lives at scores[q * qs + r * rs].
 __global__ __launch_bounds__(256) void mask_kernel(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
-                                                   uint64_t n_rows, uint64_t n, const uint32_t *__restrict__ queries, uint32_t nq,
-                                                   int exclude_self, int exclude_edges, float *__restrict__ scores) {
-    __shared__ uint32_t qv[QB];
-    if (threadIdx.x < nq) qv[threadIdx.x] = queries[threadIdx.x];
+                                                   uint64_t n_rows, uint64_t qs, uint64_t rs, const uint32_t *__restrict__ queries,
+                                                   uint32_t nq, const uint32_t *__restrict__ bits, int exclude_self,
+                                                   int exclude_edges, float *__restrict__ scores) {
+    __shared__ uint32_t qv[QM];
+    for (uint32_t j = threadIdx.x; j < nq; j += 256) qv[j] = queries[j];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint64_t waves = (uint64_t)gridDim.x * 4;
-    if (exclude_self && blockIdx.x == 0 && threadIdx.x < nq) scores[(uint64_t)threadIdx.x * n + qv[threadIdx.x]] = -2.0f;
+    if (exclude_self && blockIdx.x == 0)
+        for (uint32_t j = threadIdx.x; j < nq; j += 256) scores[(uint64_t)j * qs + (uint64_t)qv[j] * rs] = kMasked;
     if (!exclude_edges) return;
     for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += waves) {
         const uint64_t b = rowptr[row], e = rowptr[row + 1];
+        if ((bits[row >> 5] >> (row & 31)) & 1u) {            // (src, other): the row is a query — its whole edge list
+            for (uint32_t q = 0; q < nq; ++q)
+                if (qv[q] == (uint32_t)row)
+                    for (uint64_t k = b + lane; k < e; k += 64) scores[(uint64_t)q * qs + (uint64_t)col[k] * rs] = kMasked;
+        }
         for (uint64_t k = b + lane; k < e; k += 64) {
             const uint32_t c = col[k];
-            for (uint32_t q = 0; q < nq; ++q) {
-                if (qv[q] == (uint32_t)row) scores[(uint64_t)q * n + c] = -2.0f;      // (src, other)
-                if (qv[q] == c) scores[(uint64_t)q * n + row] = -2.0f;                // (other, src)
-            }
+            if ((bits[c >> 5] >> (c & 31)) & 1u)              // (other, src)
+                for (uint32_t q = 0; q < nq; ++q)
+                    if (qv[q] == c) scores[(uint64_t)q * qs + row * rs] = kMasked;
         }
     }
 }
 
-// One block: the k best of its CHUNK elements of row q, descending, ties -> larger index.  idx_in == nullptr: the
-// element's position is its index (first level).  Output: out_score / out_index [q][block][k].
+// MFMA form, step 1: column j of the d x nq matrix = x[query_j] / max(||x[query_j]||, 1e-10)   (one wave per query)
+__global__ __launch_bounds__(64) void pack_queries_kernel(const float *__restrict__ x, uint64_t ldx, uint32_t d,
+                                                          const uint32_t *__restrict__ queries, uint32_t nq,
+                                                          float *__restrict__ qmat) {
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    const float *xq = x + (uint64_t)queries[j] * ldx;
+    float sq = 0.f;
+    for (uint32_t c = lane; c < d; c += 64) sq += xq[c] * xq[c];
+    const float inv = 1.0f / fmaxf(sqrtf(wsum(sq)), 1e-10f);
+    for (uint32_t c = lane; c < d; c += 64) qmat[(uint64_t)c * nq + j] = xq[c] * inv;
+}
+
+// MFMA form: inv[r] = 1 / max(||x_r||, 1e-10), once per call; the selection applies it when it loads a raw score
+__global__ __launch_bounds__(256) void inv_row_norm_kernel(const float *__restrict__ x, uint64_t ldx, uint64_t n, uint32_t d,
+                                                           float *__restrict__ inv) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t row = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += waves) {
+        const float *xr = x + row * ldx;
+        float sq = 0.f;
+        for (uint32_t c = lane; c < d; c += 64) sq += xr[c] * xr[c];
+        sq = wsum(sq);
+        if (lane == 0) inv[row] = 1.0f / fmaxf(sqrtf(sq), 1e-10f);
+    }
+}
+
+// One block: the k best of its CHUNK elements of query q, descending, ties -> larger index.  Element p of query q is
+// score_in[q * stride_in + p * elem_stride], times scale[p] if given (the MFMA form's raw dot products); kMasked
+// becomes -2.  idx_in == nullptr: the element's position is its index (first level).  Q_FAST: the query is the fast
+// grid dimension — for the [row][query] layout, where the blocks of one chunk share their cache lines.
+// Output: out_score / out_index [q][block][k].
+template <bool Q_FAST>
 __global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict__ score_in, const uint32_t *__restrict__ idx_in,
-                                                         uint64_t len, uint64_t stride_in, uint32_t k,
+                                                         const float *__restrict__ scale, uint64_t len, uint64_t stride_in,
+                                                         uint64_t elem_stride, uint32_t k,
                                                          float *__restrict__ out_score, uint32_t *__restrict__ out_index,
                                                          uint64_t stride_out) {
     __shared__ float sv[CHUNK];
     __shared__ uint32_t si[CHUNK];
     __shared__ float rv[4];
     __shared__ uint32_t ri[4], rp[4];
-    const uint32_t q = blockIdx.y;
-    const uint64_t base = (uint64_t)blockIdx.x * CHUNK;
+    const uint32_t q = Q_FAST ? blockIdx.x : blockIdx.y, chunk = Q_FAST ? blockIdx.y : blockIdx.x;
+    const uint64_t base = (uint64_t)chunk * CHUNK;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     for (int i = t; i < CHUNK; i += 256) {
         const uint64_t p = base + i;
         const bool ok = p < len;
-        sv[i] = ok ? score_in[q * stride_in + p] : -INFINITY;
+        float v = -INFINITY;
+        if (ok) {
+            v = score_in[q * stride_in + p * elem_stride];
+            if (v == kMasked) v = -2.0f;                 // (-inf stays -inf: the padding of a short candidate list)
+            else if (scale) v *= scale[p];
+        }
+        sv[i] = v;
         si[i] = ok ? (idx_in ? idx_in[q * stride_in + p] : (uint32_t)p) : 0u;
     }
     __syncthreads();
-    float *os = out_score + q * stride_out + (uint64_t)blockIdx.x * k;
-    uint32_t *oi = out_index + q * stride_out + (uint64_t)blockIdx.x * k;
+    float *os = out_score + q * stride_out + (uint64_t)chunk * k;
+    uint32_t *oi = out_index + q * stride_out + (uint64_t)chunk * k;
     for (uint32_t round = 0; round < k; ++round) {
         float bv = -INFINITY;
         uint32_t bi = 0, bp = 0xffffffffu;
@@ -159,11 +213,21 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict
 
 static inline uint64_t chunks_of(uint64_t len) { return (len + CHUNK - 1) / CHUNK; }
 
-// floats: scores [QB][n] + two candidate levels (score + index each)
-uint64_t topk_workspace_bytes(uint64_t n, uint32_t k) {
+constexpr uint32_t kMaxD = 16384;       // widest row the query staging takes
+
+static inline uint32_t per_pass(uint32_t n_queries) {
+    return n_queries <= (uint32_t)QB ? (uint32_t)QB : n_queries <= 64u ? 64u : (uint32_t)QM;
+}
+
+// bytes: scores [per][n] + two candidate levels (score + index each) + the query bitmap + (MFMA form) 1/||x_r||, the
+// d x per query matrix and a zero "mean" of d floats for the projection kernel
+uint64_t topk_workspace_bytes(uint64_t n, uint32_t k, uint32_t n_queries) {
+    const uint64_t per = per_pass(n_queries);
     const uint64_t l1 = chunks_of(n) * k;
     const uint64_t l2 = chunks_of(l1) * k;
-    return ((uint64_t)QB * n + 2 * (uint64_t)QB * l1 + 2 * (uint64_t)QB * l2) * 4 + 1024;
+    uint64_t floats = per * n + 2 * per * l1 + 2 * per * l2 + (n + 31) / 32;
+    if (per > (uint64_t)QB) floats += n + (uint64_t)kMaxD * per + kMaxD;
+    return floats * 4 + 1024;
 }
 
 int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
@@ -175,49 +239,84 @@ int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint
     CL_REQUIRE(k >= 1 && k <= 1024 && (uint64_t)k <= n, "need 1 <= k <= min(n, 1024)");
     CL_REQUIRE(n < (1ull << 32), "more than 2^32 rows");
     CL_REQUIRE(!exclude_edges || (g != nullptr && g->n_rows == n && g->n_cols == n), "exclude_existing needs the square graph of X");
-    CL_REQUIRE((uint64_t)d * sizeof(float) * 1 <= 64 * 1024, "row too wide for the query staging (d <= 16384)");
+    CL_REQUIRE(d <= kMaxD, "row too wide for the query staging (d <= 16384)");
     if (n_queries == 0) return CLEORA_OK;
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x);
-    // queries per pass: as many as fit 64 KiB of LDS, at most QB
-    uint32_t per = (uint32_t)((64 * 1024) / ((uint64_t)d * sizeof(float)));
-    if (per > QB) per = QB;
+    const uint64_t slots = per_pass(n_queries);                       // what the workspace was sized for
+    const bool mfma = slots > (uint64_t)QB;
+    // queries per pass: VALU form — as many as fit 64 KiB of LDS, at most QB; MFMA form — 64 or 256
+    uint32_t per = mfma ? (uint32_t)slots : (uint32_t)((64 * 1024) / ((uint64_t)d * sizeof(float)));
+    if (!mfma && per > (uint32_t)QB) per = QB;
     float *scores = static_cast<float *>(workspace);
     const uint64_t l1 = chunks_of(n) * k, l2 = chunks_of(l1) * k;
-    float *s1 = scores + (uint64_t)QB * n;
-    uint32_t *i1 = reinterpret_cast<uint32_t *>(s1 + (uint64_t)QB * l1);
-    float *s2 = reinterpret_cast<float *>(i1 + (uint64_t)QB * l1);
-    uint32_t *i2 = reinterpret_cast<uint32_t *>(s2 + (uint64_t)QB * l2);
+    float *s1 = scores + slots * n;
+    uint32_t *i1 = reinterpret_cast<uint32_t *>(s1 + slots * l1);
+    float *s2 = reinterpret_cast<float *>(i1 + slots * l1);
+    uint32_t *i2 = reinterpret_cast<uint32_t *>(s2 + slots * l2);
+    uint32_t *bits = i2 + slots * l2;
+    const uint64_t bit_words = (n + 31) / 32;
+    float *inv = reinterpret_cast<float *>(bits + bit_words);         // MFMA form only from here on: [n]
+    // ... then [d][nq] and d zeros, on a 256-byte boundary (the projection's fast form wants an aligned mean)
+    float *qmat = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(inv + n) + 255) & ~(uintptr_t)255);
+    float *zeros = qmat + (uint64_t)kMaxD * slots;
     const unsigned grid = (unsigned)((n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096);
+    if (mfma) {
+        CL_HIP(hipMemsetAsync(zeros, 0, (size_t)d * sizeof(float), stream));
+        hipLaunchKernelGGL(inv_row_norm_kernel, dim3(grid), dim3(256), 0, stream, x, ldx, n, d, inv);
+    }
     for (uint32_t q0 = 0; q0 < n_queries; q0 += per) {
         const uint32_t nq = n_queries - q0 < per ? n_queries - q0 : per;
-        const size_t lds = (size_t)nq * d * sizeof(float);
-        if (w4)
-            hipLaunchKernelGGL(cosine_batch_kernel<true>, dim3(grid), dim3(256), lds, stream, x, ldx, n, d, queries_dev + q0, nq, scores);
-        else
-            hipLaunchKernelGGL(cosine_batch_kernel<false>, dim3(grid), dim3(256), lds, stream, x, ldx, n, d, queries_dev + q0, nq, scores);
-        if (exclude_self || exclude_edges)
+        uint64_t qs, rs;                                              // element (query q, row r) at scores[q * qs + r * rs]
+        if (mfma) {
+            hipLaunchKernelGGL(pack_queries_kernel, dim3(nq), dim3(64), 0, stream, x, ldx, d, queries_dev + q0, nq, qmat);
+            CL_HIP(hipGetLastError());
+            const int rc = launch_project(x, ldx, n, d, zeros, qmat, nq, scores, nq, stream);
+            if (rc != CLEORA_OK) return rc;
+            qs = 1;
+            rs = nq;
+        } else {
+            const size_t lds = (size_t)nq * d * sizeof(float);
+            if (w4)
+                hipLaunchKernelGGL(cosine_batch_kernel<true>, dim3(grid), dim3(256), lds, stream, x, ldx, n, d, queries_dev + q0, nq, scores);
+            else
+                hipLaunchKernelGGL(cosine_batch_kernel<false>, dim3(grid), dim3(256), lds, stream, x, ldx, n, d, queries_dev + q0, nq, scores);
+            qs = n;
+            rs = 1;
+        }
+        if (exclude_self || exclude_edges) {
+            if (exclude_edges) {
+                CL_HIP(hipMemsetAsync(bits, 0, (size_t)bit_words * 4, stream));
+                hipLaunchKernelGGL(mark_queries_kernel, dim3((nq + 255) / 256), dim3(256), 0, stream, queries_dev + q0, nq, bits);
+            }
             hipLaunchKernelGGL(mask_kernel, dim3(grid), dim3(256), 0, stream, exclude_edges ? g->rowptr : nullptr,
-                               exclude_edges ? g->col : nullptr, exclude_edges ? g->n_rows : 0, n, queries_dev + q0, nq,
-                               exclude_self, exclude_edges, scores);
+                               exclude_edges ? g->col : nullptr, exclude_edges ? g->n_rows : 0, qs, rs, queries_dev + q0, nq,
+                               bits, exclude_self, exclude_edges, scores);
+        }
         // selection: chunks of X rows -> chunk winners -> ... -> one block per query
         const float *sin = scores;
         const uint32_t *iin = nullptr;
-        uint64_t len = n, stride = n;
+        const float *scale = mfma ? inv : nullptr;
+        uint64_t len = n, stride = qs, estride = rs;
         float *so = s1;
         uint32_t *io = i1;
         uint64_t ostride = l1;
         for (;;) {
             const uint64_t nb = chunks_of(len);
             if (nb == 1) {   // final: straight into the caller's arrays
-                hipLaunchKernelGGL(topk_chunk_kernel, dim3(1, nq), dim3(256), 0, stream, sin, iin, len, stride, k,
+                hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3(1, nq), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, k,
                                    out_score + (uint64_t)q0 * k, out_index + (uint64_t)q0 * k, (uint64_t)k);
                 break;
             }
-            hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)nb, nq), dim3(256), 0, stream, sin, iin, len, stride, k, so, io, ostride);
+            if (estride != 1 && nb <= 65535)     // [row][query] layout: the blocks of one chunk next to each other
+                hipLaunchKernelGGL(topk_chunk_kernel<true>, dim3(nq, (unsigned)nb), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, k, so, io, ostride);
+            else
+                hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3((unsigned)nb, nq), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, k, so, io, ostride);
             sin = so;
             iin = io;
+            scale = nullptr;
             len = nb * k;
             stride = ostride;
+            estride = 1;
             // the two candidate buffers alternate (level 1 fits l2 again: it is smaller than level 0's output)
             if (so == s1) { so = s2; io = i2; ostride = l2; } else { so = s1; io = i1; ostride = l1; }
         }

@@ -258,7 +258,7 @@ def find_most_similar(graph, embeddings, query_entity, top_k=10, exclude_self=Tr
     dq = _hip.DevArray.from_host(np.asarray([query_idx], dtype=np.uint32))
     kk = k
     oi, os_ = _hip.DevArray((1, kk), np.uint32), _hip.DevArray((1, kk), np.float32)
-    ws = _hip.DevArray((L.cleora_topk_workspace(n, kk),), np.uint8)
+    ws = _hip.DevArray((L.cleora_topk_workspace_for(n, kk, 1),), np.uint8)
     _hip.check(L.cleora_topk_cosine_dev(None, dx.ptr, d, n, d, dq.ptr, 1, kk, 1 if exclude_self else 0, 0, oi.ptr, os_.ptr,
                                         ws.ptr, None))
     _hip.check(L.cleora_stream_sync(None))

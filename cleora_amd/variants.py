@@ -216,7 +216,7 @@ def _topk_neighbours(graph, x, query_rows, k, exclude_self, exclude_existing):
     dx = _hip.DevArray.from_host(x)
     dq = _hip.DevArray.from_host(np.asarray(query_rows, dtype=np.uint32))
     oi, os_ = _hip.DevArray((nq, k), np.uint32), _hip.DevArray((nq, k), np.float32)
-    ws = _hip.DevArray((L.cleora_topk_workspace(n, k),), np.uint8)
+    ws = _hip.DevArray((L.cleora_topk_workspace_for(n, k, nq),), np.uint8)
     with graph._lock:
         g = graph._graph().handle if exclude_existing else None
         _hip.check(L.cleora_topk_cosine_dev(g, dx.ptr, d, n, d, dq.ptr, nq, k, 1 if exclude_self else 0,

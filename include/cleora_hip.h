@@ -297,8 +297,12 @@ int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint
  *   exclude_self: score(q, q) = -2;  exclude_existing (needs the square graph of X): -2 for every r with a stored edge
  *   (q, r) or (r, q) (:650-660).  out_index / out_score: [n_queries][k], descending score; ties: the larger row index
  *   first (numpy's argsort()[::-1]); entries with score <= -2 are masked candidates the caller drops (:663-664).
- * X is read once per 8 queries.  workspace: cleora_topk_workspace(n, k) BYTES.  1 <= k <= min(n, 1024). */
+ * Up to 8 queries: one pass over X on the vector units.  More: the batch is a GEMM — X . Q (Q = the normalised query
+ * rows, d x q) on the f32 matrix cores, 64 queries per pass over X, then a row scale by 1 / ||x_r||.
+ * workspace: cleora_topk_workspace_for(n, k, n_queries) BYTES (8 n floats + candidates up to 8 queries, 64 n floats
+ * beyond); cleora_topk_workspace(n, k) is the size that serves any batch.  1 <= k <= min(n, 1024). */
 uint64_t cleora_topk_workspace(uint64_t n, uint32_t k);
+uint64_t cleora_topk_workspace_for(uint64_t n, uint32_t k, uint32_t n_queries);
 int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                            const uint32_t *query_rows_dev, uint32_t n_queries, uint32_t k, int exclude_self,
                            int exclude_existing, uint32_t *out_index_dev, float *out_score_dev, void *workspace, void *stream);

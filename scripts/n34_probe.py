@@ -25,11 +25,11 @@ t = timed(lambda: _hip.check(L.cleora_edge_attention_dev(gr.handle, 0, x.data_pt
 print(f"edge attention, n={n} nnz={nnz} d={d}: {t:.3f} ms  ({(nnz * d * 4 + n * d * 8) / t / 1e6:.0f} GB/s of gathered rows + norm pass)", flush=True)
 t2 = timed(lambda: _hip.check(L.cleora_propagate_dev(gr.handle, 0, x.data_ptr(), d, d, torch.empty_like(x).data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, None, s)))
 print(f"   (the SpMM over the same edges: {t2:.3f} ms)", flush=True)
-for nq, k in ((1, 10), (8, 10), (64, 10), (64, 100)):
+for nq, k in ((1, 10), (8, 10), (9, 10), (64, 10), (256, 10), (64, 100)):
     q = torch.randint(0, n, (nq,), device=dev, dtype=torch.int32)
     oi = torch.empty((nq, k), dtype=torch.int32, device=dev); os_ = torch.empty((nq, k), device=dev)
     ws = torch.empty(L.cleora_topk_workspace(n, k), dtype=torch.uint8, device=dev)
     for excl in (0, 1):
         t = timed(lambda: _hip.check(L.cleora_topk_cosine_dev(gr.handle if excl else None, x.data_ptr(), d, n, d, q.data_ptr(), nq, k, 1, excl,
                                                               oi.data_ptr(), os_.data_ptr(), ws.data_ptr(), s)))
-        print(f"top-{k} cosine for {nq} queries, exclude_existing={excl}: {t:.3f} ms  ({t / nq:.3f} ms per query; one pass over X = {n * d * 4 / 1e9:.2f} GB per 8 queries)", flush=True)
+        print(f"top-{k} cosine for {nq} queries, exclude_existing={excl}: {t:.3f} ms  ({t / nq:.3f} ms per query; X = {n * d * 4 / 1e9:.2f} GB, read once per 8 queries on the vector units, per 64 on the matrix cores)", flush=True)

@@ -159,10 +159,13 @@ def test_predict_links(ref, tag, kw):
         variants.predict_links(g, k["embed_whiten_d16"], source_entities=["no-such-entity"])
 
 
-@pytest.mark.parametrize("n,d,k,nq", [(50_000, 64, 17, 11), (5000, 256, 5, 3), (3000, 20, 40, 9), (100, 8, 100, 2)])
+@pytest.mark.parametrize("n,d,k,nq", [(50_000, 64, 17, 11), (5000, 256, 5, 3), (3000, 20, 40, 9), (100, 8, 100, 2),
+                                      (4000, 256, 10, 70), (2000, 96, 5, 64), (700, 33, 3, 12)])
 def test_topk_cosine_on_device_against_numpy(n, d, k, nq):
     """cleora_topk_cosine_dev: scores, the -2 masks (self, both directions of stored edges) and the selection order of
-    numpy's `argsort()[::-1][:k]` (ties: larger index first), for a batch of query rows, several selection levels."""
+    numpy's `argsort()[::-1][:k]` (ties: larger index first), for a batch of query rows, several selection levels.
+    Up to 8 queries take the vector-unit form, more the matrix-core form (X . Q through the projection kernel: its
+    rows-in-LDS form at d = 64 / 256 / 96, the generic one at d = 20 / 33; 70 queries = two passes)."""
     import ctypes
     from tests.graphs import random_csr
     rng = np.random.default_rng(n + d)

@@ -77,3 +77,15 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "libcleora_oracle" not in text, f
+
+
+def test_workspace_queries_are_plain_arithmetic():
+    """Workspace sizes are computed on the host (no device needed): the top-k workspace grows with the batch class
+    (<= 8 queries: vector-unit form, <= 64 and beyond: matrix-core form with 64 / 256 queries per pass) and the generic
+    query serves any batch."""
+    L = _hip.lib()
+    n, k = 1_000_000, 10
+    w1, w8, w9, w64, w65, wany = (L.cleora_topk_workspace_for(n, k, q) for q in (1, 8, 9, 64, 65, 100_000))
+    assert w1 == w8 < w9 == w64 < w65 == wany == L.cleora_topk_workspace(n, k)
+    assert w8 >= 8 * n * 4 and w64 >= 64 * n * 4 and w65 >= 256 * n * 4
+    assert L.cleora_whiten_workspace(n, 256) > 0 and L.cleora_gram_workspace(n, 256) > 0

@@ -68,18 +68,20 @@ __device__ __forceinline__ float4 load4(const float *rp, uint32_t c, uint32_t d,
     return v;
 }
 
-// Tiles of a DIAGONAL block tile: only the 36 MFMA tiles (ti <= tj) of its 8 x 8 grid are needed
-// (the rest is the mirror image).  They are dealt 9 per wave; (ti, tj) = kDiagTiles[wave][t].
-__constant__ unsigned char kDiagTiles[4][9][2] = {
-    {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {0, 7}, {1, 1}},
-    {{1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {1, 7}, {2, 2}, {2, 3}, {2, 4}},
-    {{2, 5}, {2, 6}, {2, 7}, {3, 3}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {4, 4}},
-    {{4, 5}, {4, 6}, {4, 7}, {5, 5}, {5, 6}, {5, 7}, {6, 6}, {6, 7}, {7, 7}}};
+// Tiles of a DIAGONAL block tile: only the 36 MFMA tiles (ti <= tj) of its 8 x 8 grid are needed (the rest is the
+// mirror image).  Wave WV takes tile rows WV (columns WV..7) and 7-WV (columns 7-WV..7): 9 tiles each, and — the A
+// fragment of tile row r being the same LDS column block as the B fragment of tile column r — only the 8-WV column
+// fragments WV..7 are read per k-step.  (Round 1 dealt the tiles out in sequence and read two fragments per MFMA: 18
+// reads x 8 resident waves kept the CU's LDS port busy for as long as the 9 MFMAs take; r02_whiten_pmc.json, 70 % MFMA
+// busy against 81 % for the off-diagonal blocks.)  The wave index is a template parameter so that accumulators and
+// fragments are fixed registers; the kernel branches on it once.
+__host__ __device__ constexpr int diag_tile_row(int wv, int i) { return i < 8 - wv ? wv : 7 - wv; }
+__host__ __device__ constexpr int diag_tile_col(int wv, int i) { return i < 8 - wv ? wv + i : (7 - wv) + (i - (8 - wv)); }
 
 // FAST: d is a multiple of the 128-column tile and rows are float4-aligned — the loads carry no column checks and no
 // branches (rows past the slice are read from a clamped address and zeroed when staged), so the compiler keeps the
 // prefetch in flight behind counted waits instead of `s_waitcnt vmcnt(0)` after every guarded load.
-template <bool DIAG, bool FAST>
+template <bool DIAG, bool FAST, int WV>
 __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DIAG ? 1 : 2][GKC][GLD],
                                           uint32_t bi, uint32_t bj, uint32_t pair) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -106,8 +108,8 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
     if constexpr (DIAG) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            fa_col[i] = kDiagTiles[w][i][0] * 16;
-            fb_col[i] = kDiagTiles[w][i][1] * 16;
+            fa_col[i] = diag_tile_row(WV, i) * 16;
+            fb_col[i] = diag_tile_col(WV, i) * 16;
         }
     } else {
 #pragma unroll
@@ -173,12 +175,12 @@ __device__ __forceinline__ void gram_body(const GramArgs &a, double (&lds)[2][DI
         for (int kk = 0; kk < GKC / 4; ++kk) {
             const int krow = kk * 4 + (lane >> 4);
             if constexpr (DIAG) {
+                double f[8];                                   // column fragments WV..7; f[r] is also the A fragment of tile row r
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const double fa = lds[buf][0][krow][fa_col[i] + (lane & 15)];
-                    const double fb = lds[buf][0][krow][fb_col[i] + (lane & 15)];
-                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, acc[i], 0, 0, 0);
-                }
+                for (int c = WV; c < 8; ++c) f[c] = lds[buf][0][krow][c * 16 + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < 9; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[diag_tile_row(WV, i)], f[diag_tile_col(WV, i)], acc[i], 0, 0, 0);
             } else {
                 double fa[4], fb[4];
 #pragma unroll
@@ -241,7 +243,16 @@ __global__ __launch_bounds__(256) void gram_kernel(const GramArgs a) {
         while (q >= rowlen) { q -= rowlen; ++bi; --rowlen; }
         bj = bi + 1 + q;
     }
-    gram_body<DIAG, FAST>(a, lds, bi, bj, pair_index(bi, bj, a.tiles));
+    if constexpr (DIAG) {
+        switch (threadIdx.x >> 6) {                            // whole waves take each arm; every arm meets the same barriers
+            case 0: gram_body<true, FAST, 0>(a, lds, bi, bj, pair_index(bi, bj, a.tiles)); break;
+            case 1: gram_body<true, FAST, 1>(a, lds, bi, bj, pair_index(bi, bj, a.tiles)); break;
+            case 2: gram_body<true, FAST, 2>(a, lds, bi, bj, pair_index(bi, bj, a.tiles)); break;
+            default: gram_body<true, FAST, 3>(a, lds, bi, bj, pair_index(bi, bj, a.tiles)); break;
+        }
+    } else {
+        gram_body<false, FAST, 0>(a, lds, bi, bj, pair_index(bi, bj, a.tiles));
+    }
 }
 
 // One-pass form: the Gram was centred with a shift c near the mean.  delta = sum_r (x_r - c) / n (slices added in

@@ -22,3 +22,28 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def _warm_page_cache(paths):
+    """Read files once, sequentially, in the background: a freshly provisioned GPU box pages the 931 MB system
+    librocsolver.so in through random faults when the torch-free C host first calls dsyevd (100-200 s measured for
+    tests/test_zz_c_host.py::test_c_host_whitened_loop); a sequential read ahead of time is an order of magnitude faster.
+    Test infrastructure only: nothing in the product depends on it."""
+    for path in paths:
+        try:
+            with open(path, "rb", buffering=0) as f:
+                while f.read(8 << 20):
+                    pass
+        except OSError:
+            pass
+
+
+def pytest_sessionstart(session):
+    if "gpu" not in (session.config.getoption("-m") or "") or "not gpu" in (session.config.getoption("-m") or ""):
+        return
+    import glob
+    import threading
+    paths = [p for p in ("/opt/rocm/lib/librocsolver.so.0", "/opt/rocm/lib/librocblas.so.5") if os.path.exists(p)]
+    paths += sorted(glob.glob("/opt/rocm/lib/rocblas/library/*gfx950*"))
+    if paths:
+        threading.Thread(target=_warm_page_cache, args=(paths,), daemon=True).start()

@@ -142,7 +142,8 @@ int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
  * buffer it gathers from and the buffer it writes fall into the same physical placement class of the HBM (DESIGN.md
  * §3.1; not visible in virtual addresses).  Allocates `count` buffers of max(n_rows, n_cols) x d floats: bufs[0] first,
  * then each partner by TIMING the real kernel (one launch per candidate, gathers from bufs[0], writes the candidate)
- * until a candidate is >= 5 % faster than the slowest seen (at most 8).  Use bufs[0] as the buffer EVERY SpMM of the
+ * until a candidate is >= 5 % faster than the slowest seen (at most 6, and none once CLEORA_PLACEMENT_BUDGET_MS = 1500 ms
+ * of wall clock are spent; rejected candidates are held until the slot is settled, then freed).  Use bufs[0] as the buffer EVERY SpMM of the
  * loop touches: ping-pong = the pair (bufs[0], bufs[1]); the whitened loop = SpMM output in bufs[0], the two whitened
  * iterates in bufs[1] and bufs[2].  Iterates below 256 MiB are allocated without the search.  Contents are
  * unspecified.  ms (optional, double[2]): the first candidate's launch time — what a plain allocation pair would have

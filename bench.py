@@ -140,39 +140,51 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
     return out, checks
 
 
-def rccl_comm_or_fallback(local_rank, dev, rank, world):
-    """The C-ABI communicator, checked with one small all-reduce before anything depends on it.  If it cannot be created
-    or gives a wrong sum on ANY rank (every rank learns so over the gloo launcher group), all ranks fall back to RCCL through
-    torch.distributed's nccl backend and the bench line says so in config.collectives — a scaling run should not be
-    lost to a communicator bootstrap problem on a node this code has never seen."""
-    err = ""
-    comm = None
+def rccl_comm_or_fallback(local_rank, dev, rank, world, fallback_backend="nccl"):
+    """The C-ABI communicator, checked with one small all-reduce before anything depends on it.  Two agreement points over
+    the gloo launcher group — after the creation and after the probe — so that the ranks always take the same branch: if
+    the communicator cannot be created or gives a wrong sum on ANY rank, all ranks fall back to RCCL through
+    torch.distributed's nccl backend and the bench line says so in config.collectives.  A scaling run should not be lost
+    to a communicator bootstrap problem on a node this code has never seen.  (What this cannot catch: a rank that dies
+    before ncclCommInitRank leaves the others waiting inside it; the watchdog ends that run.)"""
+    def agree(err):
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) == 1:
+            return None
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        return next(e for e in errs if e)
+
+    err, comm = "", None
     try:
         comm = comm_mod.RcclComm.from_torch_distributed(local_rank)
-        probe = torch.full((1024,), float(rank + 1), device=dev)
-        comm.allreduce(probe)
-        torch.cuda.synchronize()
-        if not bool((probe == world * (world + 1) / 2).all()):
-            err = f"all-reduce probe gave {float(probe[0])}, expected {world * (world + 1) / 2}"
     except Exception as e:                    # noqa: BLE001 - reported below, on every rank
         err = f"{type(e).__name__}: {e}"
-    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok) == 1:
-        return comm, "RCCL via the C ABI (csrc/comm.hip)"
-    errs = [None] * world
-    dist.all_gather_object(errs, err)
+    first = agree(err)
+    if first is None:
+        try:
+            probe = torch.full((1024,), float(rank + 1), device=dev)
+            comm.allreduce(probe)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            if not bool((probe == world * (world + 1) / 2).all()):
+                err = f"all-reduce probe gave {float(probe[0])}, expected {world * (world + 1) / 2}"
+        except Exception as e:                # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        first = agree(err)
+        if first is None:
+            return comm, "RCCL via the C ABI (csrc/comm.hip)"
     if rank == 0:
-        print(f"bench.py: C-ABI communicator unusable ({[e for e in errs if e]}); falling back to torch.distributed nccl",
+        print(f"bench.py: C-ABI communicator unusable ({first}); falling back to torch.distributed {fallback_backend}",
               file=sys.stderr, flush=True)
     if comm is not None:
         try:
             comm.close()
         except Exception:                     # noqa: BLE001
             pass
-    group = dist.new_group(backend="nccl")
-    first = next(e for e in errs if e)
-    return comm_mod.TorchComm(group), f"RCCL via torch.distributed nccl (fallback; C-ABI communicator: {first[:200]})"
+    group = dist.new_group(backend=fallback_backend)
+    return comm_mod.TorchComm(group), f"RCCL via torch.distributed {fallback_backend} (fallback; C-ABI communicator: {first[:200]})"
 
 
 class Launcher:

@@ -203,3 +203,61 @@ def test_column_partition_world2(world, steps):
             np.testing.assert_allclose(x, want, rtol=0, atol=2e-6)
         for _, res in got[1:]:
             np.testing.assert_array_equal(got[0][1][key][0], res[key][0])       # replicas identical
+
+
+def _fallback_worker(rank, world, port, q, fail_on):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from cleora_amd import comm as comm_mod
+
+        class FakeRccl:                       # stands in for the C-ABI communicator: same interface, gloo underneath
+            def __init__(self, wrong=False):
+                self.wrong = wrong
+
+            def allreduce(self, t):
+                dist.all_reduce(t)
+                if self.wrong:
+                    t += 1.0
+
+            def close(self):
+                pass
+
+        def from_torch_distributed(local_rank, group=None):
+            if fail_on == "raise" and rank == 1:
+                raise RuntimeError("simulated bootstrap failure")
+            return FakeRccl(wrong=(fail_on == "wrong" and rank == 0))
+
+        comm_mod.RcclComm.from_torch_distributed = staticmethod(from_torch_distributed)
+        comm, label = bench.rccl_comm_or_fallback(0, torch.device("cpu"), rank, world, fallback_backend="gloo")
+        t = torch.full((4,), float(rank + 1))
+        comm.allreduce(t)                     # whatever came back must be a working communicator on every rank
+        q.put((rank, type(comm).__name__, label, float(t[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_on", [None, "raise", "wrong"])
+def test_bench_falls_back_as_one_when_the_c_abi_communicator_is_unusable(fail_on):
+    """bench.py's N > 1 start-up: if the C-ABI RCCL communicator cannot be created on ANY rank, or its probe all-reduce
+    gives a wrong sum on any rank, every rank falls back to the torch.distributed group (and says so in
+    config.collectives); if all is well, every rank keeps it.  Two gloo ranks, the communicator replaced by a stand-in."""
+    world, port = 2, 29500 + (os.getpid() + {None: 0, "raise": 1, "wrong": 2}[fail_on]) % 400 + 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q, fail_on)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    kinds = {g[1] for g in got}
+    assert len(kinds) == 1                                   # the ranks agree
+    assert all(g[3] == 3.0 for g in got) or fail_on == "wrong" and kinds == {"TorchComm"}
+    if fail_on is None:
+        assert kinds == {"FakeRccl"} and all("C ABI" in g[2] for g in got)
+    else:
+        assert kinds == {"TorchComm"} and all("fallback" in g[2] for g in got)
+        assert all(g[3] == 3.0 for g in got)

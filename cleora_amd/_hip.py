@@ -83,6 +83,8 @@ SIGNATURES = {
     "cleora_mean_dev": (c_int, [vp, c_u64, c_u32, vp, vp, vp]),
     "cleora_eigh_workspace": (c_u64, [c_u32]),
     "cleora_whiten_transform_dev": (c_int, [vp, c_u64, c_u32, c_u32, vp, vp, vp, vp]),
+    "cleora_whiten_stats_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_int, vp, vp, vp]),
+    "cleora_whiten_transform_any_dev": (c_int, [vp, c_u64, c_u32, vp, vp, vp, ctypes.POINTER(c_int)]),
     "cleora_whiten_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_whiten_dev": (c_int, [vp, c_u64, c_u64, c_u32, c_u32, vp, c_u64, vp, vp, vp]),
     "cleora_whiten": (c_int, [vp, c_u64, c_u32, c_u32, vp]),

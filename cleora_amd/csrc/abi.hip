@@ -467,6 +467,23 @@ int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, 
     return launch_whiten_transform(gram_dev, n, d, k, transform_dev, eigenvalues_dev, workspace, S(stream));
 }
 
+int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, int intermediate,
+                            double *mean64_dev, double *gram_dev, void *stream) {
+    CL_REQUIRE(mean64_dev != nullptr && gram_dev != nullptr, "mean / gram is NULL");
+    const int rc = launch_whiten_fit_stats(x, ldx, n, d, workspace, S(stream), 2, intermediate != 0);
+    if (rc != CLEORA_OK) return rc;
+    return whiten_fit_copy_stats(workspace, n, d, mean64_dev, gram_dev, S(stream));
+}
+
+int cleora_whiten_transform_any_dev(const double *gram_dev, uint64_t n, uint32_t d, float *transform_dev,
+                                    void *workspace, void *stream, int *form_out) {
+    int rc = launch_whiten_transform_cholesky(gram_dev, n, d, transform_dev, workspace, S(stream));
+    if (rc < 0) return rc;
+    if (form_out) *form_out = rc == CLEORA_OK ? 1 : 0;
+    if (rc == 1) rc = launch_whiten_transform(gram_dev, n, d, d, transform_dev, nullptr, workspace, S(stream));
+    return rc;
+}
+
 uint64_t cleora_whiten_workspace(uint64_t n, uint32_t d) { return whiten_workspace(n, d); }
 
 int cleora_whiten_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t n_components,
@@ -736,9 +753,9 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
         // (2) rocSOLVER synchronises with the host inside dsyevd: whatever is launched after it starts only then.
         // So: statistics (stream b) -> SpMM (stream a) -> eigensolver (stream b, the host blocks here while both run).
         static const int gram_first = std::getenv("CLEORA_GRAM_FIRST") ? std::atoi(std::getenv("CLEORA_GRAM_FIRST")) : 1;
-        if (gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks)) != CLEORA_OK) return rc;
+        if (gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
         if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
-        if (!gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks)) != CLEORA_OK) return rc;
+        if (!gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
         // intermediate iterations of the L2-normalised loop may take ANY whitening transform (eigh.hip): Cholesky
         if (n > 1 && (rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, any_whitening)) != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(st.fb, st.b));

@@ -126,6 +126,29 @@ __global__ __launch_bounds__(256) void tri_transform_kernel(const double *__rest
     t[idx] = j >= i ? (float)linv[idx] : 0.0f;
 }
 
+// ... and the guard that makes the Cholesky form safe to use in place of the reference's clamped PCA form: T = L^-T, so
+// ||T||_F^2 = trace(L^-T L^-1) = trace(cov^-1) = sum_i 1/lambda_i >= 1/lambda_min.  If that sum is <= 1e10 then EVERY
+// eigenvalue of the covariance is >= 1e-10, the reference's clamp max(lambda, 1e-10) (pycleora/__init__.py:155) is inactive
+// and its transform is a whitening like ours (equal up to a rotation); otherwise the caller takes the PCA form, which
+// reproduces the clamp.  (The smallest pivot alone only bounds lambda_min from ABOVE: ADVICE round 2.)  One block, fixed
+// order: deterministic.
+__global__ __launch_bounds__(256) void frob2_kernel(const float *__restrict__ t, uint64_t elems, double *__restrict__ out) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (uint64_t i = threadIdx.x; i < elems; i += 256) {
+        const double v = (double)t[i];
+        s += v * v;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sm[threadIdx.x] += sm[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+constexpr double kMaxTraceInverse = 0.999e10;   // sum 1/lambda_i <= this  =>  lambda_min >= 1e-10 (with a margin for the f32 T)
+
 // ---- Cholesky whitening transform for d <= 256 in ONE launch, no library, no host synchronisation inside -------------
 // cov = gram / (n-1) = L L^T ;  transform = L^-T as f32 (row-major d x d, upper triangular).
 // One workgroup of 512 threads keeps a triangle of the matrix in REGISTERS (d (d+1)/2 <= 32 896 values; 512 KiB of f64
@@ -354,7 +377,8 @@ int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, fl
 // iteration removes it.  The Cholesky form W = L^-T (cov = L L^T) costs potrf + trtri — a handful of launches — instead
 // of dsyevd's ~d dependent steps (6 ms at d = 256, two thirds of a whitening at |V| = 1M).  Returns 1 (not an error) when
 // the covariance is too close to singular for that (pivot^2 < 1e-8, near the reference's 1e-10 eigenvalue clamp, or potrf
-// reports a non-positive pivot): the caller then takes the eigenvector form, which reproduces the clamp.
+// reports a non-positive pivot) or when trace(cov^-1) = ||L^-T||_F^2 > 1e10, i.e. whenever lambda_min >= 1e-10 is not
+// PROVEN: the caller then takes the eigenvector form, which reproduces the clamp.
 int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d, float *transform, void *workspace,
                                      hipStream_t stream) {
     CL_REQUIRE(gram != nullptr && transform != nullptr && workspace != nullptr, "gram / transform / workspace is NULL");
@@ -376,12 +400,13 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
     if (d <= 256 && !library_route) {
         hipLaunchKernelGGL(cholesky_whiten_kernel, dim3(1), dim3(kCholThreads), 0, stream, gram, 1.0 / (double)(n - 1), d, w.cov,
                            transform, w.w);
+        hipLaunchKernelGGL(frob2_kernel, dim3(1), dim3(256), 0, stream, transform, elems, w.w + 2);
         CL_HIP(hipGetLastError());
-        double meta[2] = {1.0, 0.0};
+        double meta[3] = {1.0, 0.0, INFINITY};
         CL_HIP(hipMemcpyAsync(meta, w.w, sizeof(meta), hipMemcpyDeviceToHost, stream));
         CL_HIP(hipStreamSynchronize(stream));
         CL_HIP(hipMemsetAsync(w.info, 0, sizeof(int), stream));            // whiten_info(): nothing failed to converge
-        return (meta[0] != 0.0 || !(meta[1] >= 1e-8)) ? 1 : CLEORA_OK;
+        return (meta[0] != 0.0 || !(meta[1] >= 1e-8) || !(meta[2] <= kMaxTraceInverse)) ? 1 : CLEORA_OK;
     }
     Solver &s = solver();
     if (!s.lib) {
@@ -422,8 +447,13 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
     }
     hipLaunchKernelGGL(tri_transform_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, w.cov, d, transform);
     // (w.info was overwritten by trtri with 0: whiten_info() keeps reporting success for this workspace)
+    // the clamp guard: trace(cov^-1) = ||T||_F^2 <= 1e10 proves lambda_min >= 1e-10 (frob2_kernel)
+    hipLaunchKernelGGL(frob2_kernel, dim3(1), dim3(256), 0, stream, transform, elems, w.w + 1);
     CL_HIP(hipGetLastError());
-    return CLEORA_OK;
+    double trace_inv = INFINITY;
+    CL_HIP(hipMemcpyAsync(&trace_inv, w.w + 1, sizeof(double), hipMemcpyDeviceToHost, stream));
+    CL_HIP(hipStreamSynchronize(stream));
+    return trace_inv <= kMaxTraceInverse ? CLEORA_OK : 1;
 }
 
 int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t k, float *transform,
@@ -573,7 +603,7 @@ const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
 // The fit in two halves, so that a caller can slip other launches between the MFMA-bound statistics and the
 // eigensolver (whose library call synchronises with the host): launch_whiten_fit = stats + solve.
 int launch_whiten_fit_stats(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, hipStream_t stream,
-                            int gram_blocks_per_cu) {
+                            int gram_blocks_per_cu, bool intermediate) {
     CL_REQUIRE(d > 0 && ldx >= d && n >= 2, "bad shape");
     CL_REQUIRE(x != nullptr && workspace != nullptr, "x / workspace is NULL");
     WhitenWs w;
@@ -588,7 +618,13 @@ int launch_whiten_fit_stats(const float *x, uint64_t ldx, uint64_t n, uint32_t d
     if ((rc = launch_colsum(x, ldx * stride, m, d, w.colsum_ws, w.colsum, stream)) != CLEORA_OK) return rc;
     if ((rc = launch_mean(w.colsum, m, d, w.shift64, w.mean32, stream)) != CLEORA_OK) return rc;
     wt_mark(stream);
-    if ((rc = launch_gram(x, ldx, n, d, w.shift64, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu)) != CLEORA_OK) return rc;
+    // intermediate iterations of the whitened loop (the caller vouches that nobody looks at this whitening): the f32-matrix-core
+    // Gram where it applies (whiten.hip, d = 256); everything else — the last iteration, cleora_whiten_dev — is f64 end to end
+    if (intermediate && gram32_applies(x, ldx, n, d))
+        rc = launch_gram32(x, ldx, n, w.shift64, w.mean32, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu);
+    else
+        rc = launch_gram(x, ldx, n, d, w.shift64, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu);
+    if (rc != CLEORA_OK) return rc;
     wt_mark(stream);
     return CLEORA_OK;
 }
@@ -614,6 +650,14 @@ int launch_whiten_fit(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint
     const int rc = launch_whiten_fit_stats(x, ldx, n, d, workspace, stream, gram_blocks_per_cu);
     if (rc != CLEORA_OK) return rc;
     return launch_whiten_fit_solve(n, d, k, workspace, eigenvalues, stream);
+}
+
+int whiten_fit_copy_stats(void *workspace, uint64_t n, uint32_t d, double *mean64, double *gram, hipStream_t stream) {
+    WhitenWs w;
+    whiten_ws_layout(n, d, workspace, &w);
+    CL_HIP(hipMemcpyAsync(mean64, w.mean64, (size_t)d * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    CL_HIP(hipMemcpyAsync(gram, w.gram, (size_t)d * d * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return CLEORA_OK;
 }
 
 void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform) {

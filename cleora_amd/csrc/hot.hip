@@ -151,7 +151,9 @@ const uint32_t *build_hot_cols(const cleora_graph *g, uint64_t want, hipStream_t
 uint64_t hot_rows_marked(const cleora_graph *g) {
     if (!g->col_hot || !g->hot_meta || !g->hot_rows_target) return 0;
     uint32_t meta[2] = {0, 0};
-    if (hipMemcpy(meta, g->hot_meta, sizeof(meta), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    // the build may have been enqueued on a non-blocking stream, which a plain hipMemcpy does not wait for
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(meta, g->hot_meta, sizeof(meta), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return meta[1];
 }
 

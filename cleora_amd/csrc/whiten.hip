@@ -13,6 +13,7 @@
 //
 // Both are MFMA-bound (2 n d^2 flops against 1-3 passes over X), unlike the SpMM.
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -295,6 +296,170 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
     if (delta) s -= n_rows * delta[gi] * delta[gj];
     gram[(uint64_t)gi * d + gj] = s;
     if (!diag || (r / 16) < (c / 16)) gram[(uint64_t)gj * d + gi] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// centred Gram on the f32 matrix cores — the INTERMEDIATE iterations of the whitened loop, d = 256
+// ---------------------------------------------------------------------------------------------
+// Inside E <- whiten(l2_normalise(A E)) the intermediate whitenings only have to be whitenings (eigh.hip: the Cholesky form),
+// and an error of 1e-7 of the covariance is below what the f32 projection adds anyway; only the last iteration, and every
+// caller that looks at a whitened iterate, needs the f64 Gram above (pycleora/__init__.py:138-143).  For those iterations:
+//   * v_mfma_f32_32x32x2_f32 — exact f32 products, one rounding per accumulate (bit-equal to an fmaf chain) at twice the
+//     f64 matrix rate; operands are centred in f32 with an f32 shift, y = x - c32 (one rounding, 3e-8 of |y|);
+//   * one block owns ALL 256 columns: the 36 upper 32x32 tiles of the 8 x 8 grid, nine per wave (tile rows WV and 7 - WV,
+//     as in the f64 diagonal blocks: 8 - WV column fragments feed 9 MFMAs per k pair), so X is read exactly once;
+//   * f32 accumulators run over at most `sub_rows` (2048) rows, then fold into the block's private f64 partial in global
+//     memory (read-modify-write of 288 KiB per 2 MiB of X; each element belongs to one lane: no atomics, fixed order), so the
+//     rounding of an accumulator is that of a 2048-term f32 sum (~1e-6 of the partial, unbiased), and the slices are
+//     combined in f64 in a fixed order by gram32_reduce_kernel: deterministic;
+//   * column sums of y in f64 beside it (the exact mean comes out of the same pass, as above).
+constexpr int G32_D = 256, G32_KC = 16, G32_TILES = 36;
+
+struct Gram32Args {
+    const float *x;
+    uint64_t ldx, n;
+    const float *shift32;    // centring vector c32 (f32)
+    double *colsum;          // [slices][256]
+    double *partial;         // [slices][36][32][32]
+    uint64_t rows_per_slice;
+    uint32_t sub_rows;       // fold period, a multiple of G32_KC
+};
+
+__host__ __device__ constexpr int upper_tile_index(int tr, int tc) { return tr * 8 - tr * (tr - 1) / 2 + (tc - tr); }
+
+template <int WV>
+__device__ __forceinline__ void gram32_body(const Gram32Args &a, float (&lds)[2][G32_KC][G32_D]) {
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const uint64_t r_begin = (uint64_t)blockIdx.x * a.rows_per_slice;
+    const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
+    const int c4 = t & 63, lr = t >> 6;                     // loader role: columns 4 c4 .. +3 of rows lr + 4 u
+    const float4 sh = *reinterpret_cast<const float4 *>(a.shift32 + c4 * 4);
+
+    f16v acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    double cs[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 pa[4];
+    bool ok[4];
+    auto prefetch = [&](uint64_t row0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t r = row0 + lr + 4 * u;
+            ok[u] = r < r_end;
+            pa[u] = *reinterpret_cast<const float4 *>(a.x + (ok[u] ? r : r_begin) * a.ldx + c4 * 4);   // always a valid row
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) y = make_float4(__fsub_rn(pa[u].x, sh.x), __fsub_rn(pa[u].y, sh.y), __fsub_rn(pa[u].z, sh.z), __fsub_rn(pa[u].w, sh.w));
+            cs[0] += (double)y.x; cs[1] += (double)y.y; cs[2] += (double)y.z; cs[3] += (double)y.w;
+            *reinterpret_cast<float4 *>(&lds[buf][lr + 4 * u][c4 * 4]) = y;
+        }
+    };
+    double *const out = a.partial + (uint64_t)blockIdx.x * (G32_TILES * 1024);
+    // The block's partial starts as zeros (written here, by the lanes that own the elements) so that every fold is the same
+    // unconditional read-modify-write: a "first fold stores, later folds add" flag makes the compiler branch around each of the
+    // 144 loads.  The lane offset is made opaque inside the fold, or the 144 element addresses are computed ahead of the
+    // main loop and live across it in scratch.
+    auto fold = [&](bool zero) {
+        uint32_t lo = (uint32_t)((4 * h) * 32 + i) * 8u;
+        asm volatile("" : "+v"(lo));
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const int tidx = upper_tile_index(diag_tile_row(WV, q), diag_tile_col(WV, q));
+            // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+            char *p = reinterpret_cast<char *>(out) + tidx * 8192 + lo;
+            if (zero) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) *reinterpret_cast<double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256) = 0.0;
+            } else {
+                double old[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) old[reg] = *reinterpret_cast<const double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256);
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    *reinterpret_cast<double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256) = old[reg] + (double)acc[q][reg];
+                    acc[q][reg] = 0.f;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // tile by tile: all 144 loads batched ahead of the adds would spill
+        }
+    };
+    fold(true);
+
+    if (r_begin < r_end) {
+        prefetch(r_begin);
+        stage(0);
+        if (r_begin + G32_KC < r_end) prefetch(r_begin + G32_KC);
+    }
+    __syncthreads();
+    int buf = 0;
+    uint32_t in_sub = 0;
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G32_KC, buf ^= 1) {
+        if (row0 + G32_KC < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * G32_KC < r_end) prefetch(row0 + 2 * G32_KC);
+        }
+#pragma unroll
+        for (int kk = 0; kk < G32_KC / 2; ++kk) {
+            float f[8];                                     // column fragments WV..7 of rows 2 kk, 2 kk + 1 (lane half h)
+#pragma unroll
+            for (int c = WV; c < 8; ++c) f[c] = lds[buf][2 * kk + h][c * 32 + i];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[diag_tile_row(WV, q)], f[diag_tile_col(WV, q)], acc[q], 0, 0, 0);
+        }
+        in_sub += G32_KC;
+        if (in_sub >= a.sub_rows || row0 + G32_KC >= r_end) {
+            fold(false);
+            in_sub = 0;
+        }
+        __syncthreads();
+    }
+
+    double *red = reinterpret_cast<double *>(&lds[0][0][0]);   // the loop ended on a barrier: the staging buffers are free
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[lr * G32_D + c4 * 4 + q] = cs[q];
+    __syncthreads();
+    if (t < G32_D) a.colsum[(uint64_t)blockIdx.x * G32_D + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
+}
+
+__global__ __launch_bounds__(256, 2) void gram32_kernel(const Gram32Args a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][G32_KC][G32_D];
+    switch (threadIdx.x >> 6) {                              // whole waves take each arm; every arm meets the same barriers
+        case 0: gram32_body<0>(a, lds); break;
+        case 1: gram32_body<1>(a, lds); break;
+        case 2: gram32_body<2>(a, lds); break;
+        default: gram32_body<3>(a, lds); break;
+    }
+}
+
+// the sampled shift as the f32 value the kernel centres with, and that same value in f64 for the exact correction
+__global__ __launch_bounds__(256) void shift_round_kernel(double *__restrict__ shift64, float *__restrict__ shift32, uint32_t d) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const float s = (float)shift64[c];
+    shift32[c] = s;
+    shift64[c] = (double)s;
+}
+
+// gram = sum over slices (fixed order) - n delta delta^T, mirrored to the lower triangle
+__global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__restrict__ partial, uint32_t slices,
+                                                            const double *__restrict__ delta, double n_rows,
+                                                            double *__restrict__ gram) {
+    const uint32_t p = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;       // tile, element of the tile
+    uint32_t tr, tc;
+    pair_to_tiles(p, 8, tr, tc);
+    const uint32_t gi = tr * 32 + e / 32, gj = tc * 32 + e % 32;
+    double s = 0.0;
+    for (uint32_t sl = 0; sl < slices; ++sl) s += partial[((uint64_t)sl * G32_TILES + p) * 1024 + e];
+    s -= n_rows * delta[gi] * delta[gj];
+    gram[(uint64_t)gi * G32_D + gj] = s;
+    if (tr != tc) gram[(uint64_t)gj * G32_D + gi] = s;
 }
 
 // Row slices per launch: the grid is sized to ONE resident round (2 blocks per CU) so there is no
@@ -663,12 +828,289 @@ __global__ __launch_bounds__(256) void pack_transform_kernel(const float *__rest
     reinterpret_cast<float4 *>(tp)[idx] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// projection, third form: f32-accurate products from the bf16 matrix cores
+// ---------------------------------------------------------------------------------------------
+// The f32 MFMA runs at the f32 VECTOR rate (157 TF), one sixteenth of the bf16 MFMA rate of the same chip.  An f32 value
+// is exactly the sum of three bf16 values up to 2^-27 of its magnitude (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 -
+// x2): 8 + 8 + 8 significand bits, every subtraction exact), and a product of two bf16 values is exact in f32.  So
+//     x * t = x1 t1 + x1 t2 + x2 t1 + x2 t2 + x1 t3 + x3 t1   + O(2^-25 |x t|)
+// — six bf16 MFMAs with f32 accumulation give the product to better than one f32 rounding (the three dropped terms are
+// <= 2^-26 + 2^-26 + 2^-36 of |x t|), i.e. the same error class as the sgemm of pycleora/__init__.py:163 (measured against
+// an f64 product in tests/test_gpu_whiten.py: not larger than the f32-MFMA kernel's own error), at 6/16 of its matrix-core
+// time.  The kernel is then bound by reading X and writing the result (HBM), not by the matrix cores.
+//
+//   * block = 4 waves = 64 rows x 256 columns (one "pass" of output columns; wider k runs blockIdx.y passes); wave (wr, wc)
+//     owns rows 32 wr .. +31 and columns 128 wc .. +127: four 32x32 accumulator tiles.  Persistent: 2 blocks per CU, each
+//     walking row tiles blockIdx.x, + gridDim.x, ...; the loop is FLAT over (row tile, k-step), so the operands of the next
+//     row tile are already in flight while the current one finishes.
+//   * A (rows of X) goes straight from HBM into the fragment registers: lane (i, h) of k-step ks loads the two 16-byte
+//     pieces [16 ks + 4 h, +4) and [16 ks + 8 + 4 h, +4) of row i (64 contiguous bytes per row and k-step, every byte of X
+//     read once), RING k-steps ahead; it is centred (and blended) in f32 exactly like the other forms, then split.
+//   * B (the transform) is split ONCE per call by pack_transform_split_kernel into fragment order with the same k mapping
+//     — Tp[((pass*KS + ks)*3 + split)*8 + tile][lane] = 8 bf16: slot e <-> k = 16 ks + 8 (e >> 2) + 4 h + (e & 3) —
+//     and streamed through a double-buffered 24 KiB LDS stage per k-step (plain loads one step ahead, ds_write_b128, one
+//     barrier per step; fragments are lane-linear 1 KiB blocks: conflict-free ds_read_b128).
+//   * per k-step and wave: 12 B fragments, 24 MFMAs (the six products of each of the four tiles; consecutive MFMAs go to
+//     different accumulators).
+//   * epilogue per row tile: optional row normalisation on the accumulators (as in the second form), stores.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SR = 64;                 // rows per block tile
+constexpr int SN = 256;                // output columns per pass
+constexpr int SKB = 3 * 8 * 64;        // 16-byte units of packed T per (pass, k-step): 24 KiB
+
+// (lo, hi) -> three packed bf16 pairs whose sum is (lo, hi) to 2^-27: v_cvt_pk_bf16_f32 (round to nearest even), the bf16
+// back as f32 by shift / mask, an exact f32 subtraction — twice.
+__device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    const f2v v = {lo, hi};
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f2v f1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    const f2v r1 = v - f1;
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    const f2v f2 = {__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
+    const f2v r2 = r1 - f2;
+    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+}
+
+// T (d x k row-major f32) -> split into three bf16 matrices, in fragment order, zero-padded to whole k-steps and passes.
+__global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *__restrict__ t, uint32_t d, uint32_t k,
+                                                                   uint32_t ksteps, uint32_t passes, u32x4 *__restrict__ tp) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;     // one 16-byte unit
+    if (idx >= (uint64_t)passes * ksteps * SKB) return;
+    const uint32_t lane = (uint32_t)(idx & 63), j = (uint32_t)((idx >> 6) & 7), s = (uint32_t)((idx >> 9) % 3);
+    const uint64_t step = idx / SKB;                                   // pass * ksteps + ks
+    const uint32_t ks = (uint32_t)(step % ksteps), pass = (uint32_t)(step / ksteps);
+    const uint32_t col = pass * SN + j * 32 + (lane & 31), h = lane >> 5;
+    uint32_t w[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t e = 2 * m + q;
+            const uint32_t kk = 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3);
+            v[q] = (kk < d && col < k) ? t[(uint64_t)kk * k + col] : 0.f;
+        }
+        uint32_t p[3];
+        split3_pair(v[0], v[1], p[0], p[1], p[2]);
+        w[m] = p[s];
+    }
+    tp[idx] = (u32x4){w[0], w[1], w[2], w[3]};
+}
+
+template <bool SCALED, bool BLEND, int RING>
+__global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
+                                                               uint32_t ksteps, uint64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *const bs = reinterpret_cast<u32x4 *>(smem);                           // [2][SKB]
+    float *const mean_s = reinterpret_cast<float *>(smem + 2 * SKB * 16);        // [16 ksteps]
+    float *const red = mean_s + 16 * ksteps;                                     // [4 waves][32 rows]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1, i = lane & 31, h = lane >> 5;
+    const uint32_t pass = blockIdx.y;
+    const u32x4 *const tpp = tp + (uint64_t)pass * ksteps * SKB;
+    const uint64_t my_tiles = tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const uint64_t total = my_tiles * ksteps;                                    // a multiple of RING (ksteps is)
+    if (total == 0) return;
+
+    for (uint32_t c = t; c < 16 * ksteps; c += 256) mean_s[c] = c < a.d ? a.mean[c] : 0.f;
+    // B of step 0 straight into buffer 0
+#pragma unroll
+    for (int u = 0; u < 6; ++u) bs[t + 256 * u] = tpp[t + 256 * u];
+
+    // ---- operand ring: A of the next RING k-steps --------------------------------------------------------------------
+    float4 ra[RING][2], rb[BLEND ? RING : 1][2];
+    float rs[SCALED ? RING : 1];          // the row's scale travels with its operand slot (an unconditional 4-byte load per
+                                          // k-step: a load behind a "first k-step of a tile" branch would cost the counted waits)
+    uint64_t ltile = blockIdx.x;          // row tile / k-step of the NEXT load
+    uint32_t lks = 0;
+    auto row_of = [&](uint64_t tile) {
+        const uint64_t r = tile * SR + (uint64_t)(wr * 32 + i);
+        return r < a.n ? r : a.n - 1;                                            // clamped: always a valid address
+    };
+    auto issue_a = [&](int slot) {
+        const uint64_t r = row_of(ltile);
+        const float *p = a.x + r * a.ldx + 16 * lks + 4 * h;
+        ra[slot][0] = *reinterpret_cast<const float4 *>(p);
+        ra[slot][1] = *reinterpret_cast<const float4 *>(p + 8);
+        if constexpr (BLEND) {
+            const float *p2 = a.x2 + r * a.ldx2 + 16 * lks + 4 * h;
+            rb[slot][0] = *reinterpret_cast<const float4 *>(p2);
+            rb[slot][1] = *reinterpret_cast<const float4 *>(p2 + 8);
+        }
+        if constexpr (SCALED) rs[slot] = a.rowscale[r];
+        if (++lks == ksteps) { lks = 0; ltile += gridDim.x; }
+    };
+#pragma unroll
+    for (int slot = 0; slot + 1 < RING; ++slot) issue_a(slot);                   // k-steps 0 .. RING-2; step g issues g + RING - 1
+
+    f16v acc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
+
+    __syncthreads();
+    uint64_t tile = blockIdx.x;
+    uint32_t ks0 = 0;
+    for (uint64_t g0 = 0; g0 < total; g0 += RING) {
+#pragma unroll
+        for (int rr = 0; rr < RING; ++rr) {
+            const uint32_t ks = ks0 + rr;
+            const int buf = rr & 1;                                              // RING is even
+            // B of the next k-step: six coalesced 16-byte loads per thread, written to the other buffer at the end
+            const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
+            u32x4 bst[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) bst[u] = tpp[(uint64_t)ksn * SKB + t + 256 * u];
+            // A of k-step g + RING - 1 into the slot the PREVIOUS step consumed, right behind the B loads: the wait for B at
+            // the end of this step leaves exactly these loads in flight (vmcnt retires in order), the one at the end of the
+            // next step completes them — two steps of latency cover, consumed in the step after
+            issue_a((rr + RING - 1) % RING);
+
+            // A: centre (block = embeddings - mean_f32, pycleora/__init__.py:161), blend, split
+            const float4 m0 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 4 * h);
+            const float4 m1 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 8 + 4 * h);
+            const float xv[8] = {ra[rr][0].x, ra[rr][0].y, ra[rr][0].z, ra[rr][0].w, ra[rr][1].x, ra[rr][1].y, ra[rr][1].z, ra[rr][1].w};
+            const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = centre(xv[e], mu[e], SCALED ? rs[rr] : 1.f, SCALED);
+            if constexpr (BLEND) {
+                const float x2v[8] = {rb[rr][0].x, rb[rr][0].y, rb[rr][0].z, rb[rr][0].w, rb[rr][1].x, rb[rr][1].y, rb[rr][1].z, rb[rr][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = __fadd_rn(__fmul_rn(a.alpha, o[e]), __fmul_rn(a.beta, __fsub_rn(x2v[e], mu[e])));
+            }
+            u32x4 as[3];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                uint32_t p1, p2, p3;
+                split3_pair(o[2 * m], o[2 * m + 1], p1, p2, p3);
+                as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
+            }
+
+            // B fragments of this wave's four tiles, all three splits
+            u32x4 bf[3][4];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bf[sp][jj] = bs[buf * SKB + (sp * 8 + wc * 4 + jj) * 64 + lane];
+            constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as[PA[q]]),
+                                                                      __builtin_bit_cast(bf16x8, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
+
+            // B of the next k-step into the other buffer (nobody reads it during this step).  Before the tile epilogue, not
+            // after: behind that branch the compiler cannot count the epilogue's stores and drains everything (vmcnt(0)),
+            // the operand ring included, at the end of every RING-th step.
+#pragma unroll
+            for (int u = 0; u < 6; ++u) bs[(buf ^ 1) * SKB + t + 256 * u] = bst[u];
+
+            if (rr == RING - 1 && ks0 + RING == ksteps) {
+                // ---- end of a row tile: normalise (whole rows live in this block when there is one pass), store --------
+                if (a.norm) {
+                    float pr[16];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) v += a.norm == 1 ? acc[jj][reg] * acc[jj][reg] : fabsf(acc[jj][reg]);
+                        pr[reg] = v;
+                    }
+#pragma unroll
+                    for (int ofs = 16; ofs > 0; ofs >>= 1)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) pr[reg] += __shfl_xor(pr[reg], ofs, 64);
+                    float mine = 0.f;                                            // lane i < 16 of half h publishes row slot i
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        if (i == reg) mine = pr[reg];
+                    if (i < 16) red[w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = mine;
+                    __syncthreads();
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                        const float sum = red[(wr * 2) * 32 + rl] + red[(wr * 2 + 1) * 32 + rl];      // column halves in order
+                        // L2: v * (1 / max(sqrt(s), 1e-10)) like src/embedding.rs:98-102; L1: v / max(s, 1e-10) (pycleora/__init__.py:947-950)
+                        const float f = a.norm == 1 ? 1.0f / fmaxf(sqrtf(sum), 1e-10f) : fmaxf(sum, 1e-10f);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[jj][reg] = a.norm == 1 ? acc[jj][reg] * f : acc[jj][reg] / f;
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                        const uint64_t row = tile * SR + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                        const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
+                        if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[jj][reg];
+                        acc[jj][reg] = 0.f;
+                    }
+                tile += gridDim.x;
+            }
+            __syncthreads();
+        }
+        ks0 = ks0 + RING == ksteps ? 0 : ks0 + RING;
+    }
+}
+
 }  // namespace
+
+inline uint32_t gram32_slices(uint64_t n, int per_cu) { return gram_slices(n, 1, per_cu); }
 
 uint64_t gram_workspace(uint64_t n, uint32_t d) {
     const GramPlan p = gram_plan(n, d);
     // tile partials, per-slice column sums of the diagonal blocks, delta
-    return (uint64_t)p.s_max * p.pairs * GT * GT + (uint64_t)p.s_diag * p.tiles * GT + (uint64_t)p.tiles * GT;
+    uint64_t need = (uint64_t)p.s_max * p.pairs * GT * GT + (uint64_t)p.s_diag * p.tiles * GT + (uint64_t)p.tiles * GT;
+    if (d == G32_D) {   // the f32 form: [slices][36][32][32] partials, [slices][256] column sums, delta
+        const uint64_t s32 = gram32_slices(n, 2);
+        const uint64_t need32 = s32 * (G32_TILES * 1024 + G32_D) + G32_D;
+        if (need32 > need) need = need32;
+    }
+    return need;
+}
+
+bool gram32_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d) {
+    static const bool off = std::getenv("CLEORA_GRAM") && !std::strcmp(std::getenv("CLEORA_GRAM"), "f64");   // A/B switch
+    return !off && d == G32_D && ldx % 4 == 0 && aligned16(x) && n >= 4096;
+}
+
+// One-pass centred Gram on the f32 matrix cores (d = 256; see gram32_kernel).  shift64 / shift32: the sampled shift, rounded to
+// f32 here (both are updated: the kernel centres with the f32 value, the exact correction uses that same value).
+int launch_gram32(const float *x, uint64_t ldx, uint64_t n, double *shift64, float *shift32, double *ws, double *gram,
+                  hipStream_t stream, double *mean_out64, float *mean_out32, int blocks_per_cu) {
+    CL_REQUIRE(x != nullptr && shift64 != nullptr && shift32 != nullptr && ws != nullptr && gram != nullptr && mean_out64 != nullptr &&
+               mean_out32 != nullptr, "x / shift / workspace / gram / mean is NULL");
+    CL_REQUIRE(gram32_applies(x, ldx, n, G32_D), "internal: the f32 Gram does not apply to this shape");
+    const uint32_t slices = gram32_slices(n, blocks_per_cu == 1 ? 1 : 2);
+    Gram32Args a{};
+    a.x = x;
+    a.ldx = ldx;
+    a.n = n;
+    a.partial = ws;
+    a.colsum = ws + (uint64_t)slices * (G32_TILES * 1024);
+    double *delta = a.colsum + (uint64_t)slices * G32_D;
+    uint64_t rps = (n + slices - 1) / slices;
+    a.rows_per_slice = (rps + G32_KC - 1) / G32_KC * G32_KC;
+    a.sub_rows = 2048;
+    hipLaunchKernelGGL(shift_round_kernel, dim3(1), dim3(256), 0, stream, shift64, shift32, (uint32_t)G32_D);
+    // mean_out32 may be the buffer that holds shift32: the kernel reads it before gram_mean_kernel (same stream) rewrites it
+    a.shift32 = shift32;
+    hipLaunchKernelGGL(gram32_kernel, dim3(slices), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gram_mean_kernel, dim3(1), dim3(256), 0, stream, a.colsum, slices, 2u, (uint32_t)G32_D, n, shift64, delta,
+                       mean_out64, mean_out32);
+    hipLaunchKernelGGL(gram32_reduce_kernel, dim3(4, G32_TILES), dim3(256), 0, stream, ws, slices, delta, (double)n, gram);
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
 }
 
 // mean_out64 / mean_out32 == nullptr: `mean` is the exact mean (two-pass form, pycleora/__init__.py:136-143 literally).
@@ -750,6 +1192,46 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.nb_n = (k + PN - 1) / PN;
     a.w4x = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && (!x2 || (ldx2 % 4 == 0 && aligned16(x2)));
     a.w4t = (k % 4 == 0) && aligned16(t);
+    // split-bf16 form (third form above): any d that is a multiple of 32, any k.  CLEORA_PROJECT=f32 keeps the f32-MFMA
+    // forms below (A/B runs, and the accuracy comparison of tests/test_gpu_whiten.py).
+    static const char *form_env = std::getenv("CLEORA_PROJECT");
+    const bool f32_forms = form_env && !std::strcmp(form_env, "f32");
+    if (!f32_forms && a.w4x && d % 32 == 0 && n >= 1) {
+        const uint32_t ksteps = d / 16, passes = (k + SN - 1) / SN;
+        const uint64_t units = (uint64_t)passes * ksteps * SKB;
+        u32x4 *tp = nullptr;
+        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
+        hipLaunchKernelGGL(pack_transform_split_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, t, d, k,
+                           ksteps, passes, tp);
+        const uint64_t tiles = (n + SR - 1) / SR;
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0, c = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+            cus = c > 0 ? c : 256;
+        }
+        const uint64_t resident = 2ull * (uint64_t)cus;                       // two 256-thread blocks per CU
+        const unsigned gx = (unsigned)(tiles < resident ? tiles : resident);
+        const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 4 * 32 * sizeof(float);
+        a.norm = (norm && passes == 1) ? norm : 0;                            // whole rows inside one block only
+        if (norm_done) *norm_done = a.norm != 0;
+        const dim3 grid(gx, passes);
+        const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
+#define CLEORA_SPLIT_LAUNCH(SC, BL, RG) \
+        hipLaunchKernelGGL((project_split_kernel<SC, BL, RG>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles)
+        if (d % 64 == 0 && !blend) {
+            if (scaled) CLEORA_SPLIT_LAUNCH(true, false, 4); else CLEORA_SPLIT_LAUNCH(false, false, 4);
+        } else if (blend) {
+            if (scaled) CLEORA_SPLIT_LAUNCH(true, true, 2); else CLEORA_SPLIT_LAUNCH(false, true, 2);
+        } else {
+            if (scaled) CLEORA_SPLIT_LAUNCH(true, false, 2); else CLEORA_SPLIT_LAUNCH(false, false, 2);
+        }
+#undef CLEORA_SPLIT_LAUNCH
+        const hipError_t le = hipGetLastError();
+        CL_HIP(hipFreeAsync(tp, stream));
+        CL_HIP(le);
+        return CLEORA_OK;
+    }
     // rows-in-LDS form: whole rows as float4, reduction index in groups of 8, the X tile within the LDS budget
     static const bool first_form_only = std::getenv("CLEORA_PROJECT_TILED") != nullptr;   // A/B switch for profiling
     if (!first_form_only && a.w4x && d % 32 == 0 && d <= 512 && aligned16(mean) && n >= 4 * RM) {
@@ -760,12 +1242,9 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         hipLaunchKernelGGL(pack_transform_kernel, dim3((unsigned)((packed / 4 + 255) / 256)), dim3(256), 0, stream, t, d, k,
                            col_tiles, tp);
         const size_t lds_bytes = (size_t)RM * (d + 4) * sizeof(float) + 64;   // + the one-group read-ahead of the last row
-        static bool attr_set = false;
-        if (!attr_set) {
-            CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(project_rows_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        // per DEVICE and cheap: set on every call (a process-wide "done" flag broke the second GPU of a multi-device host)
+        CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(project_rows_kernel<2>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         const uint64_t row_blocks = (n + RM - 1) / RM;
         CL_REQUIRE(row_blocks < (1ull << 31), "internal: too many row blocks");
         a.norm = (norm && col_tiles == 8) ? norm : 0;                     // whole rows inside one block only

@@ -253,6 +253,11 @@ def find_most_similar(graph, embeddings, query_entity, top_k=10, exclude_self=Tr
     k = min(int(top_k), n)
     if k <= 0:
         return []
+    ids = graph.entity_ids
+    if k > 1024:        # beyond the device selection's limit: device scores, host selection (variants._topk_by_host_selection)
+        from .variants import _topk_by_host_selection
+        idx, sims = _topk_by_host_selection(graph, x, [query_idx], k, exclude_self, False, self_score=-1.0)
+        return [{"entity_id": ids[int(i)], "index": int(i), "similarity": float(v)} for i, v in zip(idx[0], sims[0])]
     L = _hip.lib()
     dx = _hip.DevArray.from_host(x)
     dq = _hip.DevArray.from_host(np.asarray([query_idx], dtype=np.uint32))
@@ -263,7 +268,6 @@ def find_most_similar(graph, embeddings, query_entity, top_k=10, exclude_self=Tr
                                         ws.ptr, None))
     _hip.check(L.cleora_stream_sync(None))
     idx, sims = oi.to_host()[0], os_.to_host()[0]
-    ids = graph.entity_ids
     # the reference sets the query's own similarity to -1 (:768-769) and still lists it if it ranks; the device masks
     # with -2: report -1 for it like the reference
     return [{"entity_id": ids[int(i)], "index": int(i), "similarity": float(-1.0 if (exclude_self and int(i) == query_idx) else v)}

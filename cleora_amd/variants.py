@@ -208,8 +208,45 @@ def predict_links(graph, embeddings, top_k=10, exclude_existing=True, source_ent
     return [{"source": ids[int(src[i])], "target": ids[int(tgt[i])], "score": float(sc[i])} for i in order]
 
 
+TOPK_DEVICE_MAX = 1024      # cleora_topk_cosine_dev selects at most this many per query (csrc/similarity.hip)
+
+
+def _topk_by_host_selection(graph, x, query_rows, k, exclude_self, exclude_existing, self_score=-2.0):
+    """The same result for k > TOPK_DEVICE_MAX (the reference accepts any top_k): the scores still come from the device
+    (cleora_cosine_scores_dev, one pass over X per query), the masks and the selection run on the host like the
+    reference's `np.argsort(sims)[::-1][:top_k]` (pycleora/__init__.py:663, 771)."""
+    L = _hip.lib()
+    n, d = x.shape
+    dx = _hip.DevArray.from_host(x)
+    dq, ds = _hip.DevArray((d,), np.float32), _hip.DevArray((n,), np.float32)
+    out_i, out_s = np.empty((len(query_rows), k), np.uint32), np.empty((len(query_rows), k), np.float32)
+    nbr_out = nbr_in = None
+    if exclude_existing:
+        rows, cols = (np.asarray(a, dtype=np.int64) for a in graph.to_sparse_csr()[:2])
+        by_row, by_col = np.argsort(rows, kind="stable"), np.argsort(cols, kind="stable")
+        nbr_out = (np.searchsorted(rows[by_row], np.arange(n + 1)), cols[by_row])     # (r, *) stored
+        nbr_in = (np.searchsorted(cols[by_col], np.arange(n + 1)), rows[by_col])      # (*, r) stored
+    for j, q in enumerate(query_rows):
+        v = x[q].astype(np.float32)
+        v = v / max(float(np.linalg.norm(v)), 1e-10)
+        _hip.check(L.cleora_memcpy_h2d(dq.ptr, _hip.ptr(np.ascontiguousarray(v)), dq.nbytes, None))
+        _hip.check(L.cleora_cosine_scores_dev(dx.ptr, d, n, d, dq.ptr, ds.ptr, None))
+        _hip.check(L.cleora_stream_sync(None))
+        sims = ds.to_host()
+        if exclude_self:
+            sims[q] = self_score
+        if exclude_existing:
+            for ptr, other in (nbr_out, nbr_in):
+                sims[other[ptr[q]:ptr[q + 1]]] = -2.0
+        top = np.argsort(sims)[::-1][:k]
+        out_i[j], out_s[j] = top, sims[top]
+    return out_i, out_s
+
+
 def _topk_neighbours(graph, x, query_rows, k, exclude_self, exclude_existing):
     """(index uint32[nq, k], score f32[nq, k]) of the k most cosine-similar rows of x for every query row."""
+    if k > TOPK_DEVICE_MAX:
+        return _topk_by_host_selection(graph, x, query_rows, k, exclude_self, exclude_existing)
     L = _hip.lib()
     n, d = x.shape
     nq = len(query_rows)

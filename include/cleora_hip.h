@@ -235,6 +235,27 @@ int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, 
                                 float *transform_dev, double *eigenvalues_dev, void *workspace,
                                 void *stream);
 
+/* The statistics half of whiten_embeddings in ONE pass over X (what cleora_whiten_dev and the whitened cleora_embed loop run):
+ * the exact f64 mean (:136) and the centred Gram sum_r (x_r - mean)(x_r - mean)^T (:138-143 without the 1/(n-1)), computed
+ * around a sampled shift and corrected exactly (csrc/whiten.hip).  intermediate = 0: f64 matrix cores end to end, the form
+ * behind every whitening a caller can observe.  intermediate = 1: the form the whitened loop takes for iterations whose
+ * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — at d = 256 the Gram runs on the f32 matrix
+ * cores (exact products, f32 sums over <= 2048 rows, f64 across; ~1e-7 of the diagonal), other shapes as intermediate = 0.
+ * workspace: cleora_whiten_workspace(n, d) BYTES; mean64_dev: f64[d]; gram_dev: f64[d*d].  n >= 2. */
+int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, int intermediate,
+                            double *mean64_dev, double *gram_dev, void *stream);
+
+/* The transform for the INTERMEDIATE iterations of the loop E <- whiten(l2_normalise(A E)) (pycleora/__init__.py:109-117):
+ * inside that loop any W with W^T cov W = I gives the same final embedding as the reference's PCA form (two whitenings
+ * differ by a rotation, which the row-wise L2 norm and the last iteration's PCA whitening remove), so the cheap Cholesky form
+ * transform = L^-T (cov = L L^T; d x d row-major f32, upper triangular) is taken — but ONLY when the reference's clamp
+ * max(lambda, 1e-10) (:155) is provably inactive: potrf succeeds, the smallest squared pivot is >= 1e-8 and
+ * trace(cov^-1) = ||L^-T||_F^2 <= 1e10 (=> lambda_min >= 1e-10).  Otherwise the PCA form of cleora_whiten_transform_dev
+ * (k = d) is computed.  *form_out (host, may be NULL): 1 = Cholesky form, 0 = PCA form.
+ * Unlike the other *_dev entry points this one WAITS for `stream` (the decision is taken on the host). */
+int cleora_whiten_transform_any_dev(const double *gram_dev, uint64_t n, uint32_t d, float *transform_dev,
+                                    void *workspace, void *stream, int *form_out);
+
 /* whiten_embeddings (pycleora/__init__.py:130-164) on device buffers, one stream, no host round trip:
  * column sums -> mean -> centred Gram -> transform -> projection.  y: n x k (ldy), must not alias x.
  * n_components = 0 (or >= d) keeps all d components.  n == 1 copies the row unchanged (:132-133).

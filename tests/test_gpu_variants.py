@@ -233,3 +233,49 @@ def test_edge_attention_kernels_on_random_graphs(n, d):
     nonempty = np.diff(rowptr64) > 0
     np.testing.assert_allclose(sums[nonempty], 1.0, atol=2e-6)
     g.close()
+
+
+def test_top_k_beyond_the_device_selection_limit():
+    """find_most_similar / predict_links accept any top_k like the reference (pycleora/__init__.py:636-681, 753-781); beyond
+    the 1024 the device selection handles the scores still come from the device and the selection runs on
+    the host.  Against a numpy restatement of the reference's own lines."""
+    from cleora_amd import embed as dev_embed
+    rng = np.random.default_rng(5)
+    n = 2500
+    edges = [f"e{a} e{b}" for a, b in zip(rng.integers(0, n, 12_000), rng.integers(0, n, 12_000)) if a != b]
+    edges += [f"e{i} e{(i + 1) % n}" for i in range(n)]            # every entity exists
+    g = SparseMatrix.from_iterator(iter(edges), "complex::reflexive::x")
+    n = g.num_entities
+    emb = rng.standard_normal((n, 24)).astype(np.float32)
+    normed = emb / np.maximum(np.linalg.norm(emb, axis=1, keepdims=True), 1e-10)
+    ids = g.entity_ids
+    # find_most_similar, top_k = 1500
+    q = 17
+    got = dev_embed.find_most_similar(g, emb, ids[q], top_k=1500)
+    sims = normed @ (emb[q] / max(np.linalg.norm(emb[q]), 1e-10))
+    sims[q] = -1.0
+    top = np.argsort(sims)[::-1][:1500]
+    assert len(got) == 1500
+    assert [r["index"] for r in got[:50]] == [int(i) for i in top[:50]]
+    assert set(r["index"] for r in got) ^ set(int(i) for i in top) <= set(int(i) for i in top[-5:]) | set(r["index"] for r in got[-5:])
+    np.testing.assert_allclose([r["similarity"] for r in got], sims[[r["index"] for r in got]], rtol=0, atol=2e-6)
+    # predict_links, top_k = 1200 over two sources, existing edges excluded
+    rows, cols = g.to_sparse_csr()[:2]
+    existing = set(zip(rows.tolist(), cols.tolist()))
+    src = [3, 40]
+    got = variants.predict_links(g, emb, top_k=1200, exclude_existing=True, source_entities=[ids[s] for s in src])
+    cand = []
+    for s in src:
+        sm = normed @ normed[s]
+        sm[s] = -2.0
+        for o in range(n):
+            if (s, o) in existing or (o, s) in existing:
+                sm[o] = -2.0
+        for tgt in np.argsort(sm)[::-1][:1200]:
+            if sm[tgt] > -2.0:
+                cand.append((ids[s], ids[int(tgt)], float(sm[tgt])))
+    cand.sort(key=lambda c: c[2], reverse=True)
+    cand = cand[:1200]
+    assert len(got) == len(cand) == 1200
+    np.testing.assert_allclose([r["score"] for r in got], [c[2] for c in cand], rtol=0, atol=2e-6)
+    assert sum((r["source"], r["target"]) == (c[0], c[1]) for r, c in zip(got, cand)) >= 1190     # near-ties may swap

@@ -229,3 +229,115 @@ def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, k
         want, _ = ow.embed_slow(lambda v: oracle.spmm(rowptr, col, val, v), x0, iters, whiten=True)
         assert np.abs(cos(outs[0]) - cos(want)).max() < 1e-3
     g.close()
+
+
+@pytest.mark.parametrize("route", ["library", "kernel"])
+def test_cholesky_guard_implies_the_reference_clamp(route, monkeypatch):
+    """Intermediate iterations may take the Cholesky whitening only when the reference's clamp max(lambda, 1e-10)
+    (pycleora/__init__.py:155) is provably inactive.  The smallest pivot of the factor only bounds lambda_min from ABOVE
+    (a covariance with lambda_min = 5e-11 and every squared pivot >= 1e-8 exists: below); the guard therefore also
+    requires trace(cov^-1) = ||L^-T||_F^2 <= 1e10, which implies lambda_min >= 1e-10.  Checked on synthetic
+    covariances Q diag(lambda) Q^T through cleora_whiten_transform_any_dev:
+      lambda_min = 1e-9  -> Cholesky form (form = 1), T^T C T = I
+      lambda_min = 5e-11 -> PCA form (form = 0) with the clamp: T^T C T = diag(1, ..., 1, 0.5)."""
+    import ctypes
+    monkeypatch.setenv("CLEORA_CHOLESKY", route)
+    L = _hip.lib()
+    d, n = 256, 10_000
+    rng = np.random.default_rng(3)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    ws = _hip.DevArray((L.cleora_eigh_workspace(d),), np.uint8)
+    dt = _hip.DevArray((d, d), np.float32)
+    for lam_min, want_form in ((1e-9, 1), (5e-11, 0)):
+        lam = np.sort(rng.uniform(0.5, 2.0, d) / d)[::-1].copy()
+        lam[-1] = lam_min
+        cov = (q * lam) @ q.T
+        cov = (cov + cov.T) / 2
+        piv = np.diag(np.linalg.cholesky(cov)) ** 2
+        if want_form == 0:
+            assert piv.min() >= 1e-8, "the case must pass the pivot test alone (it is the case the old guard let through)"
+        dg = _hip.DevArray.from_host(np.ascontiguousarray(cov * (n - 1)))
+        form = ctypes.c_int(-1)
+        _hip.check(L.cleora_whiten_transform_any_dev(dg.ptr, n, d, dt.ptr, ws.ptr, None, ctypes.byref(form)))
+        _hip.check(L.cleora_stream_sync(None))
+        assert form.value == want_form, (lam_min, form.value, piv.min())
+        t = dt.to_host().astype(np.float64)
+        m = t.T @ cov @ t
+        if want_form == 1:
+            assert np.abs(m - np.eye(d)).max() <= 2e-3          # f32 transform of a 1e7-conditioned matrix
+        else:
+            dm = np.diag(m)
+            assert np.abs(dm[:-1] - 1).max() <= 2e-3 and abs(dm[-1] - 0.5) <= 2e-3      # lambda_min / 1e-10
+            assert np.abs(m - np.diag(dm)).max() <= 2e-3
+
+
+def test_intermediate_gram_on_the_f32_matrix_cores():
+    """cleora_whiten_stats_dev(intermediate = 1) at d = 256: centred Gram on v_mfma_f32_32x32x2_f32 (f32 sums over <= 2048
+    rows, f64 across) against the f64 form (intermediate = 0) and numpy fp64.  Stated: the f64 form 1e-13 relative
+    Frobenius as before; the f32 form <= 5e-7 of the Gram's Frobenius norm and of its diagonal entry by entry; mean to 1e-9."""
+    L = _hip.lib()
+    n, d = 70_001, 256                                         # not a multiple of the 16-row chunk or of the slice count
+    rng = np.random.default_rng(8)
+    x = (rng.standard_normal((n, d)) * np.linspace(0.3, 2.0, d) + rng.standard_normal(d) * 0.2).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    dx = _hip.DevArray.from_host(x)
+    ws = _hip.DevArray((L.cleora_whiten_workspace(n, d),), np.uint8)
+    dm, dg = _hip.DevArray((d,), np.float64), _hip.DevArray((d, d), np.float64)
+    x64 = x.astype(np.float64)
+    mean = x64.mean(axis=0)
+    gram = (x64 - mean).T @ (x64 - mean)
+    for intermediate, tol in ((0, 1e-12), (1, 5e-7)):
+        _hip.check(L.cleora_whiten_stats_dev(dx.ptr, d, n, d, ws.ptr, intermediate, dm.ptr, dg.ptr, None))
+        _hip.check(L.cleora_stream_sync(None))
+        gm, gg = dm.to_host(), dg.to_host()
+        assert np.abs(gm - mean).max() <= 1e-9
+        assert np.linalg.norm(gg - gram) <= tol * np.linalg.norm(gram), (intermediate, np.linalg.norm(gg - gram) / np.linalg.norm(gram))
+        assert np.abs(np.diag(gg) - np.diag(gram)).max() <= tol * np.diag(gram).max()
+        np.testing.assert_array_equal(gg, gg.T)
+
+
+PROJECTION_ERROR_SCRIPT = r'''
+import json, sys
+import numpy as np
+from cleora_amd import _hip
+L = _hip.lib()
+out = {}
+for n, d, k in ((50_000, 256, 256), (20_000, 1024, 1024), (30_000, 64, 64), (20_000, 256, 100), (5_000, 96, 96)):
+    rng = np.random.default_rng(d + k)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    mean = x.mean(axis=0).astype(np.float32)
+    t = (rng.standard_normal((d, k)) * np.sqrt(d)).astype(np.float32)
+    dx, dm, dt = (_hip.DevArray.from_host(a) for a in (x, mean, t))
+    do = _hip.DevArray((n, k), np.float32)
+    _hip.check(L.cleora_project_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, k, do.ptr, k, None))
+    _hip.check(L.cleora_stream_sync(None))
+    got = do.to_host().astype(np.float64)
+    ref = (x - mean).astype(np.float64) @ t.astype(np.float64)
+    out[f"{n}x{d}x{k}"] = [float(np.abs(got - ref).max() / np.abs(ref).max()), float(np.sqrt(((got - ref) ** 2).mean()) / np.abs(ref).max())]
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_split_projection_is_as_accurate_as_the_f32_matrix_cores():
+    """The projection's default form computes every f32 product from six bf16 MFMAs (three-way split operands, whiten.hip);
+    CLEORA_PROJECT=f32 keeps the v_mfma_f32_32x32x2_f32 forms.  Both against an f64 product of the same f32 inputs, several
+    shapes: the split form's maximum and RMS error must not exceed 1.5x the f32 matrix cores' (the numpy sgemm of
+    pycleora/__init__.py:163 sits in the same class: ~1e-7 of max|out| at d = 256)."""
+    import json
+    import subprocess
+    import sys
+    res = {}
+    for form in ("split", "f32"):
+        env = dict(os.environ)
+        env.pop("CLEORA_PROJECT", None)
+        if form == "f32":
+            env["CLEORA_PROJECT"] = "f32"
+        p = subprocess.run([sys.executable, "-c", PROJECTION_ERROR_SCRIPT], env=env, capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[form] = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for shape, (emax, erms) in res["split"].items():
+        fmax, frms = res["f32"][shape]
+        assert emax <= 1.5 * fmax + 1e-9 and erms <= 1.5 * frms + 1e-10, (shape, emax, fmax, erms, frms)
+        assert emax <= 2e-6, (shape, emax)

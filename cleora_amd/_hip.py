@@ -80,6 +80,9 @@ SIGNATURES = {
     "cleora_gram_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_centered_gram_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, vp, vp]),
     "cleora_project_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp]),
+    "cleora_project_general_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp, vp, c_u64, c_f32, c_f32, c_int,
+                                           ctypes.POINTER(c_int), vp]),
+    "cleora_csr_rowsum_dev": (c_int, [vp, c_int, vp, vp]),
     "cleora_mean_dev": (c_int, [vp, c_u64, c_u32, vp, vp, vp]),
     "cleora_eigh_workspace": (c_u64, [c_u32]),
     "cleora_whiten_transform_dev": (c_int, [vp, c_u64, c_u32, c_u32, vp, vp, vp, vp]),

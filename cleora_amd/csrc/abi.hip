@@ -467,6 +467,25 @@ int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, 
     return launch_whiten_transform(gram_dev, n, d, k, transform_dev, eigenvalues_dev, workspace, S(stream));
 }
 
+int cleora_project_general_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean_f32_dev,
+                               const float *transform_dev, uint32_t k, float *out, uint64_t ldo,
+                               const float *rowscale_dev, const float *x2, uint64_t ldx2, float alpha, float beta,
+                               int norm, int *norm_done, void *stream) {
+    CL_REQUIRE(norm >= 0 && norm <= 2, "norm must be 0, 1 or 2");
+    bool done = false;
+    const int rc = launch_project(x, ldx, n, d, mean_f32_dev, transform_dev, k, out, ldo, S(stream), rowscale_dev, x2, ldx2, alpha,
+                                  beta, norm, &done);
+    if (norm_done) *norm_done = done ? 1 : 0;
+    return rc;
+}
+
+int cleora_csr_rowsum_dev(const cleora_graph *g, int markov_type, float *rowsum_dev, void *stream) {
+    CL_REQUIRE(g != nullptr && rowsum_dev != nullptr, "graph / rowsum is NULL");
+    CL_REQUIRE(markov_type == CLEORA_LEFT || markov_type == CLEORA_SYMMETRIC, "unknown markov_type");
+    CL_REQUIRE(g->val[markov_type] != nullptr, "graph has no values for this markov_type");
+    return launch_csr_rowsum(g, markov_type, rowsum_dev, S(stream));
+}
+
 int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, int intermediate,
                             double *mean64_dev, double *gram_dev, void *stream) {
     CL_REQUIRE(mean64_dev != nullptr && gram_dev != nullptr, "mean / gram is NULL");

@@ -705,10 +705,12 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
                 if (hot) {
                     SpmmArgs h = a;
                     h.col = hot;
-                    // whole-wave rows: hand-counted waits behind the per-edge policy branch (CLEORA_SPMM_WAITS=compiler
-                    // keeps the compiler's single vmcnt(0) per 8-edge group for A/B runs)
+                    // whole-wave rows: CLEORA_SPMM_WAITS=counted takes the variant with hand-counted waits behind the per-edge
+                    // policy branch.  Measured round 3 at C3 (profiles/r03_spmm_waits.json): 32.55 ms against 32.36 ms for the
+                    // compiler's single vmcnt(0) per 8-edge group — no gain (8 waves per SIMD hide the difference), so the
+                    // default stays the compiler's.
                     if constexpr (kG == 64 && kFull && kV <= 4) {
-                        static const bool counted = !(std::getenv("CLEORA_SPMM_WAITS") && !std::strcmp(std::getenv("CLEORA_SPMM_WAITS"), "compiler"));
+                        static const bool counted = std::getenv("CLEORA_SPMM_WAITS") && !std::strcmp(std::getenv("CLEORA_SPMM_WAITS"), "counted");
                         if (counted) {
                             hipLaunchKernelGGL((spmm_rows_kernel<kG, kV, kW, kFull, true, true>),
                                                grid_for(h.n_items, 256 / kG), dim3(256), 0, stream, h);

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
     double s = 0.0;
     for (uint32_t sl = 0; sl < slices; ++sl)
         s += partial[((uint64_t)sl * pairs + p) * (uint64_t)(GT * GT) + e];
-    if (delta) s -= n_rows * delta[gi] * delta[gj];
+    if (delta) s -= n_rows * (delta[gi] * delta[gj]);     // the product first: the same rounding for (i, j) and (j, i)
     gram[(uint64_t)gi * d + gj] = s;
     if (!diag || (r / 16) < (c / 16)) gram[(uint64_t)gj * d + gi] = s;
 }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__rest
     const uint32_t gi = tr * 32 + e / 32, gj = tc * 32 + e % 32;
     double s = 0.0;
     for (uint32_t sl = 0; sl < slices; ++sl) s += partial[((uint64_t)sl * G32_TILES + p) * 1024 + e];
-    s -= n_rows * delta[gi] * delta[gj];
+    s -= n_rows * (delta[gi] * delta[gj]);                  // the product first: the same rounding for (i, j) and (j, i)
     gram[(uint64_t)gi * G32_D + gj] = s;
     if (tr != tc) gram[(uint64_t)gj * G32_D + gi] = s;
 }

@@ -93,6 +93,36 @@ class HipBackend:
                                                transform.data_ptr(), transform.shape[1], out.data_ptr(),
                                                out.stride(0), self._stream()))
 
+    # pieces of the reorganised whitened loop (csrc/abi.hip embed_whitened_overlapped) on a row range
+    def rowsum(self, block, kind, out):
+        """out[r] = sum of the stored values of row r of the block: s = A 1."""
+        _hip.check(self.lib.cleora_csr_rowsum_dev(block.handle, kind, out.data_ptr(), self._stream()))
+
+    def whiten_transform_any(self, gram, n):
+        """(transform d x d, form): the Cholesky whitening when the reference's eigenvalue clamp is provably inactive
+        (form 1), else the PCA form (form 0).  Waits for the stream (cleora_whiten_transform_any_dev)."""
+        import ctypes
+        d = gram.shape[0]
+        ws = torch.empty(self.lib.cleora_eigh_workspace(d), dtype=torch.uint8, device=gram.device)
+        out = torch.empty((d, d), dtype=torch.float32, device=gram.device)
+        form = ctypes.c_int(0)
+        _hip.check(self.lib.cleora_whiten_transform_any_dev(gram.data_ptr(), n, d, out.data_ptr(), ws.data_ptr(),
+                                                            self._stream(), ctypes.byref(form)))
+        return out, form.value
+
+    def project_general(self, x, mean32, transform, out, rowscale=None, x2=None, alpha=1.0, beta=0.0, norm=0):
+        """out = normalise((alpha (x - rowscale mean) + beta (x2 - mean)) @ transform); returns whether the kernel
+        normalised the rows itself (else the caller runs rowops)."""
+        import ctypes
+        n, d = x.shape
+        done = ctypes.c_int(0)
+        _hip.check(self.lib.cleora_project_general_dev(
+            x.data_ptr(), x.stride(0), n, d, mean32.data_ptr(), transform.data_ptr(), transform.shape[1], out.data_ptr(),
+            out.stride(0), rowscale.data_ptr() if rowscale is not None else None,
+            x2.data_ptr() if x2 is not None else None, x2.stride(0) if x2 is not None else 0, alpha, beta, norm,
+            ctypes.byref(done), self._stream()))
+        return bool(done.value)
+
 
 def block_size(n, world, steps):
     """Rows per block of the equal-rows split: the padded row count is block * world * steps (block a
@@ -192,12 +222,9 @@ class ShardedGraph:
         b0, b1 = self.my_rows[k]
         return b0, max(0, min(b1, self.n) - b0)
 
-    def whiten(self, y, out, n_components=None):
-        """whiten_embeddings (pycleora/__init__.py:130-164) over the row partition: `y` holds this
-        rank's blocks of the matrix to whiten; `out` receives the whitened matrix, replicated.
-        Local f64 column sums and centred Gram -> all-reduce (d and d*d doubles) -> transform
-        (cleora_whiten_transform_dev, replicated; rank 0's copy is broadcast) -> row-local projection ->
-        in-place all-gather per block."""
+    def stats(self, y):
+        """(mean f64[d], centred Gram f64[d, d]) of the matrix whose row blocks `y` holds on every rank: local f64 column
+        sums and centred Gram (pycleora/__init__.py:136-143), all-reduced (d and d*d doubles)."""
         d = y.shape[1]
         cs = torch.zeros(d, dtype=torch.float64, device=y.device)
         for k in range(self.steps):
@@ -212,6 +239,26 @@ class ShardedGraph:
             if nv:
                 gram += self.backend.gram(y[r0:r0 + nv], mean)
         self.comm.allreduce(gram)
+        return mean, gram
+
+    def rowsums(self, kind, like):
+        """s = A 1 for this rank's row blocks (one f32 tensor per block, padding rows 0)."""
+        out = []
+        for k in range(self.steps):
+            b0, b1 = self.my_rows[k]
+            t = torch.zeros(b1 - b0, dtype=torch.float32, device=like.device)
+            self.backend.rowsum(self.blocks[k], kind, t)
+            out.append(t)
+        return out
+
+    def whiten(self, y, out, n_components=None):
+        """whiten_embeddings (pycleora/__init__.py:130-164) over the row partition: `y` holds this
+        rank's blocks of the matrix to whiten; `out` receives the whitened matrix, replicated.
+        Local f64 column sums and centred Gram -> all-reduce (d and d*d doubles) -> transform
+        (cleora_whiten_transform_dev, replicated; rank 0's copy is broadcast) -> row-local projection ->
+        in-place all-gather per block."""
+        d = y.shape[1]
+        mean, gram = self.stats(y)
         kdim = d if n_components is None else min(int(n_components), d)
         # every rank holds the same all-reduced Gram, so the (deterministic) eigensolver is replicated;
         # the transform is still broadcast from rank 0 so that the ranks cannot drift apart
@@ -233,18 +280,71 @@ class ShardedGraph:
         return float(t)
 
 
+def embed_whitened_sharded(sg, kind, x0, iterations, residual_weight=0.0):
+    """The default embed() loop (pycleora/__init__.py:109-117, L2 normalisation, no convergence test) over a ShardedGraph in
+    the reorganised form of the single-GPU library loop (csrc/abi.hip embed_whitened_overlapped):
+
+        Y_0 = normalise(A E_0 [+ blend]);   per iteration:  Z = A Y (row blocks, no epilogue) | statistics of Y
+        -> all-reduce (d + d*d doubles) -> replicated transform: Cholesky form while the reference's eigenvalue clamp is
+        provably inactive (any whitening leads to the same final result), else the PCA form
+        -> Y' = normalise((alpha (Z - s mu^T) + rw (Y - mu)) T) on the local rows, normalised in the projection's epilogue
+        -> in-place all-gather of Y' (block k's gather beside block k+1's projection);   E_T = PCA-whiten(Y_{T-1}).
+
+    One all-gather of the n x d iterate per iteration, as in the plain loop; the eigensolver only in the last iteration.
+    x0: (n_pad, d) replica.  Returns the replica of E_T."""
+    if iterations <= 0:
+        return x0
+    n, rw = sg.n, float(residual_weight)
+    blend = rw > 0.0
+    y = torch.zeros_like(x0)
+    y_next = torch.zeros_like(x0)
+    z = torch.zeros_like(x0)                       # only this rank's row blocks are ever written
+    s = sg.rowsums(kind, x0)
+    sg.propagate(kind, x0, y, _hip.F_L2NORM | _hip.F_RESIDUAL | _hip.F_BLEND_ANY, rw)            # Y_0, replicated
+    for _ in range(iterations - 1):
+        sg.propagate(kind, y, z, 0, 0.0, gather=False)
+        mean, gram = sg.stats(y)
+        transform, _ = sg.backend.whiten_transform_any(gram, n) if n > 1 else (None, 0)
+        if transform is not None:
+            sg.comm.broadcast(transform, 0)        # identical on every rank already; keeps the ranks from drifting apart
+        mean32 = mean.to(torch.float32)
+        for k in range(sg.steps):
+            r0, nv = sg._valid_rows(k)
+            if nv and transform is not None:
+                rows = slice(r0, r0 + nv)
+                done = sg.backend.project_general(z[rows], mean32, transform, y_next[rows], rowscale=s[k][:nv],
+                                                  x2=y[rows] if blend else None, alpha=1.0 - rw, beta=rw, norm=1)
+                if not done:
+                    sg.backend.rowops(y_next[rows], y_next[rows], _hip.F_L2NORM)
+            elif nv:                               # one entity: whiten_embeddings returns its input (:132-133)
+                rows = slice(r0, r0 + nv)
+                sg.backend.rowops(z[rows], y_next[rows], _hip.F_L2NORM | _hip.F_RESIDUAL | _hip.F_BLEND_ANY, rw, y[rows])
+            if sg.world > 1:
+                sg.comm.allgather_rows(y_next, sg.step_bounds(k))
+        sg.comm.join()
+        y, y_next = y_next, y
+    out = y_next
+    sg.whiten(y, out)
+    return out
+
+
 def embed_sharded(sg, kind, x0, iterations, residual_weight=0.0, convergence_threshold=0.0,
                   flags=_hip.F_L2NORM, whiten=False):
     """embed_full / embed_full_with_convergence (src/embedding.rs:106-188) over a ShardedGraph;
     with whiten=True the default embed() loop of pycleora/__init__.py:109-125 (normalise, then
-    whiten, every iteration; no convergence test in that mode here).
+    whiten, every iteration; no convergence test in that mode here) — in the reorganised form
+    (embed_whitened_sharded) for the L2 normalisation, in the reference's order (whiten="sequential", or any other
+    normalisation: the Cholesky intermediate whitening needs the rotation invariance of the L2 norm).
     x0: (n_pad, d) replica (rows >= n zero).  Returns (x, iterations_run)."""
     x = x0
     x_next = torch.zeros_like(x0)
     if whiten:
+        if whiten != "sequential" and flags == _hip.F_L2NORM:
+            return embed_whitened_sharded(sg, kind, x0, iterations, residual_weight), iterations
         y = torch.zeros_like(x0)
         for _ in range(iterations):
-            sg.propagate(kind, x, y, flags | _hip.F_RESIDUAL, residual_weight, gather=False)
+            # the Python loop blends for ANY rw > 0 (pycleora/__init__.py:111-115)
+            sg.propagate(kind, x, y, flags | _hip.F_RESIDUAL | _hip.F_BLEND_ANY, residual_weight, gather=False)
             sg.whiten(y, x_next)
             x, x_next = x_next, x
         return x, iterations
@@ -315,6 +415,9 @@ class ColumnShardedGraph:
 
     def propagate(self, kind, x, x_next, rowsq, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None):
         """x, x_next: (n, d/P) column slices; rowsq: f32[n] scratch.  One iteration."""
+        if (flags & _hip.F_L1NORM) and self.world > 1:
+            # each rank would divide its slice by its PARTIAL sum of |.|: wrong.  (The L2 norm has the ROWSQ / SCALE pair.)
+            raise ValueError("the column partition supports the L2 normalisation only: use the row partition for 'l1'")
         norm = flags & _hip.F_L2NORM
         if self.world == 1:   # nothing to reduce: the fused single-pass epilogue
             for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
@@ -336,8 +439,10 @@ class ColumnShardedGraph:
                                     row_sqdiff[r0:r1] if row_sqdiff is not None else None,
                                     rowsq[r0:r1] if norm else None)
 
-    def whiten(self, y_local, out_local):
+    def whiten(self, y_local, out_local, any_whitening=False):
         """whiten_embeddings (pycleora/__init__.py:130-164) for a column-partitioned matrix.
+        any_whitening: an intermediate iteration of the L2-normalised loop — the Cholesky transform where the reference's
+        eigenvalue clamp is provably inactive (cleora_whiten_transform_any_dev), the eigensolver only otherwise.
         The Gram matrix couples every pair of columns, so the step runs in a ROW layout:
         all-to-all (each rank receives all d columns of its n/P rows: (P-1)/P^2 of the matrix
         per rank, 8x less than an all-gather at P = 8) -> row-local f64 column sums / centred Gram,
@@ -358,7 +463,7 @@ class ColumnShardedGraph:
         self.comm.allreduce(gram)
         # every rank holds the same all-reduced Gram: eigh is replicated (deterministic routine),
         # but the transform is still broadcast from rank 0 so the ranks cannot drift apart
-        transform = self.backend.whiten_transform(gram, self.n, d)
+        transform = self.backend.whiten_transform_any(gram, self.n)[0] if any_whitening else self.backend.whiten_transform(gram, self.n, d)
         self.comm.broadcast(transform, 0)
         proj = torch.zeros((rp, d), dtype=torch.float32, device=rows.device)
         if nv:
@@ -404,9 +509,11 @@ def embed_column_sharded(cg, kind, x0_local, iterations, residual_weight=0.0,
         if x0_local.shape[0] < cg.n_pad:
             raise ValueError(f"whiten=True needs {cg.n_pad} (padded) rows, got {x0_local.shape[0]}")
         y = torch.zeros_like(x0_local)
-        for _ in range(iterations):
-            cg.propagate(kind, x[: cg.n], y[: cg.n], rowsq, flags | _hip.F_RESIDUAL, residual_weight)
-            cg.whiten(y, x_next)
+        for it in range(iterations):
+            # the Python loop blends for ANY rw > 0 (pycleora/__init__.py:111-115); intermediate iterations of the
+            # L2-normalised loop may take any whitening (Cholesky), the last one the reference's PCA form
+            cg.propagate(kind, x[: cg.n], y[: cg.n], rowsq, flags | _hip.F_RESIDUAL | _hip.F_BLEND_ANY, residual_weight)
+            cg.whiten(y, x_next, any_whitening=(flags == _hip.F_L2NORM and it + 1 < iterations and whiten != "sequential"))
             x, x_next = x_next, x
         return x, iterations
     check = convergence_threshold > 0

@@ -219,6 +219,22 @@ int cleora_project_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                        const float *mean_f32_dev, const float *transform_dev, uint32_t k,
                        float *out, uint64_t ldo, void *stream);
 
+/* The projection of the REORGANISED whitened loop (csrc/abi.hip embed_whitened_overlapped; the SpMM is linear, so it is
+ * taken before the projection: A ((Y - 1 mu^T) T) = (A Y - s mu^T) T with s = A 1):
+ *     out[r,:] = normalise( (alpha * (x[r,:] - rowscale[r] * mean) + beta * (x2[r,:] - mean)) @ transform )
+ * rowscale_dev == NULL: scale 1; x2 == NULL: no second term (alpha is then 1) — the plain cleora_project_dev.
+ * norm: 0 none, 1 L2-normalise (src/embedding.rs:98-102), 2 L1-normalise (pycleora/__init__.py:947-950) every output row in
+ * the kernel's epilogue when the shape allows it (k <= 256); *norm_done (host, may be NULL) reports whether it was — if not,
+ * the caller runs cleora_rowops_dev on `out`. */
+int cleora_project_general_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean_f32_dev,
+                               const float *transform_dev, uint32_t k, float *out, uint64_t ldo,
+                               const float *rowscale_dev, const float *x2, uint64_t ldx2, float alpha, float beta,
+                               int norm, int *norm_done, void *stream);
+
+/* rowsum[r] = sum of the stored values of row r (f32, stored order): s = A 1 of the identity above; 1 for every row of a
+ * row-stochastic left Markov matrix up to rounding, anything for symmetric values or trimmed hyperedges. */
+int cleora_csr_rowsum_dev(const cleora_graph *g, int markov_type, float *rowsum_dev, void *stream);
+
 /* mean64[c] = colsum[c] / n (f64, :136) and mean32[c] = (float)mean64[c] (:159), on the device. */
 int cleora_mean_dev(const double *colsum_dev, uint64_t n, uint32_t d, double *mean64_dev,
                     float *mean32_dev, void *stream);

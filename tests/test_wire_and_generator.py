@@ -234,3 +234,31 @@ def test_reference_cli_info_runs_over_install(tmp_path, golden_dir):
         for m, v in saved.items():
             if v is not None:
                 sys.modules[m] = v
+
+
+def test_bench_c5_text_is_what_the_reference_builder_would_read():
+    """bench.py --config C5 assembles its `complex::reflexive::product` lines as one numpy byte buffer (5M lines without
+    40M Python strings) and hands it to cleora_host_build_from_lines.  On a 3 000-line sample: the buffer decodes to
+    well-formed lines (2..14 tokens `pNNNNNNN`), and the graph the C++ builder makes of the BUFFER equals, bit for bit, the
+    graph the pure-Python restatement of the reference's builder (oracle/refgraph.py: src/pipeline.rs:223-240,
+    src/sparse_matrix_builder.rs:170-343) makes of the decoded LINES."""
+    import ctypes
+    import bench
+    from cleora_amd import _host
+    from oracle import refgraph
+    n_lines, products = 3000, 900
+    data, offsets, tokens = bench.hypergraph_lines(n_lines, products, 5)
+    off = offsets.astype(np.int64)
+    lines = [data[off[i]:off[i + 1]].decode("ascii") for i in range(n_lines)]
+    ar = [len(l.split()) for l in lines]
+    assert sum(ar) == tokens and min(ar) >= 2 and max(ar) <= 14
+    assert all(len(t) == 8 and t[0] == "p" and t[1:].isdigit() and int(t[1:]) < products for l in lines[:200] for t in l.split())
+    h = _host.vp()
+    assert _host.lib().cleora_host_build_from_lines(data, offsets.ctypes.data_as(_host.vp), n_lines, b"complex::reflexive::product", 16,
+                                                    ctypes.byref(h)) == 0
+    hg = _host.HostGraph(h)
+    g = refgraph.build_graph([l.strip() for l in lines], "complex::reflexive::product", 16)
+    a = hg.arrays()
+    assert hg.entity_ids() == list(g.entity_ids)
+    for key, want in (("hashes", g.entity_hashes), ("rowptr", g.rowptr), ("col", g.col), ("val_left", g.val_left), ("val_sym", g.val_sym)):
+        np.testing.assert_array_equal(a[key], want)

@@ -14,6 +14,7 @@
 // Both are MFMA-bound (2 n d^2 flops against 1-3 passes over X), unlike the SpMM.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -903,7 +904,12 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
     tp[idx] = (u32x4){w[0], w[1], w[2], w[3]};
 }
 
-template <bool SCALED, bool BLEND, int RING>
+// DBG (profiling builds of the plain instantiation only, CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = every row tile reads
+// the rows of tile 0 (A comes from cache, not HBM), 4 = no global loads for the B stage (zeros are staged instead).
+// U = k-steps per trip of the flat loop (a divisor of ksteps, a multiple of RING): the compiler copies the live part of the
+// operand ring at the loop's back edge — behind a vmcnt(0) that drains the prefetch — so the back edge is taken as rarely
+// as the shape allows (once per row tile at d = 256).
+template <bool SCALED, bool BLEND, int RING, int U, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
                                                                uint32_t ksteps, uint64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -915,7 +921,7 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
     const uint32_t pass = blockIdx.y;
     const u32x4 *const tpp = tp + (uint64_t)pass * ksteps * SKB;
     const uint64_t my_tiles = tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    const uint64_t total = my_tiles * ksteps;                                    // a multiple of RING (ksteps is)
+    const uint64_t total = my_tiles * ksteps;                                    // a multiple of U (ksteps is)
     if (total == 0) return;
 
     for (uint32_t c = t; c < 16 * ksteps; c += 256) mean_s[c] = c < a.d ? a.mean[c] : 0.f;
@@ -930,7 +936,7 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
     uint64_t ltile = blockIdx.x;          // row tile / k-step of the NEXT load
     uint32_t lks = 0;
     auto row_of = [&](uint64_t tile) {
-        const uint64_t r = tile * SR + (uint64_t)(wr * 32 + i);
+        const uint64_t r = ((DBG & 2) ? 0 : tile * SR) + (uint64_t)(wr * 32 + i);
         return r < a.n ? r : a.n - 1;                                            // clamped: always a valid address
     };
     auto issue_a = [&](int slot) {
@@ -946,8 +952,30 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
         if constexpr (SCALED) rs[slot] = a.rowscale[r];
         if (++lks == ksteps) { lks = 0; ltile += gridDim.x; }
     };
+    // centre (block = embeddings - mean_f32, pycleora/__init__.py:161), blend, split: slot -> three bf16x8 fragments
+    auto split_a = [&](int slot, uint32_t ks, u32x4 (&as)[3]) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 4 * h);
+        const float4 m1 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 8 + 4 * h);
+        const float xv[8] = {ra[slot][0].x, ra[slot][0].y, ra[slot][0].z, ra[slot][0].w, ra[slot][1].x, ra[slot][1].y, ra[slot][1].z, ra[slot][1].w};
+        const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        float o[8];
 #pragma unroll
-    for (int slot = 0; slot + 1 < RING; ++slot) issue_a(slot);                   // k-steps 0 .. RING-2; step g issues g + RING - 1
+        for (int e = 0; e < 8; ++e) o[e] = centre(xv[e], mu[e], SCALED ? rs[slot] : 1.f, SCALED);
+        if constexpr (BLEND) {
+            const int sb = BLEND ? slot : 0;
+            const float x2v[8] = {rb[sb][0].x, rb[sb][0].y, rb[sb][0].z, rb[sb][0].w, rb[sb][1].x, rb[sb][1].y, rb[sb][1].z, rb[sb][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __fadd_rn(__fmul_rn(a.alpha, o[e]), __fmul_rn(a.beta, __fsub_rn(x2v[e], mu[e])));
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            uint32_t p1, p2, p3;
+            split3_pair(o[2 * m], o[2 * m + 1], p1, p2, p3);
+            as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
+        }
+    };
+#pragma unroll
+    for (int slot = 0; slot < RING; ++slot) issue_a(slot);                       // k-steps 0 .. RING-1
 
     f16v acc[4];
 #pragma unroll
@@ -956,43 +984,26 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
         for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
 
     __syncthreads();
+    u32x4 as_cur[3];
+    split_a(0, 0, as_cur);                                                       // the fragments of k-step 0
     uint64_t tile = blockIdx.x;
     uint32_t ks0 = 0;
-    for (uint64_t g0 = 0; g0 < total; g0 += RING) {
+    for (uint64_t g0 = 0; g0 < total; g0 += U) {
 #pragma unroll
-        for (int rr = 0; rr < RING; ++rr) {
-            const uint32_t ks = ks0 + rr;
-            const int buf = rr & 1;                                              // RING is even
+        for (int uu = 0; uu < U; ++uu) {
+            constexpr int kRing = RING;
+            const int rr = uu % kRing;                                           // the ring slot of this k-step
+            const uint32_t ks = ks0 + uu;
+            const int buf = uu & 1;                                              // U is even
             // B of the next k-step: six coalesced 16-byte loads per thread, written to the other buffer at the end
             const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
             u32x4 bst[6];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) bst[u] = tpp[(uint64_t)ksn * SKB + t + 256 * u];
-            // A of k-step g + RING - 1 into the slot the PREVIOUS step consumed, right behind the B loads: the wait for B at
-            // the end of this step leaves exactly these loads in flight (vmcnt retires in order), the one at the end of the
-            // next step completes them — two steps of latency cover, consumed in the step after
-            issue_a((rr + RING - 1) % RING);
-
-            // A: centre (block = embeddings - mean_f32, pycleora/__init__.py:161), blend, split
-            const float4 m0 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 4 * h);
-            const float4 m1 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 8 + 4 * h);
-            const float xv[8] = {ra[rr][0].x, ra[rr][0].y, ra[rr][0].z, ra[rr][0].w, ra[rr][1].x, ra[rr][1].y, ra[rr][1].z, ra[rr][1].w};
-            const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-            float o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = centre(xv[e], mu[e], SCALED ? rs[rr] : 1.f, SCALED);
-            if constexpr (BLEND) {
-                const float x2v[8] = {rb[rr][0].x, rb[rr][0].y, rb[rr][0].z, rb[rr][0].w, rb[rr][1].x, rb[rr][1].y, rb[rr][1].z, rb[rr][1].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = __fadd_rn(__fmul_rn(a.alpha, o[e]), __fmul_rn(a.beta, __fsub_rn(x2v[e], mu[e])));
-            }
-            u32x4 as[3];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                uint32_t p1, p2, p3;
-                split3_pair(o[2 * m], o[2 * m + 1], p1, p2, p3);
-                as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
-            }
+            for (int u = 0; u < 6; ++u) bst[u] = (DBG & 4) ? (u32x4){0u, 0u, 0u, 0u} : tpp[(uint64_t)ksn * SKB + t + 256 * u];
+            // A of k-step g + RING into the slot whose fragments were made during the PREVIOUS step, right behind the B loads:
+            // the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in order), the one at
+            // the end of the next step completes them; they are split two steps after that
+            issue_a(rr);
 
             // B fragments of this wave's four tiles, all three splits
             u32x4 bf[3][4];
@@ -1001,12 +1012,17 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) bf[sp][jj] = bs[buf * SKB + (sp * 8 + wc * 4 + jj) * 64 + lane];
             constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+            u32x4 as_next[3];
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < 6; ++q) {
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
-                    acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as[PA[q]]),
+                    acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as_cur[PA[q]]),
                                                                       __builtin_bit_cast(bf16x8, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
+                // the fragments of the NEXT k-step are made here, under this step's MFMAs (the matrix pipe runs them for
+                // 32 cycles each; the ~50 VALU instructions of centre + split issue in their shadow)
+                if (q == 0) split_a((rr + 1) % RING, ksn, as_next);
+            }
 
             // B of the next k-step into the other buffer (nobody reads it during this step).  Before the tile epilogue, not
             // after: behind that branch the compiler cannot count the epilogue's stores and drains everything (vmcnt(0)),
@@ -1014,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
 #pragma unroll
             for (int u = 0; u < 6; ++u) bs[(buf ^ 1) * SKB + t + 256 * u] = bst[u];
 
-            if (rr == RING - 1 && ks0 + RING == ksteps) {
+            if (uu == U - 1 && ks0 + U == ksteps) {
                 // ---- end of a row tile: normalise (whole rows live in this block when there is one pass), store --------
                 if (a.norm) {
                     float pr[16];
@@ -1052,14 +1068,17 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
                         // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
                         const uint64_t row = tile * SR + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
                         const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
-                        if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[jj][reg];
+                        if (row < a.n && col < a.k && (!(DBG & 1) || acc[jj][reg] == 12345.678f)) a.out[row * a.ldo + col] = acc[jj][reg];
                         acc[jj][reg] = 0.f;
                     }
                 tile += gridDim.x;
             }
+            as_cur[0] = as_next[0];
+            as_cur[1] = as_next[1];
+            as_cur[2] = as_next[2];
             __syncthreads();
         }
-        ks0 = ks0 + RING == ksteps ? 0 : ks0 + RING;
+        ks0 = ks0 + U == ksteps ? 0 : ks0 + U;
     }
 }
 
@@ -1217,14 +1236,31 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         if (norm_done) *norm_done = a.norm != 0;
         const dim3 grid(gx, passes);
         const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
-#define CLEORA_SPLIT_LAUNCH(SC, BL, RG) \
-        hipLaunchKernelGGL((project_split_kernel<SC, BL, RG>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles)
-        if (d % 64 == 0 && !blend) {
-            if (scaled) CLEORA_SPLIT_LAUNCH(true, false, 4); else CLEORA_SPLIT_LAUNCH(false, false, 4);
+        auto launch_shape = [&](auto SCt, auto BLt) {
+            constexpr bool SC = decltype(SCt)::value, BL = decltype(BLt)::value;
+#define CLEORA_SPLIT_LAUNCH(RG, UU) \
+            hipLaunchKernelGGL((project_split_kernel<SC, BL, RG, UU>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles)
+            if constexpr (!BL) {                  // ring of 4 k-steps (the blended operand doubles the ring: 2 there)
+                if (ksteps % 16 == 0) { CLEORA_SPLIT_LAUNCH(4, 16); return; }
+                if (ksteps % 8 == 0) { CLEORA_SPLIT_LAUNCH(4, 8); return; }
+                if (ksteps % 4 == 0) { CLEORA_SPLIT_LAUNCH(4, 4); return; }
+            }
+            if (ksteps % 8 == 0) CLEORA_SPLIT_LAUNCH(2, 8);
+            else CLEORA_SPLIT_LAUNCH(2, 2);
+#undef CLEORA_SPLIT_LAUNCH
+        };
+        if (ksteps % 16 == 0 && !blend && !scaled && dbg) {                  // profiling builds (see the kernel)
+            switch (dbg) {
+                case 1: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 1>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 2: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 3: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 3>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 4: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 4>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                default: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 7>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+            }
         } else if (blend) {
-            if (scaled) CLEORA_SPLIT_LAUNCH(true, true, 2); else CLEORA_SPLIT_LAUNCH(false, true, 2);
+            if (scaled) launch_shape(std::true_type{}, std::true_type{}); else launch_shape(std::false_type{}, std::true_type{});
         } else {
-            if (scaled) CLEORA_SPLIT_LAUNCH(true, false, 2); else CLEORA_SPLIT_LAUNCH(false, false, 2);
+            if (scaled) launch_shape(std::true_type{}, std::false_type{}); else launch_shape(std::false_type{}, std::false_type{});
         }
 #undef CLEORA_SPLIT_LAUNCH
         const hipError_t le = hipGetLastError();

@@ -113,10 +113,28 @@ def loop(nodes, pairs, d):
     print(json.dumps(res), flush=True)
 
 
+def project_only(n, d):
+    """The projection alone (profiling: CLEORA_PROJECT_DEBUG variants, rocprofv3 --pmc passes)."""
+    dev = torch.device("cuda:0")
+    L = _hip.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    x = torch.randn((n, d), device=dev)
+    x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+    mean = x.mean(0).contiguous()
+    t = (torch.randn((d, d), device=dev) * d ** 0.5).contiguous()
+    out = torch.empty_like(x)
+    ms = timed(lambda: _hip.check(L.cleora_project_dev(x.data_ptr(), d, n, d, mean.data_ptr(), t.data_ptr(), d, out.data_ptr(), d, s)),
+               reps=4, warm=1)
+    print(json.dumps({"mode": "project", "n": n, "d": d, "env": ENV, "debug": os.environ.get("CLEORA_PROJECT_DEBUG"), "project_ms": ms,
+                      "f32_equiv_tflops": 2.0 * n * d * d / (ms * 1e-3) / 1e12}), flush=True)
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(v) for v in sys.argv[2:]]
-    if mode == "kernels":
+    if mode == "project":
+        project_only(*(args + [10_000_000, 256][len(args):]))
+    elif mode == "kernels":
         kernels(*(args + [10_000_000, 256][len(args):]))
     else:
         loop(*(args + [10_000_000, 95_000_000, 256][len(args):]))

@@ -52,6 +52,7 @@ SIGNATURES = {
     "cleora_comm_destroy": (c_int, [vp]),
     "cleora_comm_info": (c_int, [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "cleora_comm_set_allgather": (c_int, [vp, c_int]),
+    "cleora_comm_get_allgather": (c_int, [vp, ctypes.POINTER(c_int)]),
     "cleora_allgatherv_f32_dev": (c_int, [vp, vp, vp, vp]),
     "cleora_allgather_f32_dev": (c_int, [vp, vp, c_u64, vp]),
     "cleora_allreduce_f32_dev": (c_int, [vp, vp, c_u64, vp]),

@@ -201,6 +201,12 @@ int cleora_comm_set_allgather(cleora_comm *c, int algo) {
     return CLEORA_OK;
 }
 
+int cleora_comm_get_allgather(const cleora_comm *c, int *algo) {
+    CL_REQUIRE(c != nullptr && algo != nullptr, "comm / algo is NULL");
+    *algo = c->allgather_algo;
+    return CLEORA_OK;
+}
+
 int cleora_allgatherv_f32_dev(cleora_comm *c, float *buf, const uint64_t *offsets, void *stream) {
     CL_REQUIRE(c != nullptr, "comm is NULL");
     CL_REQUIRE(buf != nullptr && offsets != nullptr, "buf / offsets is NULL");

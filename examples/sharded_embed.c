@@ -153,8 +153,11 @@ int main(int argc, char **argv) {
     } else {
         cleora_stream_sync(compute);
     }
-    fprintf(stderr, "sharded_embed: rank %d of %d: %llu entities, %llu iterations\n", rank, world, (unsigned long long)n,
-            (unsigned long long)iterations);
+    int algo = -1;
+    cleora_comm_get_allgather(comm, &algo);
+    fprintf(stderr, "sharded_embed: rank %d of %d: %llu entities, %llu iterations, all-gather: %s\n", rank, world, (unsigned long long)n,
+            (unsigned long long)iterations,
+            world == 1 ? "none (one rank)" : algo == CLEORA_ALLGATHER_P2P ? "send/recv mesh (CLEORA_ALLGATHER=p2p)" : "ncclAllGather (ring)");
     for (int k = 0; k < STEPS; ++k) cleora_graph_destroy(blocks[k]);
     cleora_comm_destroy(comm);
     cleora_stream_destroy(compute);

@@ -313,6 +313,7 @@ int cleora_comm_create(const void *id, int rank, int world, int device, cleora_c
 int cleora_comm_destroy(cleora_comm *c);
 int cleora_comm_info(const cleora_comm *c, int *rank, int *world, int *device);
 int cleora_comm_set_allgather(cleora_comm *c, int algo);   /* default RING; env CLEORA_ALLGATHER=p2p selects P2P */
+int cleora_comm_get_allgather(const cleora_comm *c, int *algo);   /* which of the two cleora_allgatherv_f32_dev will take */
 
 /* The exchange step of the row partition: buf holds offsets[world] floats (e.g. a row range of the next iterate,
  * contiguous, ld = d); rank r has just written elements [offsets[r], offsets[r+1]) and every rank ends up with all

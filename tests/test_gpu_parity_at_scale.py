@@ -135,3 +135,50 @@ def test_forty_iteration_drift_of_the_plain_loop_at_c2_size(c2):
     assert same[~hub].all()
     assert np.isfinite(got).all()
     assert drift <= 5e-5, drift
+
+
+def test_config5_hypergraph_d1024_whitened_loop_against_the_oracle_loop():
+    """BASELINE config 5's flavour at a size the oracle finishes in seconds: `complex::reflexive::product` hyperedges (the bench's
+    generator: arity 2..14, Zipf-like products) through the C++ host builder, d = 1024 — the shapes this path takes there and
+    nowhere else: spmm_rows_kernel<64,4,4>, the split projection in four column passes, the f64 Gram in 8 x 8 block tiles,
+    rocSOLVER's Cholesky / eigensolver at d = 1024 — three iterations of the default loop against oracle.whiten.embed_slow.
+    Stated: pairwise cosines of 1 500 rows to 1e-4, row norms to 1e-4 relative, covariance of the result within 2e-3 of I."""
+    import bench
+    from cleora_amd import _host
+    n_lines, products, d, iters = 250_000, 80_000, 1024, 3
+    data, offsets, _ = bench.hypergraph_lines(n_lines, products, 5)
+    h = _host.vp()
+    assert _host.lib().cleora_host_build_from_lines(data, offsets.ctypes.data_as(_host.vp), n_lines, b"complex::reflexive::product", 16,
+                                                    ctypes.byref(h)) == 0
+    hg = _host.HostGraph(h)
+    a = hg.arrays()
+    n = a["rowptr"].shape[0] - 1
+    assert n > 4 * d                                     # full-rank covariance
+    g = _hip.Graph.from_host(a["rowptr"], a["col"], a["val_left"], a["val_sym"])
+    L = _hip.lib()
+    x0 = oracle.init(a["hashes"], d, 0)
+    dx = _hip.DevArray.from_host(x0)
+    _hip.check(L.cleora_embed_dev(g.handle, dx.ptr, _hip.LEFT, d, iters, 0.0, 0.0, _hip.F_WHITEN, None))
+    got = dx.to_host()
+    threads = oracle.max_threads()
+    want, _ = ow.embed_slow(lambda v: oracle.spmm(a["rowptr"], a["col"], a["val_left"], v, threads), x0, iters, whiten=True)
+    rows = np.random.default_rng(2).choice(n, 1500, replace=False)
+
+    def cosines(e):
+        s = e[rows].astype(np.float64)
+        s /= np.linalg.norm(s, axis=1, keepdims=True)
+        return s @ s.T
+
+    cos_err = float(np.abs(cosines(got) - cosines(want)).max())
+    ng, nw = np.linalg.norm(got.astype(np.float64), axis=1), np.linalg.norm(want.astype(np.float64), axis=1)
+    norm_err = float((np.abs(ng - nw) / nw).max())
+    cov_err = float(np.abs(np.cov(got.astype(np.float64).T) - np.eye(d)).max())
+    _record("whitened_loop_c5_flavour", {"n": int(n), "nnz": int(a["col"].shape[0]), "d": d, "iterations": iters,
+                                         "longest_row": int(np.diff(a["rowptr"].astype(np.int64)).max()),
+                                         "max_abs_cosine_diff_1500_rows": cos_err, "max_rel_row_norm_diff": norm_err,
+                                         "max_abs_cov_minus_identity_gpu": cov_err})
+    g.close()
+    assert np.isfinite(got).all()
+    assert cos_err <= 1e-4, cos_err
+    assert norm_err <= 1e-4, norm_err
+    assert cov_err <= 2e-3, cov_err

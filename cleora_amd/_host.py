@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcleora_host.so")
+# CLEORA_HOST_LIB: another build of the same library (the sanitizer build of tests/test_host_sanitizers.py)
+LIB_PATH = os.environ.get("CLEORA_HOST_LIB") or os.path.join(_HERE, "libcleora_host.so")
 
 vp, c_u64, c_u32, c_int = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
 u8p = ctypes.POINTER(ctypes.c_uint8)

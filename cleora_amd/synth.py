@@ -114,7 +114,8 @@ def bipartite_graph(n_users, n_items, n_pairs, seed, device):
 def entity_hashes(n, seed, device):
     """Stand-in for XXH64(entity id): n distinct-ish 64-bit values (splitmix64 of the index) so
     that initialize_deterministically has realistic inputs without 10M strings."""
-    x = torch.arange(n, device=device, dtype=torch.int64) + (seed + 1) * -7046029254386353131
+    off = ((seed + 1) * -7046029254386353131 + (1 << 63)) % (1 << 64) - (1 << 63)     # wraps like the int64 arithmetic below
+    x = torch.arange(n, device=device, dtype=torch.int64) + off
     x = (x ^ (x >> 30)) * -4658895280553007687
     x = (x ^ (x >> 27)) * -7723592293110705685
     return x ^ (x >> 31)

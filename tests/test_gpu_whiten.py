@@ -274,7 +274,8 @@ def test_cholesky_guard_implies_the_reference_clamp(route, monkeypatch):
 def test_intermediate_gram_on_the_f32_matrix_cores():
     """cleora_whiten_stats_dev(intermediate = 1) at d = 256: centred Gram on v_mfma_f32_32x32x2_f32 (f32 sums over <= 2048
     rows, f64 across) against the f64 form (intermediate = 0) and numpy fp64.  Stated: the f64 form 1e-13 relative
-    Frobenius as before; the f32 form <= 5e-7 of the Gram's Frobenius norm and of its diagonal entry by entry; mean to 1e-9."""
+    Frobenius as before; the f32 form <= 5e-7 of the Gram's Frobenius norm and of its diagonal entry by entry.  Mean: 1e-12 for
+    the f64 form; the f32 form centres in f32 (y = x - c32, one rounding of 3e-8 |y|), so its mean carries that: <= 1e-8."""
     L = _hip.lib()
     n, d = 70_001, 256                                         # not a multiple of the 16-row chunk or of the slice count
     rng = np.random.default_rng(8)
@@ -290,7 +291,7 @@ def test_intermediate_gram_on_the_f32_matrix_cores():
         _hip.check(L.cleora_whiten_stats_dev(dx.ptr, d, n, d, ws.ptr, intermediate, dm.ptr, dg.ptr, None))
         _hip.check(L.cleora_stream_sync(None))
         gm, gg = dm.to_host(), dg.to_host()
-        assert np.abs(gm - mean).max() <= 1e-9
+        assert np.abs(gm - mean).max() <= (1e-8 if intermediate else 1e-12)
         assert np.linalg.norm(gg - gram) <= tol * np.linalg.norm(gram), (intermediate, np.linalg.norm(gg - gram) / np.linalg.norm(gram))
         assert np.abs(np.diag(gg) - np.diag(gram)).max() <= tol * np.diag(gram).max()
         np.testing.assert_array_equal(gg, gg.T)

@@ -1,0 +1,63 @@
+// project_common.h — shared by whiten.hip and project_fat.hip: the projection's argument block and the three-way bf16 split.
+#pragma once
+#include "common.h"
+
+namespace cleora {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+struct ProjArgs {
+    const float *x;
+    uint64_t ldx;
+    uint64_t n;
+    uint32_t d;
+    const float *mean;
+    const float *t;   // d x k row-major
+    uint32_t k;
+    float *out;
+    uint64_t ldo;
+    uint32_t nb_n;    // column blocks
+    uint64_t n_blocks;
+    int w4x, w4t;
+    // generalised centring (the propagate-before-project form of the embed loop, abi.hip): the operand row is
+    //   alpha * (x[r] - rowscale[r] * mean) + beta * (x2[r] - mean)
+    // rowscale == nullptr: scale 1; x2 == nullptr: no second term (alpha is then 1): the plain (x - mean).
+    const float *rowscale;
+    const float *x2;
+    uint64_t ldx2;
+    float alpha, beta;
+    int dbg;          // profiling only (CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = no X loads (LDS tile of ones)
+    int norm;         // rows-in-LDS form, k <= 256: 1 = L2-normalise, 2 = L1-normalise every output row in the epilogue
+};
+
+static __device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
+    return scaled ? __fsub_rn(v, __fmul_rn(s, mu)) : __fsub_rn(v, mu);
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SR = 64;                 // rows per block tile
+constexpr int SN = 256;                // output columns per pass
+constexpr int SKB = 3 * 8 * 64;        // 16-byte units of packed T per (pass, k-step): 24 KiB
+
+// (lo, hi) -> three packed bf16 pairs whose sum is (lo, hi) to 2^-27: v_cvt_pk_bf16_f32 (round to nearest even), the bf16
+// back as f32 by shift / mask, an exact f32 subtraction — twice.
+static __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
+    const f2v v = {lo, hi};
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f2v f1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    const f2v r1 = v - f1;
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    const f2v f2 = {__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
+    const f2v r2 = r1 - f2;
+    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+}
+
+constexpr int kFatRows = 128;          // rows per block tile of project_split_fat_kernel (project_fat.hip)
+// launches the 128-row form over every row tile and column pass; tp = the packed split transform (pack_transform_split_kernel)
+hipError_t launch_project_split_fat(const ProjArgs &a, const u32x4 *tp, uint32_t ksteps, uint32_t passes, int cus, hipStream_t stream);
+
+}  // namespace cleora

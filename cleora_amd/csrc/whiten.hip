@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "project_common.h"
 
 namespace cleora {
 namespace {
@@ -498,34 +499,6 @@ inline GramPlan gram_plan(uint64_t n, uint32_t d, int per_cu = 2) {
 constexpr int PM = 128, PN = 128, PK = 32;
 constexpr int PLA = PK + 1;  // A tile row stride (floats): odd -> conflict-free column reads
 
-struct ProjArgs {
-    const float *x;
-    uint64_t ldx;
-    uint64_t n;
-    uint32_t d;
-    const float *mean;
-    const float *t;   // d x k row-major
-    uint32_t k;
-    float *out;
-    uint64_t ldo;
-    uint32_t nb_n;    // column blocks
-    uint64_t n_blocks;
-    int w4x, w4t;
-    // generalised centring (the propagate-before-project form of the embed loop, abi.hip): the operand row is
-    //   alpha * (x[r] - rowscale[r] * mean) + beta * (x2[r] - mean)
-    // rowscale == nullptr: scale 1; x2 == nullptr: no second term (alpha is then 1): the plain (x - mean).
-    const float *rowscale;
-    const float *x2;
-    uint64_t ldx2;
-    float alpha, beta;
-    int dbg;          // profiling only (CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = no X loads (LDS tile of ones)
-    int norm;         // rows-in-LDS form, k <= 256: 1 = L2-normalise, 2 = L1-normalise every output row in the epilogue
-};
-
-__device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
-    return scaled ? __fsub_rn(v, __fmul_rn(s, mu)) : __fsub_rn(v, mu);
-}
-
 __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     __shared__ __attribute__((aligned(16))) float As[PM][PLA];
     __shared__ __attribute__((aligned(16))) float Bs[PK][PN];
@@ -856,28 +829,6 @@ __global__ __launch_bounds__(256) void pack_transform_kernel(const float *__rest
 //   * per k-step and wave: 12 B fragments, 24 MFMAs (the six products of each of the four tiles; consecutive MFMAs go to
 //     different accumulators).
 //   * epilogue per row tile: optional row normalisation on the accumulators (as in the second form), stores.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int SR = 64;                 // rows per block tile
-constexpr int SN = 256;                // output columns per pass
-constexpr int SKB = 3 * 8 * 64;        // 16-byte units of packed T per (pass, k-step): 24 KiB
-
-// (lo, hi) -> three packed bf16 pairs whose sum is (lo, hi) to 2^-27: v_cvt_pk_bf16_f32 (round to nearest even), the bf16
-// back as f32 by shift / mask, an exact f32 subtraction — twice.
-__device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t &p1, uint32_t &p2, uint32_t &p3) {
-    const f2v v = {lo, hi};
-    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    const f2v f1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-    const f2v r1 = v - f1;
-    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
-    const f2v f2 = {__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
-    const f2v r2 = r1 - f2;
-    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
-}
-
 // T (d x k row-major f32) -> split into three bf16 matrices, in fragment order, zero-padded to whole k-steps and passes.
 __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *__restrict__ t, uint32_t d, uint32_t k,
                                                                    uint32_t ksteps, uint32_t passes, u32x4 *__restrict__ tp) {
@@ -1222,20 +1173,30 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
         hipLaunchKernelGGL(pack_transform_split_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, t, d, k,
                            ksteps, passes, tp);
-        const uint64_t tiles = (n + SR - 1) / SR;
+        uint64_t tiles = (n + SR - 1) / SR;
         static int cus = 0;
         if (!cus) {
             int dev = 0, c = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
             cus = c > 0 ? c : 256;
         }
+        a.norm = (norm && passes == 1) ? norm : 0;                            // whole rows inside one block only
+        if (norm_done) *norm_done = a.norm != 0;
+        const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
+        // large n: 128-row tiles, one block of four waves per CU, one wave per SIMD (project_fat.hip); CLEORA_PROJECT=split64
+        // keeps the 64-row form for A/B runs
+        const bool fat = !(form_env && !std::strcmp(form_env, "split64")) && ksteps % 4 == 0 && !blend && (n + kFatRows - 1) / kFatRows >= (uint64_t)cus && !dbg;
+        if (fat) {
+            const hipError_t fe = launch_project_split_fat(a, tp, ksteps, passes, cus, stream);
+            const hipError_t le = fe != hipSuccess ? fe : hipGetLastError();
+            CL_HIP(hipFreeAsync(tp, stream));
+            CL_HIP(le);
+            return CLEORA_OK;
+        }
         const uint64_t resident = 2ull * (uint64_t)cus;                       // two 256-thread blocks per CU
         const unsigned gx = (unsigned)(tiles < resident ? tiles : resident);
         const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 4 * 32 * sizeof(float);
-        a.norm = (norm && passes == 1) ? norm : 0;                            // whole rows inside one block only
-        if (norm_done) *norm_done = a.norm != 0;
         const dim3 grid(gx, passes);
-        const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
         auto launch_shape = [&](auto SCt, auto BLt) {
             constexpr bool SC = decltype(SCt)::value, BL = decltype(BLt)::value;
 #define CLEORA_SPLIT_LAUNCH(RG, UU) \

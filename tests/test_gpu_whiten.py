@@ -303,7 +303,9 @@ import numpy as np
 from cleora_amd import _hip
 L = _hip.lib()
 out = {}
-for n, d, k in ((50_000, 256, 256), (20_000, 1024, 1024), (30_000, 64, 64), (20_000, 256, 100), (5_000, 96, 96)):
+# >= 32 768 rows take the 128-row / one-wave-per-SIMD form (project_fat.hip), fewer the 64-row form (whiten.hip)
+for n, d, k in ((50_000, 256, 256), (40_000, 1024, 1024), (36_000, 64, 64), (40_000, 256, 100), (20_000, 256, 100), (9_000, 1024, 1024),
+                (5_000, 96, 96)):
     rng = np.random.default_rng(d + k)
     x = rng.standard_normal((n, d)).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)

@@ -8,7 +8,7 @@ OUT=../libcleora_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 mkdir -p obj
 pids=()
-for f in spmm rowops whiten project_fat eigh hot attention comm stager similarity abi; do
+for f in spmm rowops whiten eigh hot attention comm stager similarity abi; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ project_common.h -nt obj/$f.o ] || [ ../../include/cleora_hip.h -nt obj/$f.o ]; then
     # whiten.hip: MFMA accumulators in the VGPR form — hipcc otherwise parks loop-carried accumulators in VGPRs and copies
     # them to AGPRs and back around every chunk of MFMAs (256 v_accvgpr moves per 64 MFMAs in the Gram kernel)
@@ -18,5 +18,5 @@ for f in spmm rowops whiten project_fat eigh hot attention comm stager similarit
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC obj/spmm.o obj/rowops.o obj/whiten.o obj/project_fat.o obj/eigh.o obj/hot.o obj/attention.o obj/comm.o obj/stager.o obj/similarity.o obj/abi.o -ldl -lpthread -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC obj/spmm.o obj/rowops.o obj/whiten.o obj/eigh.o obj/hot.o obj/attention.o obj/comm.o obj/stager.o obj/similarity.o obj/abi.o -ldl -lpthread -o $OUT
 echo "built $(realpath $OUT)"

@@ -1,4 +1,4 @@
-// project_common.h — shared by whiten.hip and project_fat.hip: the projection's argument block and the three-way bf16 split.
+// project_common.h — the projection's argument block and the three-way bf16 split (whiten.hip).
 #pragma once
 #include "common.h"
 
@@ -55,9 +55,5 @@ static __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t 
     const f2v r2 = r1 - f2;
     p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
 }
-
-constexpr int kFatRows = 128;          // rows per block tile of project_split_fat_kernel (project_fat.hip)
-// launches the 128-row form over every row tile and column pass; tp = the packed split transform (pack_transform_split_kernel)
-hipError_t launch_project_split_fat(const ProjArgs &a, const u32x4 *tp, uint32_t ksteps, uint32_t passes, int cus, hipStream_t stream);
 
 }  // namespace cleora

@@ -860,13 +860,19 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
 // U = k-steps per trip of the flat loop (a divisor of ksteps, a multiple of RING): the compiler copies the live part of the
 // operand ring at the loop's back edge — behind a vmcnt(0) that drains the prefetch — so the back edge is taken as rarely
 // as the shape allows (once per row tile at d = 256).
-template <bool SCALED, bool BLEND, int RING, int U, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
-                                                               uint32_t ksteps, uint64_t tiles) {
+// RG = row groups of 32 rows per block: 2 (a 64-row tile, 4 waves, two blocks per CU) or 4 (a 128-row tile, 8 waves, one
+// block per CU — for large n: the same two waves per SIMD, but one B stage feeds twice the MFMAs, so the L2 traffic of
+// the B stream (60 GB per call at the C3 shape, 2.6 of 8.75 ms by the profiling builds) halves).
+template <bool SCALED, bool BLEND, int RING, int U, int RG = 2, int DBG = 0>
+__global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
+                                                                                   uint32_t ksteps, uint64_t tiles) {
+    constexpr int T = RG * 128;            // threads
+    constexpr int NB = SKB / T;            // 16-byte units of a B stage per thread (6 or 3)
+    constexpr int SRT = RG * 32;           // rows per block tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *const bs = reinterpret_cast<u32x4 *>(smem);                           // [2][SKB]
     float *const mean_s = reinterpret_cast<float *>(smem + 2 * SKB * 16);        // [16 ksteps]
-    float *const red = mean_s + 16 * ksteps;                                     // [4 waves][32 rows]
+    float *const red = mean_s + 16 * ksteps;                                     // [2 RG waves][32 rows]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1, i = lane & 31, h = lane >> 5;
     const uint32_t pass = blockIdx.y;
@@ -875,10 +881,10 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
     const uint64_t total = my_tiles * ksteps;                                    // a multiple of U (ksteps is)
     if (total == 0) return;
 
-    for (uint32_t c = t; c < 16 * ksteps; c += 256) mean_s[c] = c < a.d ? a.mean[c] : 0.f;
+    for (uint32_t c = t; c < 16 * ksteps; c += T) mean_s[c] = c < a.d ? a.mean[c] : 0.f;
     // B of step 0 straight into buffer 0
 #pragma unroll
-    for (int u = 0; u < 6; ++u) bs[t + 256 * u] = tpp[t + 256 * u];
+    for (int u = 0; u < NB; ++u) bs[t + T * u] = tpp[t + T * u];
 
     // ---- operand ring: A of the next RING k-steps --------------------------------------------------------------------
     float4 ra[RING][2], rb[BLEND ? RING : 1][2];
@@ -887,7 +893,7 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
     uint64_t ltile = blockIdx.x;          // row tile / k-step of the NEXT load
     uint32_t lks = 0;
     auto row_of = [&](uint64_t tile) {
-        const uint64_t r = ((DBG & 2) ? 0 : tile * SR) + (uint64_t)(wr * 32 + i);
+        const uint64_t r = ((DBG & 2) ? 0 : tile * SRT) + (uint64_t)(wr * 32 + i);
         return r < a.n ? r : a.n - 1;                                            // clamped: always a valid address
     };
     auto issue_a = [&](int slot) {
@@ -948,9 +954,9 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
             const int buf = uu & 1;                                              // U is even
             // B of the next k-step: six coalesced 16-byte loads per thread, written to the other buffer at the end
             const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
-            u32x4 bst[6];
+            u32x4 bst[NB];
 #pragma unroll
-            for (int u = 0; u < 6; ++u) bst[u] = (DBG & 4) ? (u32x4){0u, 0u, 0u, 0u} : tpp[(uint64_t)ksn * SKB + t + 256 * u];
+            for (int u = 0; u < NB; ++u) bst[u] = (DBG & 4) ? (u32x4){0u, 0u, 0u, 0u} : tpp[(uint64_t)ksn * SKB + t + T * u];
             // A of k-step g + RING into the slot whose fragments were made during the PREVIOUS step, right behind the B loads:
             // the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in order), the one at
             // the end of the next step completes them; they are split two steps after that
@@ -979,7 +985,7 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
             // after: behind that branch the compiler cannot count the epilogue's stores and drains everything (vmcnt(0)),
             // the operand ring included, at the end of every RING-th step.
 #pragma unroll
-            for (int u = 0; u < 6; ++u) bs[(buf ^ 1) * SKB + t + 256 * u] = bst[u];
+            for (int u = 0; u < NB; ++u) bs[(buf ^ 1) * SKB + t + T * u] = bst[u];
 
             if (uu == U - 1 && ks0 + U == ksteps) {
                 // ---- end of a row tile: normalise (whole rows live in this block when there is one pass), store --------
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void project_split_kernel(const ProjArgs a,
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-                        const uint64_t row = tile * SR + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                        const uint64_t row = tile * SRT + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
                         const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
                         if (row < a.n && col < a.k && (!(DBG & 1) || acc[jj][reg] == 12345.678f)) a.out[row * a.ldo + col] = acc[jj][reg];
                         acc[jj][reg] = 0.f;
@@ -1173,7 +1179,6 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
         hipLaunchKernelGGL(pack_transform_split_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, t, d, k,
                            ksteps, passes, tp);
-        uint64_t tiles = (n + SR - 1) / SR;
         static int cus = 0;
         if (!cus) {
             int dev = 0, c = 256;
@@ -1183,24 +1188,19 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         a.norm = (norm && passes == 1) ? norm : 0;                            // whole rows inside one block only
         if (norm_done) *norm_done = a.norm != 0;
         const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
-        // large n: 128-row tiles, one block of four waves per CU, one wave per SIMD (project_fat.hip); CLEORA_PROJECT=split64
-        // keeps the 64-row form for A/B runs
-        const bool fat = !(form_env && !std::strcmp(form_env, "split64")) && ksteps % 4 == 0 && !blend && (n + kFatRows - 1) / kFatRows >= (uint64_t)cus && !dbg;
-        if (fat) {
-            const hipError_t fe = launch_project_split_fat(a, tp, ksteps, passes, cus, stream);
-            const hipError_t le = fe != hipSuccess ? fe : hipGetLastError();
-            CL_HIP(hipFreeAsync(tp, stream));
-            CL_HIP(le);
-            return CLEORA_OK;
-        }
-        const uint64_t resident = 2ull * (uint64_t)cus;                       // two 256-thread blocks per CU
+        // large n: 128-row tiles, one 8-wave block per CU (RG = 4: half the B-stage traffic per MFMA); otherwise 64-row tiles,
+        // two 4-wave blocks per CU.  CLEORA_PROJECT=split64 keeps the 64-row form for A/B runs.
+        const bool wide = !(form_env && !std::strcmp(form_env, "split64")) && (n + 127) / 128 >= (uint64_t)cus && !dbg;
+        const uint64_t tiles = wide ? (n + 127) / 128 : (n + SR - 1) / SR;
+        const uint64_t resident = wide ? (uint64_t)cus : 2ull * (uint64_t)cus;
         const unsigned gx = (unsigned)(tiles < resident ? tiles : resident);
-        const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 4 * 32 * sizeof(float);
+        const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
         const dim3 grid(gx, passes);
-        auto launch_shape = [&](auto SCt, auto BLt) {
+        auto launch_shape = [&](auto SCt, auto BLt, auto RGt) {
             constexpr bool SC = decltype(SCt)::value, BL = decltype(BLt)::value;
-#define CLEORA_SPLIT_LAUNCH(RG, UU) \
-            hipLaunchKernelGGL((project_split_kernel<SC, BL, RG, UU>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles)
+            constexpr int RG = decltype(RGt)::value;
+#define CLEORA_SPLIT_LAUNCH(RING, UU) \
+            hipLaunchKernelGGL((project_split_kernel<SC, BL, RING, UU, RG>), grid, dim3(RG * 128), lds_bytes, stream, a, tp, ksteps, tiles)
             if constexpr (!BL) {                  // ring of 4 k-steps (the blended operand doubles the ring: 2 there)
                 if (ksteps % 16 == 0) { CLEORA_SPLIT_LAUNCH(4, 16); return; }
                 if (ksteps % 8 == 0) { CLEORA_SPLIT_LAUNCH(4, 8); return; }
@@ -1210,20 +1210,26 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
             else CLEORA_SPLIT_LAUNCH(2, 2);
 #undef CLEORA_SPLIT_LAUNCH
         };
+        auto launch_rg = [&](auto RGt) {
+            if (blend) {
+                if (scaled) launch_shape(std::true_type{}, std::true_type{}, RGt); else launch_shape(std::false_type{}, std::true_type{}, RGt);
+            } else {
+                if (scaled) launch_shape(std::true_type{}, std::false_type{}, RGt); else launch_shape(std::false_type{}, std::false_type{}, RGt);
+            }
+        };
         if (ksteps % 16 == 0 && !blend && !scaled && dbg) {                  // profiling builds (see the kernel)
             switch (dbg) {
-                case 1: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 1>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                case 2: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                case 3: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 3>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                case 4: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 4>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                default: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 7>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 1: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 1>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 2: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 2>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 3: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 3>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                case 4: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 4>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
+                default: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 7>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
             }
-        } else if (blend) {
-            if (scaled) launch_shape(std::true_type{}, std::true_type{}); else launch_shape(std::false_type{}, std::true_type{});
+        } else if (wide) {
+            launch_rg(std::integral_constant<int, 4>{});
         } else {
-            if (scaled) launch_shape(std::true_type{}, std::false_type{}); else launch_shape(std::false_type{}, std::false_type{});
+            launch_rg(std::integral_constant<int, 2>{});
         }
-#undef CLEORA_SPLIT_LAUNCH
         const hipError_t le = hipGetLastError();
         CL_HIP(hipFreeAsync(tp, stream));
         CL_HIP(le);

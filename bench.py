@@ -53,7 +53,7 @@ F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = the
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16 measured 2495 TF)
 F64_MFMA_PEAK_TF = 78.6     # AMD's MI355X datasheet figure for FP64 matrix (the guide lists none); the measured
                             # ceiling of v_mfma_f64_16x16x4_f64 on this chip is in DESIGN.md §3.5 (scripts/mfma_peak.hip)
-KERNEL_SOURCES = ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h")
+KERNEL_SOURCES = ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/row_epilogue.h", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h")
 
 
 def algorithmic_bytes(nnz, n_rows_written, n_rowptr, d):

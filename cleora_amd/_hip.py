@@ -71,6 +71,7 @@ SIGNATURES = {
     "cleora_alloc_iterates": (c_int, [vp, c_u32, c_u32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double * 2)]),
     "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_propagate_vals_dev": (c_int, [vp, vp, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
+    "cleora_propagate_attention_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, c_f32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
     "cleora_edge_attention_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, c_f32, vp, vp]),
     "cleora_rowops_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_init_dev": (c_int, [vp, c_u64, c_u32, c_i64, vp, c_u64, vp]),

@@ -393,6 +393,13 @@ int cleora_propagate_vals_dev(const cleora_graph *g, const float *edge_vals_dev,
                             row_sumsq, S(stream), edge_vals_dev);
 }
 
+int cleora_propagate_attention_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx, uint32_t d,
+                                   float temperature, float *y, uint64_t ldy, uint32_t flags, float residual_weight,
+                                   const float *x_self, double *row_sqdiff, void *stream) {
+    return launch_propagate_attention(g, markov_type, x, ldx, d, temperature, y, ldy, flags, residual_weight, x_self, row_sqdiff,
+                                      S(stream));
+}
+
 int cleora_edge_attention_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx, uint32_t d,
                               float temperature, float *edge_vals_out_dev, void *stream) {
     return launch_edge_attention(g, markov_type, x, ldx, d, temperature, edge_vals_out_dev, S(stream));

@@ -12,6 +12,7 @@
 // 16-byte gathers, 8 rows in flight, scores in registers — below) and the scalar edge_attention_kernel for
 // every other shape.  Rows are not split: a hub row is served by a single wavefront.
 #include "common.h"
+#include "row_epilogue.h"
 
 namespace cleora {
 namespace {
@@ -195,8 +196,155 @@ __global__ __launch_bounds__(256) void edge_attention_vec_kernel(const uint64_t 
         out[e] = (float)(exp(score(chunk, e) - mx) / se * (double)adj[e] / sw);
 }
 
+// ---- attention weights AND the weighted SpMM in one pass over the edges ---------------------------------------------------------
+// embed_with_attention computes the weights from the current iterate and multiplies with them at once (:241-269):
+//     y_r = sum_e w_e x_{c_e},   w_e = exp(s_e - max_r) adj_e / (se_r * max(sum_e' exp(s_e' - max_r) adj_e' / se_r, 1e-10)),   se_r = max(sum exp, 1e-10)
+// The two-kernel route (edge_attention_vec_kernel, then the SpMM with those values) gathers every neighbour row twice.  Here the
+// softmax is accumulated ONLINE: the running maximum m, l = sum exp(s - m) adj, se = sum exp(s - m) and the weighted sum
+// acc = sum exp(s - m) adj x_c are rescaled by exp(m_old - m_new) whenever an edge raises the maximum, so each neighbour row is
+// gathered once, used for its score and for the sum, and dropped.  Same function of the inputs as the reference's (f32 here where
+// the reference holds the weights in f64: tests carry the tolerance of the two-kernel route, 2e-5 on unit rows); the row
+// epilogue (residual, normalisation, squared difference) is the SpMM's (row_epilogue.h).  One wavefront per row, rows not split.
+template <int V>
+__global__ __launch_bounds__(256) void attention_spmm_kernel(const uint64_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                             const float *__restrict__ adj, const float *__restrict__ x, uint64_t ldx,
+                                                             uint32_t d, const float *__restrict__ norm, uint64_t n_rows,
+                                                             float temperature, const RowArgs ra) {
+    const int lane = threadIdx.x & 63;
+    uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    row = uniform_u64(row);
+    const uint64_t beg = uniform_u64(rowptr[row]), end = uniform_u64(rowptr[row + 1]);
+    float acc[V][4];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.f;
+    if (beg < end) {
+        float4 xr[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const uint32_t c = (uint32_t)(v * 64 + lane) * 4;
+            xr[v] = c < d ? *reinterpret_cast<const float4 *>(x + row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float nr = norm[row];
+        float m = -INFINITY, l = 0.f, se = 0.f;
+        for (uint64_t e0 = beg; e0 < end; e0 += 64) {
+            const uint32_t cnt = end - e0 < 64 ? (uint32_t)(end - e0) : 64u;
+            const uint32_t cv = (uint32_t)lane < cnt ? col[e0 + lane] : 0u;
+            const float av = (uint32_t)lane < cnt ? adj[e0 + lane] : 0.f;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += 8) {
+                float4 g[8][V];
+                float dot[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)(k0 + u < cnt ? k0 + u : k0));
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const uint32_t cc = (uint32_t)(v * 64 + lane) * 4;
+                        g[u][v] = cc < d ? *reinterpret_cast<const float4 *>(x + (uint64_t)c * ldx + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) s += xr[v].x * g[u][v].x + xr[v].y * g[u][v].y + xr[v].z * g[u][v].z + xr[v].w * g[u][v].w;
+                    dot[u] = s;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < cnt) {                                             // wave-uniform
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)(k0 + u));
+                        const float a_e = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(av), (int)(k0 + u)));
+                        const float s = dot[u] / (nr * norm[c]) / temperature;      // (:243-248)
+                        if (s > m) {                                                // a new row maximum: rescale what was summed so far
+                            const float sc = expf(m - s);                          // exp(-inf) = 0 for the first edge
+                            l *= sc;
+                            se *= sc;
+#pragma unroll
+                            for (int v = 0; v < V; ++v) { acc[v][0] *= sc; acc[v][1] *= sc; acc[v][2] *= sc; acc[v][3] *= sc; }
+                            m = s;
+                        }
+                        const float ex = expf(s - m);
+                        const float p = ex * a_e;
+                        se += ex;
+                        l += p;
+#pragma unroll
+                        for (int v = 0; v < V; ++v) {
+                            acc[v][0] += p * g[u][v].x; acc[v][1] += p * g[u][v].y; acc[v][2] += p * g[u][v].z; acc[v][3] += p * g[u][v].w;
+                        }
+                    }
+            }
+        }
+        const float se_c = fmaxf(se, 1e-10f);                                       // (:257-258)
+        const float inv = 1.0f / (se_c * fmaxf(l / se_c, 1e-10f));                 // (:264-267)
+#pragma unroll
+        for (int v = 0; v < V; ++v) { acc[v][0] *= inv; acc[v][1] *= inv; acc[v][2] *= inv; acc[v][3] *= inv; }
+    }
+    finish_row<64, V, 4, false>(ra, row, lane, 0, acc);
+}
+
 }  // namespace
 
+// y = epilogue(attention-weighted A x) in one pass over the edges (see attention_spmm_kernel); CLEORA_E_INVALID for shapes the
+// vector form does not take (d % 4 != 0, unaligned, d > 2048): the caller then runs the two-kernel route.
+int launch_propagate_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d, float temperature,
+                               float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
+                               hipStream_t stream) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    CL_REQUIRE(kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC, "unknown markov_type");
+    CL_REQUIRE(g->val[kind] != nullptr, "graph has no values for this markov_type");
+    CL_REQUIRE(g->n_rows == g->n_cols, "edge attention needs the whole (square) graph");
+    CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
+    CL_REQUIRE(x != nullptr && y != nullptr && x != y, "x / y is NULL or aliased");
+    CL_REQUIRE(temperature > 0.0f, "attention_temperature must be positive");
+    CL_REQUIRE(!(flags & (CLEORA_F_ROWSQ | CLEORA_F_SCALE)), "ROWSQ / SCALE are not available on the attention path");
+    CL_REQUIRE(!((flags & CLEORA_F_L1NORM) && (flags & CLEORA_F_L2NORM)), "L1NORM is exclusive with L2NORM");
+    const bool vec = d % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(y) & 15u) == 0 && d <= 2048;
+    CL_REQUIRE(vec, "the fused attention SpMM takes 16-byte aligned rows of at most 2048 floats, d % 4 == 0");
+    if (flags & CLEORA_F_RESIDUAL) {                     // the gate of launch_propagate (spmm.hip gate_residual)
+        const bool on = rw > 0.0f && (rw < 1.0f || (flags & CLEORA_F_BLEND_ANY));
+        if (!on) flags &= ~CLEORA_F_RESIDUAL;
+    }
+    if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) {
+        if (!x_self) x_self = x;
+        CL_REQUIRE((reinterpret_cast<uintptr_t>(x_self) & 15u) == 0, "x_self must be 16-byte aligned");
+    }
+    if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
+    if (g->n_rows == 0) return CLEORA_OK;
+    CL_HIP(hipSetDevice(g->device));
+    RowArgs ra{};
+    ra.y = y;
+    ra.ldy = ldy;
+    ra.x_self = x_self;
+    ra.ldxs = ldx;
+    ra.row_sqdiff = row_sqdiff;
+    ra.row_sumsq = nullptr;
+    ra.rw = rw;
+    ra.alpha = 1.0f - rw;
+    ra.flags = flags;
+    ra.d = d;
+    float *norm = nullptr;                      // n floats of scratch, stream-ordered
+    CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&norm), g->n_rows * sizeof(float), stream));
+    const dim3 grid = grid_1d_as_2d((g->n_rows + 3) / 4);
+    hipLaunchKernelGGL(row_norm_kernel, grid, dim3(256), 0, stream, x, ldx, g->n_rows, d, norm);
+#define CLEORA_ATT(VV) hipLaunchKernelGGL(attention_spmm_kernel<VV>, grid, dim3(256), 0, stream, g->rowptr, g->col, g->val[kind], x, ldx, d, norm, g->n_rows, temperature, ra)
+    switch ((d + 255) / 256) {
+        case 1: CLEORA_ATT(1); break;
+        case 2: CLEORA_ATT(2); break;
+        case 3: case 4: CLEORA_ATT(4); break;
+        default: CLEORA_ATT(8); break;
+    }
+#undef CLEORA_ATT
+    const hipError_t le = hipGetLastError();
+    CL_HIP(hipFreeAsync(norm, stream));
+    CL_HIP(le);
+    return CLEORA_OK;
+}
 
 int launch_edge_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                           float temperature, float *vals_out, hipStream_t stream) {

@@ -142,6 +142,9 @@ int staged_h2d(void *dst_dev, const void *src_host, uint64_t bytes, hipStream_t 
 int staged_d2h(void *dst_host, const void *src_dev, uint64_t bytes, hipStream_t after);
 
 // attention.hip
+int launch_propagate_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d, float temperature,
+                               float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
+                               hipStream_t stream);
 int launch_edge_attention(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                           float temperature, float *vals_out, hipStream_t stream);
 // eigh.hip

@@ -196,7 +196,9 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
     sq = _hip.DevArray((n,), np.float64) if check else None
     ws = _hip.DevArray((L.cleora_reduce_workspace(n),), np.float64) if check else None
     tot = _hip.DevArray((1,), np.float64) if check else None
-    attn = _hip.DevArray((max(int(g.info().nnz), 1),), np.float32) if attention_temperature is not None else None
+    fused_attention = attention_temperature is not None and d % 4 == 0 and d <= 2048      # cleora_propagate_attention_dev's shapes
+    attn = (_hip.DevArray((max(int(g.info().nnz), 1),), np.float32)
+            if attention_temperature is not None and not fused_attention else None)
     flags = {"l2": _hip.F_L2NORM, "l1": _hip.F_L1NORM, "none": 0}[normalization]   # _normalize, :942-959
     # this is the Python loop of embed(): it blends for ANY rw > 0 (:111-115), unlike the Rust loop's
     # 0 < rw < 1 (src/embedding.rs:116) that the kernel applies without CLEORA_F_BLEND_ANY
@@ -204,7 +206,10 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
         flags |= _hip.F_RESIDUAL | _hip.F_BLEND_ANY
     taken = []
     for i in range(int(num_iterations)):
-        if attn is not None and i > 0:                # pycleora/__init__.py:241-269
+        if attention_temperature is not None and i > 0 and fused_attention:      # pycleora/__init__.py:241-269, one pass
+            _hip.check(L.cleora_propagate_attention_dev(g.handle, kind, cur.ptr, d, d, float(attention_temperature), nxt.ptr, d,
+                                                        flags, float(residual_weight), cur.ptr, None, None))
+        elif attn is not None and i > 0:              # shapes the fused kernel does not take: weights, then the SpMM
             _hip.check(L.cleora_edge_attention_dev(g.handle, kind, cur.ptr, d, d, float(attention_temperature),
                                                    attn.ptr, None))
             _hip.check(L.cleora_propagate_vals_dev(g.handle, attn.ptr, cur.ptr, d, d, nxt.ptr, d, flags,

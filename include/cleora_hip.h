@@ -180,6 +180,15 @@ int cleora_propagate_vals_dev(const cleora_graph *g, const float *edge_vals_dev,
 int cleora_edge_attention_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx, uint32_t d,
                               float temperature, float *edge_vals_out_dev, void *stream);
 
+/* One iteration of embed_with_attention (pycleora/__init__.py:241-270) as ONE pass over the edges: the attention weights of
+ * cleora_edge_attention_dev and the weighted sum of cleora_propagate_vals_dev together (softmax accumulated online: every
+ * neighbour row is gathered once instead of twice), then the same epilogue flags as cleora_propagate_dev (RESIDUAL / BLEND_ANY,
+ * L2NORM or L1NORM, SQDIFF / SQDIFF64; not ROWSQ / SCALE).  Square graphs; rows of d % 4 == 0 floats, d <= 2048, x / y /
+ * x_self 16-byte aligned with ld % 4 == 0 (CLEORA_E_INVALID otherwise: run the two calls above instead). */
+int cleora_propagate_attention_dev(const cleora_graph *g, int markov_type, const float *x, uint64_t ldx, uint32_t d,
+                                   float temperature, float *y, uint64_t ldy, uint32_t flags, float residual_weight,
+                                   const float *x_self, double *row_sqdiff, void *stream);
+
 /* Row-wise epilogue alone: NdArrayMatrix::l2_normalize_inplace (src/embedding.rs:88-104) when
  * flags = CLEORA_F_L2NORM; same flags as above.  x may equal y (in place). */
 int cleora_rowops_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,

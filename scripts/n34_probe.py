@@ -25,6 +25,12 @@ t = timed(lambda: _hip.check(L.cleora_edge_attention_dev(gr.handle, 0, x.data_pt
 print(f"edge attention, n={n} nnz={nnz} d={d}: {t:.3f} ms  ({(nnz * d * 4 + n * d * 8) / t / 1e6:.0f} GB/s of gathered rows + norm pass)", flush=True)
 t2 = timed(lambda: _hip.check(L.cleora_propagate_dev(gr.handle, 0, x.data_ptr(), d, d, torch.empty_like(x).data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, None, s)))
 print(f"   (the SpMM over the same edges: {t2:.3f} ms)", flush=True)
+y = torch.empty_like(x)
+t3 = timed(lambda: (_hip.check(L.cleora_edge_attention_dev(gr.handle, 0, x.data_ptr(), d, d, 1.0, vals.data_ptr(), s)),
+                    _hip.check(L.cleora_propagate_vals_dev(gr.handle, vals.data_ptr(), x.data_ptr(), d, d, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, None, s))))
+t4 = timed(lambda: _hip.check(L.cleora_propagate_attention_dev(gr.handle, 0, x.data_ptr(), d, d, 1.0, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, s)))
+print(f"one attention iteration: weights + SpMM as two kernels {t3:.3f} ms; fused, softmax online (cleora_propagate_attention_dev) {t4:.3f} ms "
+      f"= {t4 / t2:.2f} x the plain SpMM", flush=True)
 for nq, k in ((1, 10), (8, 10), (9, 10), (64, 10), (256, 10), (64, 100)):
     q = torch.randint(0, n, (nq,), device=dev, dtype=torch.int32)
     oi = torch.empty((nq, k), dtype=torch.int32, device=dev); os_ = torch.empty((nq, k), device=dev)

@@ -86,7 +86,7 @@ def spmm_counters(sub):
     acc = collections.defaultdict(list)
     if os.path.exists(path):
         for r in csv.DictReader(open(path)):
-            if "spmm_rows_kernel" in r["Kernel_Name"] and (sub.endswith("nohot") or "true, true>" in r["Kernel_Name"]):
+            if "spmm_rows_kernel" in r["Kernel_Name"] and (sub.endswith("nohot") or "true, true" in r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
@@ -94,7 +94,7 @@ policy = {}
 nohot = spmm_counters("fetch_nohot")
 if nohot:
     policy["fetch_bytes_per_launch_policy_off"] = nohot["FETCH_SIZE"] * 1024 * fetch_corr
-    policy["fetch_bytes_per_launch_policy_on"] = out["kernels"]["spmm_rows_kernel<64, 1, 4, true, true>"]["FETCH_SIZE_KiB_avg"] * 1024 * fetch_corr
+    policy["fetch_bytes_per_launch_policy_on"] = [v for k, v in out["kernels"].items() if k.startswith("spmm_rows_kernel<64, 1, 4, true, true")][0]["FETCH_SIZE_KiB_avg"] * 1024 * fetch_corr
 for sub, key in (("hit", "policy_on"), ("hit_nohot", "policy_off")):
     c = spmm_counters(sub)
     if c:
@@ -107,7 +107,7 @@ if ea:
     # FETCH_SIZE is derived from these; 64-B requests unless flagged 32B.  "_DRAM" = destined for the memory controller (as
     # opposed to a peer GPU or the host) — still counted on the L2 side of the Infinity Cache.
     rd, rd32, dram = ea.get("TCC_EA0_RDREQ_sum", 0.0), ea.get("TCC_EA0_RDREQ_32B_sum", 0.0), ea.get("TCC_EA0_RDREQ_DRAM_sum", 0.0)
-    out["ea_read_requests"] = {"kernel": "spmm_rows_kernel<64, 1, 4, true, true>", "TCC_EA0_RDREQ": rd, "TCC_EA0_RDREQ_32B": rd32,
+    out["ea_read_requests"] = {"kernel": "spmm_rows_kernel<64, 1, 4, true, true, ...>", "TCC_EA0_RDREQ": rd, "TCC_EA0_RDREQ_32B": rd32,
                                "TCC_EA0_RDREQ_DRAM": dram, "bytes_at_64B": (rd - rd32) * 64 + rd32 * 32,
                                "bytes_at_64B_x_fetch_correction": ((rd - rd32) * 64 + rd32 * 32) * fetch_corr,
                                "dram_fraction_of_requests": dram / rd if rd else None}
@@ -117,7 +117,7 @@ dom = sorted((k for k in out["kernels"] if k.startswith("spmm_rows_kernel")), ke
 # the profile, before touching the kernel sources)
 import hashlib
 _h = hashlib.sha256()
-for rel in ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h"):
+for rel in ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/row_epilogue.h", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h"):   # = bench.py KERNEL_SOURCES
     _h.update(open(os.path.join(os.path.dirname(dst), rel), "rb").read())
 json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"{tag}_pmc.json",
            "kernel_source_sha16": _h.hexdigest()[:16],
@@ -131,8 +131,8 @@ wp = os.path.join(src, "wpmc", "pmc_counter_collection.csv")
 if os.path.exists(wp):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(wp)):
-        if "cleora" in r["Kernel_Name"] and ("gram_kernel" in r["Kernel_Name"] or "project_kernel" in r["Kernel_Name"]
-                                             or "project_rows_kernel" in r["Kernel_Name"]):
+        if "cleora" in r["Kernel_Name"] and any(k in r["Kernel_Name"] for k in ("gram_kernel", "gram32_kernel", "project_kernel",
+                                                                                "project_rows_kernel", "project_split_kernel")):
             acc[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     wout = {"formula": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)  [8 XCDs, 1024 SIMDs]", "kernels": []}
     for (name, grid), c in sorted(acc.items()):

@@ -279,3 +279,53 @@ def test_top_k_beyond_the_device_selection_limit():
     assert len(got) == len(cand) == 1200
     np.testing.assert_allclose([r["score"] for r in got], [c[2] for c in cand], rtol=0, atol=2e-6)
     assert sum((r["source"], r["target"]) == (c[0], c[1]) for r, c in zip(got, cand)) >= 1190     # near-ties may swap
+
+
+@pytest.mark.parametrize("n,d,flags,rw", [(6000, 256, _hip.F_L2NORM, 0.0), (3000, 512, _hip.F_L2NORM | _hip.F_RESIDUAL | _hip.F_BLEND_ANY, 0.3),
+                                          (2000, 260, 0, 0.0), (2500, 1024, _hip.F_L1NORM, 0.0), (1800, 64, _hip.F_L2NORM, 0.0)])
+def test_fused_attention_spmm_against_the_reference_formula(n, d, flags, rw):
+    """cleora_propagate_attention_dev — weights and weighted sum in one pass, softmax accumulated online — against a numpy fp64
+    restatement of pycleora/__init__.py:241-270 (weights in f64, `weighted_adj @ embeddings`), and against the two-kernel route
+    (cleora_edge_attention_dev + cleora_propagate_vals_dev) it replaces: rows of every length class (empty, a few edges, several
+    64-edge chunks, a 700-edge row).  Stated: 2e-5 absolute on the epilogue's output (unit rows / blended rows of norm <= 1)."""
+    from tests.graphs import random_csr
+    rowptr, col, vl, vs = random_csr(n, 10, seed=n + d, empty_frac=0.05, hubs=[(3, 700), (40, 130)])
+    rowptr64, col64, adj = rowptr.astype(np.int64), col.astype(np.int64), vl.astype(np.float64)
+    x = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    temp = 0.7
+    rows = np.repeat(np.arange(n), np.diff(rowptr64))
+    xn = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)
+    score = np.sum(xn[rows].astype(np.float64) * xn[col64], axis=1) / temp
+    mx = np.full(n, -np.inf)
+    np.maximum.at(mx, rows, score)
+    ex = np.exp(score - mx[rows])
+    a = ex / np.maximum(np.bincount(rows, weights=ex, minlength=n), 1e-10)[rows] * adj
+    w = a / np.maximum(np.bincount(rows, weights=a, minlength=n), 1e-10)[rows]
+    y = np.zeros((n, d))
+    np.add.at(y, rows, w[:, None] * x[col64].astype(np.float64))
+    y = y.astype(np.float32)
+    if flags & _hip.F_RESIDUAL:
+        y = (np.float32(1 - rw) * y + np.float32(rw) * x).astype(np.float32)
+    if flags & _hip.F_L2NORM:
+        y = y / np.maximum(np.linalg.norm(y, axis=1, keepdims=True), 1e-10)
+    if flags & _hip.F_L1NORM:
+        y = y / np.maximum(np.abs(y).sum(axis=1, keepdims=True), 1e-10)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    L = _hip.lib()
+    dx = _hip.DevArray.from_host(x)
+    dy, dy2 = _hip.DevArray((n, d), np.float32), _hip.DevArray((n, d), np.float32)
+    dv = _hip.DevArray((col.shape[0],), np.float32)
+    _hip.check(L.cleora_propagate_attention_dev(g.handle, _hip.LEFT, dx.ptr, d, d, temp, dy.ptr, d, flags, rw, dx.ptr, None, None))
+    _hip.check(L.cleora_edge_attention_dev(g.handle, _hip.LEFT, dx.ptr, d, d, temp, dv.ptr, None))
+    _hip.check(L.cleora_propagate_vals_dev(g.handle, dv.ptr, dx.ptr, d, d, dy2.ptr, d, flags, rw, dx.ptr, None, None, None))
+    _hip.check(L.cleora_stream_sync(None))
+    got, two = dy.to_host(), dy2.to_host()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, y, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(got, two, rtol=0, atol=2e-5)
+    g.close()
+    # a shape the fused kernel does not take is refused, not mangled
+    with pytest.raises(ValueError):
+        _hip.check(L.cleora_propagate_attention_dev(_hip.Graph.from_host(rowptr, col, vl).handle, _hip.LEFT, dx.ptr, d, 30, temp, dy.ptr, d, 0,
+                                                    0.0, None, None, None))

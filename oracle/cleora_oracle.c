@@ -225,9 +225,13 @@ uint64_t oracle_embed(uint64_t n, const uint64_t *rowptr, const uint32_t *col, c
     return actual;
 }
 
+/* Threads worth using on this host.  NOT omp_get_max_threads(): that returns whatever the last omp_set_num_threads() call of
+ * this process asked for — after any single-threaded oracle call (the default of oracle.spmm) it is 1, and the at-scale
+ * checks that followed it in one pytest session ran on one core (round 3: 87 s for 20 of 40 iterations). */
 int oracle_max_threads(void) {
 #ifdef _OPENMP
-    return omp_get_max_threads();
+    int n = omp_get_num_procs();
+    return n > 0 ? n : 1;
 #else
     return 1;
 #endif

@@ -544,8 +544,8 @@ def run_whitened(args, g, x, dev, L, iters):
     mfma_tiles = tiles * 36 + (tiles * (tiles - 1) // 2) * 64
     gram_flops = 2.0 * n * mfma_tiles * 256
     proj_flops = 2.0 * n * d * d
-    # the Gram form the product's loop takes in its intermediate iterations (f32 matrix cores at d = 256, csrc/whiten.hip
-    # gram32_kernel: all 36 upper 32x32 tiles of the 8 x 8 grid), timed stand-alone with events on this stream
+    # the Gram form the product's loop takes in its intermediate iterations (f32 matrix cores for d a multiple of 256, csrc/whiten.hip
+    # gram32_kernel), timed stand-alone with events on this stream
     m64 = torch.empty(d, dtype=torch.float64, device=dev)
     g64 = torch.empty((d, d), dtype=torch.float64, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -556,8 +556,9 @@ def run_whitened(args, g, x, dev, L, iters):
     e1.record()
     torch.cuda.synchronize()
     stats_inter_ms = e0.elapsed_time(e1) / 3
-    f32_gram = d == 256 and os.environ.get("CLEORA_GRAM") != "f64" and n >= 4096
-    gram32_flops = 2.0 * n * 36 * 1024 if f32_gram else gram_flops
+    f32_gram = d % 256 == 0 and d <= 2048 and os.environ.get("CLEORA_GRAM") != "f64" and n >= 4096
+    sup = d // 256        # 256-column super-tiles: 36 upper 32x32 tiles per diagonal one, 64 per off-diagonal pair (csrc/whiten.hip)
+    gram32_flops = 2.0 * n * (sup * 36 + sup * (sup - 1) // 2 * 64) * 1024 if f32_gram else gram_flops
     split_proj = os.environ.get("CLEORA_PROJECT") != "f32" and d % 32 == 0
     del m64, g64
     # the product's loop for this path (cleora_embed_dev, what cleora_amd.embed.embed() runs): SpMM(t+1) beside Gram / eigh(t)

@@ -120,9 +120,9 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
                 double *ws, double *gram, hipStream_t stream, double *mean_out64 = nullptr,
                 float *mean_out32 = nullptr,    // outputs given: `mean` is only a shift, the exact mean is produced
                 int blocks_per_cu = 2);
-// the f32-matrix-core form for the intermediate iterations of the whitened loop (d = 256 only: gram32_applies)
+// the f32-matrix-core form for the intermediate iterations of the whitened loop (d a multiple of 256: gram32_applies)
 bool gram32_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d);
-int launch_gram32(const float *x, uint64_t ldx, uint64_t n, double *shift64, float *shift32, double *ws, double *gram,
+int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *shift64, float *shift32, double *ws, double *gram,
                   hipStream_t stream, double *mean_out64, float *mean_out32, int blocks_per_cu = 2);
 // out = (alpha * (x - rowscale (x) mean) + beta * (x2 - mean)) @ t; rowscale / x2 == nullptr: the plain (x - mean) @ t
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,

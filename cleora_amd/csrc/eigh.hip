@@ -621,7 +621,7 @@ int launch_whiten_fit_stats(const float *x, uint64_t ldx, uint64_t n, uint32_t d
     // intermediate iterations of the whitened loop (the caller vouches that nobody looks at this whitening): the f32-matrix-core
     // Gram where it applies (whiten.hip, d = 256); everything else — the last iteration, cleora_whiten_dev — is f64 end to end
     if (intermediate && gram32_applies(x, ldx, n, d))
-        rc = launch_gram32(x, ldx, n, w.shift64, w.mean32, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu);
+        rc = launch_gram32(x, ldx, n, d, w.shift64, w.mean32, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu);
     else
         rc = launch_gram(x, ldx, n, d, w.shift64, w.gram_ws, w.gram, stream, w.mean64, w.mean32, gram_blocks_per_cu);
     if (rc != CLEORA_OK) return rc;

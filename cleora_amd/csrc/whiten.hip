@@ -301,41 +301,77 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// centred Gram on the f32 matrix cores — the INTERMEDIATE iterations of the whitened loop, d = 256
+// centred Gram on the f32 matrix cores — the INTERMEDIATE iterations of the whitened loop, d = 256 S
 // ---------------------------------------------------------------------------------------------
 // Inside E <- whiten(l2_normalise(A E)) the intermediate whitenings only have to be whitenings (eigh.hip: the Cholesky form),
 // and an error of 1e-7 of the covariance is below what the f32 projection adds anyway; only the last iteration, and every
 // caller that looks at a whitened iterate, needs the f64 Gram above (pycleora/__init__.py:138-143).  For those iterations:
 //   * v_mfma_f32_32x32x2_f32 — exact f32 products, one rounding per accumulate (bit-equal to an fmaf chain) at twice the
 //     f64 matrix rate; operands are centred in f32 with an f32 shift, y = x - c32 (one rounding, 3e-8 of |y|);
-//   * one block owns ALL 256 columns: the 36 upper 32x32 tiles of the 8 x 8 grid, nine per wave (tile rows WV and 7 - WV,
-//     as in the f64 diagonal blocks: 8 - WV column fragments feed 9 MFMAs per k pair), so X is read exactly once;
+//   * the columns are cut into S super-tiles of 256.  A DIAGONAL block owns one super-tile: the 36 upper 32x32 tiles of its
+//     8 x 8 grid, nine per wave (tile rows WV and 7 - WV, as in the f64 diagonal blocks: 8 - WV column fragments feed 9 MFMAs
+//     per k pair); at d = 256 that is the whole matrix and X is read exactly once.  An OFF-DIAGONAL pair (I < J) of
+//     super-tiles is two blocks, each 128 columns of I against all 256 of J: wave w owns tile row w of its half, 8 tiles
+//     (one A fragment and 8 B fragments per 8 MFMAs).  The blocks of one row slice are neighbours in the grid and read the
+//     same rows at about the same time (L2 / Infinity Cache);
 //   * f32 accumulators run over at most `sub_rows` (2048) rows, then fold into the block's private f64 partial in global
-//     memory (read-modify-write of 288 KiB per 2 MiB of X; each element belongs to one lane: no atomics, fixed order), so the
-//     rounding of an accumulator is that of a 2048-term f32 sum (~1e-6 of the partial, unbiased), and the slices are
-//     combined in f64 in a fixed order by gram32_reduce_kernel: deterministic;
-//   * column sums of y in f64 beside it (the exact mean comes out of the same pass, as above).
-constexpr int G32_D = 256, G32_KC = 16, G32_TILES = 36;
+//     memory (each element belongs to one lane: no atomics, fixed order), so the rounding of an accumulator is that of a
+//     2048-term f32 sum (~1e-6 of the partial, unbiased), and the slices are combined in f64 in a fixed order by
+//     gram32_reduce_kernel: deterministic;
+//   * column sums of y in f64 beside the diagonal blocks (the exact mean comes out of the same pass, as above).
+constexpr int G32_D = 256, G32_KC = 16, G32_TILES = 36, G32_OFF_TILES = 64, G32_LDS = 2 * G32_KC * 384;
 
 struct Gram32Args {
     const float *x;
     uint64_t ldx, n;
-    const float *shift32;    // centring vector c32 (f32)
-    double *colsum;          // [slices][256]
-    double *partial;         // [slices][36][32][32]
+    const float *shift32;    // centring vector c32 (f32), d entries
+    double *colsum;          // [slices][d]
+    double *partial;         // [slices][tiles_per_slice][32][32]: S x 36 diagonal tiles, then S (S - 1) / 2 x 64 off-diagonal ones
     uint64_t rows_per_slice;
     uint32_t sub_rows;       // fold period, a multiple of G32_KC
+    uint32_t d, S, tiles_per_slice;
 };
 
 __host__ __device__ constexpr int upper_tile_index(int tr, int tc) { return tr * 8 - tr * (tr - 1) / 2 + (tc - tr); }
 
+// The block's partial starts as zeros (written by the lanes that own the elements) so that every fold is the same
+// unconditional read-modify-write: a "first fold stores, later folds add" flag makes the compiler branch around each of the
+// loads.  The lane offset is made opaque inside the fold, or the element addresses are computed ahead of the main loop and
+// live across it in scratch; tile by tile behind sched_barrier, or all loads are batched ahead of the adds and spill.
+template <int NT, class TileIndex>
+__device__ __forceinline__ void gram32_fold(double *out, f16v (&acc)[NT], int i, int h, bool zero, TileIndex tile_index) {
+    uint32_t lo = (uint32_t)((4 * h) * 32 + i) * 8u;
+    asm volatile("" : "+v"(lo));
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+        // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        char *p = reinterpret_cast<char *>(out) + tile_index(q) * 8192 + lo;
+        if (zero) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) *reinterpret_cast<double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256) = 0.0;
+        } else {
+            double old[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) old[reg] = *reinterpret_cast<const double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                *reinterpret_cast<double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256) = old[reg] + (double)acc[q][reg];
+                acc[q][reg] = 0.f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int WV>
-__device__ __forceinline__ void gram32_body(const Gram32Args &a, float (&lds)[2][G32_KC][G32_D]) {
+__device__ __forceinline__ void gram32_body(const Gram32Args &a, float *lds_raw, uint32_t sup) {
+    float (*lds)[G32_KC][G32_D] = reinterpret_cast<float (*)[G32_KC][G32_D]>(lds_raw);
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
-    const uint64_t r_begin = (uint64_t)blockIdx.x * a.rows_per_slice;
+    const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
     const int c4 = t & 63, lr = t >> 6;                     // loader role: columns 4 c4 .. +3 of rows lr + 4 u
-    const float4 sh = *reinterpret_cast<const float4 *>(a.shift32 + c4 * 4);
+    const uint32_t cb = sup * G32_D;                        // first column of this super-tile
+    const float4 sh = *reinterpret_cast<const float4 *>(a.shift32 + cb + c4 * 4);
 
     f16v acc[9];
 #pragma unroll
@@ -350,7 +386,7 @@ __device__ __forceinline__ void gram32_body(const Gram32Args &a, float (&lds)[2]
         for (int u = 0; u < 4; ++u) {
             const uint64_t r = row0 + lr + 4 * u;
             ok[u] = r < r_end;
-            pa[u] = *reinterpret_cast<const float4 *>(a.x + (ok[u] ? r : r_begin) * a.ldx + c4 * 4);   // always a valid row
+            pa[u] = *reinterpret_cast<const float4 *>(a.x + (ok[u] ? r : r_begin) * a.ldx + cb + c4 * 4);   // always a valid row
         }
     };
     auto stage = [&](int buf) {
@@ -362,36 +398,9 @@ __device__ __forceinline__ void gram32_body(const Gram32Args &a, float (&lds)[2]
             *reinterpret_cast<float4 *>(&lds[buf][lr + 4 * u][c4 * 4]) = y;
         }
     };
-    double *const out = a.partial + (uint64_t)blockIdx.x * (G32_TILES * 1024);
-    // The block's partial starts as zeros (written here, by the lanes that own the elements) so that every fold is the same
-    // unconditional read-modify-write: a "first fold stores, later folds add" flag makes the compiler branch around each of the
-    // 144 loads.  The lane offset is made opaque inside the fold, or the 144 element addresses are computed ahead of the
-    // main loop and live across it in scratch.
-    auto fold = [&](bool zero) {
-        uint32_t lo = (uint32_t)((4 * h) * 32 + i) * 8u;
-        asm volatile("" : "+v"(lo));
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const int tidx = upper_tile_index(diag_tile_row(WV, q), diag_tile_col(WV, q));
-            // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-            char *p = reinterpret_cast<char *>(out) + tidx * 8192 + lo;
-            if (zero) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) *reinterpret_cast<double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256) = 0.0;
-            } else {
-                double old[16];
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) old[reg] = *reinterpret_cast<const double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256);
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    *reinterpret_cast<double *>(p + ((reg & 3) + 8 * (reg >> 2)) * 256) = old[reg] + (double)acc[q][reg];
-                    acc[q][reg] = 0.f;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);          // tile by tile: all 144 loads batched ahead of the adds would spill
-        }
-    };
-    fold(true);
+    double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + (uint64_t)sup * G32_TILES) * 1024;
+    auto tile_index = [](int q) { return upper_tile_index(diag_tile_row(WV, q), diag_tile_col(WV, q)); };
+    gram32_fold<9>(out, acc, i, h, true, tile_index);
 
     if (r_begin < r_end) {
         prefetch(r_begin);
@@ -417,26 +426,119 @@ __device__ __forceinline__ void gram32_body(const Gram32Args &a, float (&lds)[2]
         }
         in_sub += G32_KC;
         if (in_sub >= a.sub_rows || row0 + G32_KC >= r_end) {
-            fold(false);
+            gram32_fold<9>(out, acc, i, h, false, tile_index);
             in_sub = 0;
         }
         __syncthreads();
     }
 
-    double *red = reinterpret_cast<double *>(&lds[0][0][0]);   // the loop ended on a barrier: the staging buffers are free
+    double *red = reinterpret_cast<double *>(lds_raw);      // the loop ended on a barrier: the staging buffers are free
 #pragma unroll
     for (int q = 0; q < 4; ++q) red[lr * G32_D + c4 * 4 + q] = cs[q];
     __syncthreads();
-    if (t < G32_D) a.colsum[(uint64_t)blockIdx.x * G32_D + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
+    if (t < G32_D) a.colsum[(uint64_t)blockIdx.y * a.d + cb + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
 }
 
+// off-diagonal block: columns [256 I + 128 half, +128) (A panel) against [256 J, +256) (B panel); wave W owns tile row 4 half + W
+template <int W>
+__device__ __forceinline__ void gram32_off_body(const Gram32Args &a, float *lds_raw, uint32_t I, uint32_t J, uint32_t half, uint32_t pair) {
+    float (*lds)[G32_KC][384] = reinterpret_cast<float (*)[G32_KC][384]>(lds_raw);
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
+    const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
+    const int ca4 = t & 31, ra = t >> 5;                    // A panel: columns 4 ca4 .. +3 of rows ra, ra + 8
+    const int cb4 = t & 63, rb = t >> 6;                    // B panel: columns 4 cb4 .. +3 of rows rb + 4 u
+    const uint32_t colA = I * G32_D + half * 128 + ca4 * 4, colB = J * G32_D + cb4 * 4;
+    const float4 shA = *reinterpret_cast<const float4 *>(a.shift32 + colA), shB = *reinterpret_cast<const float4 *>(a.shift32 + colB);
+
+    f16v acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float4 pa[2], pb[4];
+    bool oka[2], okb[4];
+    auto prefetch = [&](uint64_t row0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint64_t r = row0 + ra + 8 * u;
+            oka[u] = r < r_end;
+            pa[u] = *reinterpret_cast<const float4 *>(a.x + (oka[u] ? r : r_begin) * a.ldx + colA);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t r = row0 + rb + 4 * u;
+            okb[u] = r < r_end;
+            pb[u] = *reinterpret_cast<const float4 *>(a.x + (okb[u] ? r : r_begin) * a.ldx + colB);
+        }
+    };
+    auto centred = [](float4 v, float4 s, bool ok) {
+        return ok ? make_float4(__fsub_rn(v.x, s.x), __fsub_rn(v.y, s.y), __fsub_rn(v.z, s.z), __fsub_rn(v.w, s.w)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4 *>(&lds[buf][ra + 8 * u][ca4 * 4]) = centred(pa[u], shA, oka[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(&lds[buf][rb + 4 * u][128 + cb4 * 4]) = centred(pb[u], shB, okb[u]);
+    };
+    const uint32_t tile_base = a.S * G32_TILES + pair * G32_OFF_TILES + (4 * half + W) * 8;
+    double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + tile_base) * 1024;
+    auto tile_index = [](int q) { return q; };
+    gram32_fold<8>(out, acc, i, h, true, tile_index);
+
+    if (r_begin < r_end) {
+        prefetch(r_begin);
+        stage(0);
+        if (r_begin + G32_KC < r_end) prefetch(r_begin + G32_KC);
+    }
+    __syncthreads();
+    int buf = 0;
+    uint32_t in_sub = 0;
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G32_KC, buf ^= 1) {
+        if (row0 + G32_KC < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * G32_KC < r_end) prefetch(row0 + 2 * G32_KC);
+        }
+#pragma unroll
+        for (int kk = 0; kk < G32_KC / 2; ++kk) {
+            const float fa = lds[buf][2 * kk + h][W * 32 + i];
+            float fb[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) fb[c] = lds[buf][2 * kk + h][128 + c * 32 + i];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[c], acc[c], 0, 0, 0);
+        }
+        in_sub += G32_KC;
+        if (in_sub >= a.sub_rows || row0 + G32_KC >= r_end) {
+            gram32_fold<8>(out, acc, i, h, false, tile_index);
+            in_sub = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// grid = (S + S (S - 1), slices): block x < S is the diagonal block of super-tile x; the others come in pairs per (I < J)
 __global__ __launch_bounds__(256, 2) void gram32_kernel(const Gram32Args a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][G32_KC][G32_D];
-    switch (threadIdx.x >> 6) {                              // whole waves take each arm; every arm meets the same barriers
-        case 0: gram32_body<0>(a, lds); break;
-        case 1: gram32_body<1>(a, lds); break;
-        case 2: gram32_body<2>(a, lds); break;
-        default: gram32_body<3>(a, lds); break;
+    __shared__ __attribute__((aligned(16))) float lds[G32_LDS];
+    const uint32_t b = blockIdx.x;
+    if (b < a.S) {
+        switch (threadIdx.x >> 6) {                          // whole waves take each arm; every arm meets the same barriers
+            case 0: gram32_body<0>(a, lds, b); break;
+            case 1: gram32_body<1>(a, lds, b); break;
+            case 2: gram32_body<2>(a, lds, b); break;
+            default: gram32_body<3>(a, lds, b); break;
+        }
+        return;
+    }
+    const uint32_t pair = (b - a.S) >> 1, half = (b - a.S) & 1;
+    uint32_t q = pair, rowlen = a.S - 1, I = 0;
+    while (q >= rowlen) { q -= rowlen; ++I; --rowlen; }
+    const uint32_t J = I + 1 + q;
+    switch (threadIdx.x >> 6) {
+        case 0: gram32_off_body<0>(a, lds, I, J, half, pair); break;
+        case 1: gram32_off_body<1>(a, lds, I, J, half, pair); break;
+        case 2: gram32_off_body<2>(a, lds, I, J, half, pair); break;
+        default: gram32_off_body<3>(a, lds, I, J, half, pair); break;
     }
 }
 
@@ -449,19 +551,35 @@ __global__ __launch_bounds__(256) void shift_round_kernel(double *__restrict__ s
     shift64[c] = (double)s;
 }
 
-// gram = sum over slices (fixed order) - n delta delta^T, mirrored to the lower triangle
-__global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__restrict__ partial, uint32_t slices,
+// gram = sum over slices (fixed order) - n delta delta^T, mirrored to the lower triangle.  grid = (4, tiles_per_slice)
+__global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__restrict__ partial, uint32_t slices, uint32_t S,
+                                                            uint32_t tiles_per_slice, uint32_t d,
                                                             const double *__restrict__ delta, double n_rows,
                                                             double *__restrict__ gram) {
     const uint32_t p = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;       // tile, element of the tile
-    uint32_t tr, tc;
-    pair_to_tiles(p, 8, tr, tc);
-    const uint32_t gi = tr * 32 + e / 32, gj = tc * 32 + e % 32;
+    uint32_t gi, gj;
+    bool mirror;
+    if (p < S * G32_TILES) {
+        const uint32_t sup = p / G32_TILES;
+        uint32_t tr, tc;
+        pair_to_tiles(p % G32_TILES, 8, tr, tc);
+        gi = sup * G32_D + tr * 32 + e / 32;
+        gj = sup * G32_D + tc * 32 + e % 32;
+        mirror = tr != tc;
+    } else {
+        const uint32_t po = p - S * G32_TILES, pair = po / G32_OFF_TILES, tq = po % G32_OFF_TILES;
+        uint32_t q = pair, rowlen = S - 1, I = 0;
+        while (q >= rowlen) { q -= rowlen; ++I; --rowlen; }
+        const uint32_t J = I + 1 + q;
+        gi = I * G32_D + (tq / 8) * 32 + e / 32;
+        gj = J * G32_D + (tq % 8) * 32 + e % 32;
+        mirror = true;
+    }
     double s = 0.0;
-    for (uint32_t sl = 0; sl < slices; ++sl) s += partial[((uint64_t)sl * G32_TILES + p) * 1024 + e];
+    for (uint32_t sl = 0; sl < slices; ++sl) s += partial[((uint64_t)sl * tiles_per_slice + p) * 1024 + e];
     s -= n_rows * (delta[gi] * delta[gj]);                  // the product first: the same rounding for (i, j) and (j, i)
-    gram[(uint64_t)gi * G32_D + gj] = s;
-    if (tr != tc) gram[(uint64_t)gj * G32_D + gi] = s;
+    gram[(uint64_t)gi * d + gj] = s;
+    if (mirror) gram[(uint64_t)gj * d + gi] = s;
 }
 
 // Row slices per launch: the grid is sized to ONE resident round (2 blocks per CU) so there is no
@@ -1041,15 +1159,23 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
 
 }  // namespace
 
-inline uint32_t gram32_slices(uint64_t n, int per_cu) { return gram_slices(n, 1, per_cu); }
+struct Gram32Plan { uint32_t S, blocks, tiles_per_slice, slices; };
+inline Gram32Plan gram32_plan(uint64_t n, uint32_t d, int per_cu) {
+    Gram32Plan p;
+    p.S = d / G32_D;
+    p.blocks = p.S + p.S * (p.S - 1);
+    p.tiles_per_slice = p.S * G32_TILES + p.S * (p.S - 1) / 2 * G32_OFF_TILES;
+    p.slices = gram_slices(n, p.blocks, per_cu);
+    return p;
+}
 
 uint64_t gram_workspace(uint64_t n, uint32_t d) {
     const GramPlan p = gram_plan(n, d);
     // tile partials, per-slice column sums of the diagonal blocks, delta
     uint64_t need = (uint64_t)p.s_max * p.pairs * GT * GT + (uint64_t)p.s_diag * p.tiles * GT + (uint64_t)p.tiles * GT;
-    if (d == G32_D) {   // the f32 form: [slices][36][32][32] partials, [slices][256] column sums, delta
-        const uint64_t s32 = gram32_slices(n, 2);
-        const uint64_t need32 = s32 * (G32_TILES * 1024 + G32_D) + G32_D;
+    if (d % G32_D == 0 && d <= 2048) {   // the f32 form: [slices][tiles][32][32] partials, [slices][d] column sums, delta
+        const Gram32Plan q = gram32_plan(n, d, 2);
+        const uint64_t need32 = (uint64_t)q.slices * ((uint64_t)q.tiles_per_slice * 1024 + d) + d;
         if (need32 > need) need = need32;
     }
     return need;
@@ -1057,34 +1183,39 @@ uint64_t gram_workspace(uint64_t n, uint32_t d) {
 
 bool gram32_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d) {
     static const bool off = std::getenv("CLEORA_GRAM") && !std::strcmp(std::getenv("CLEORA_GRAM"), "f64");   // A/B switch
-    return !off && d == G32_D && ldx % 4 == 0 && aligned16(x) && n >= 4096;
+    return !off && d % G32_D == 0 && d <= 2048 && ldx % 4 == 0 && aligned16(x) && n >= 4096;
 }
 
-// One-pass centred Gram on the f32 matrix cores (d = 256; see gram32_kernel).  shift64 / shift32: the sampled shift, rounded to
-// f32 here (both are updated: the kernel centres with the f32 value, the exact correction uses that same value).
-int launch_gram32(const float *x, uint64_t ldx, uint64_t n, double *shift64, float *shift32, double *ws, double *gram,
+// One-pass centred Gram on the f32 matrix cores (d a multiple of 256; see gram32_kernel).  shift64 / shift32: the sampled shift,
+// rounded to f32 here (both are updated: the kernel centres with the f32 value, the exact correction uses that same value).
+int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *shift64, float *shift32, double *ws, double *gram,
                   hipStream_t stream, double *mean_out64, float *mean_out32, int blocks_per_cu) {
     CL_REQUIRE(x != nullptr && shift64 != nullptr && shift32 != nullptr && ws != nullptr && gram != nullptr && mean_out64 != nullptr &&
                mean_out32 != nullptr, "x / shift / workspace / gram / mean is NULL");
-    CL_REQUIRE(gram32_applies(x, ldx, n, G32_D), "internal: the f32 Gram does not apply to this shape");
-    const uint32_t slices = gram32_slices(n, blocks_per_cu == 1 ? 1 : 2);
+    CL_REQUIRE(gram32_applies(x, ldx, n, d), "internal: the f32 Gram does not apply to this shape");
+    const Gram32Plan q = gram32_plan(n, d, blocks_per_cu == 1 ? 1 : 2);
+    CL_REQUIRE(q.slices <= 65535, "internal: too many Gram slices");
     Gram32Args a{};
     a.x = x;
     a.ldx = ldx;
     a.n = n;
+    a.d = d;
+    a.S = q.S;
+    a.tiles_per_slice = q.tiles_per_slice;
     a.partial = ws;
-    a.colsum = ws + (uint64_t)slices * (G32_TILES * 1024);
-    double *delta = a.colsum + (uint64_t)slices * G32_D;
-    uint64_t rps = (n + slices - 1) / slices;
+    a.colsum = ws + (uint64_t)q.slices * q.tiles_per_slice * 1024;
+    double *delta = a.colsum + (uint64_t)q.slices * d;
+    uint64_t rps = (n + q.slices - 1) / q.slices;
     a.rows_per_slice = (rps + G32_KC - 1) / G32_KC * G32_KC;
     a.sub_rows = 2048;
-    hipLaunchKernelGGL(shift_round_kernel, dim3(1), dim3(256), 0, stream, shift64, shift32, (uint32_t)G32_D);
+    hipLaunchKernelGGL(shift_round_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, shift64, shift32, d);
     // mean_out32 may be the buffer that holds shift32: the kernel reads it before gram_mean_kernel (same stream) rewrites it
     a.shift32 = shift32;
-    hipLaunchKernelGGL(gram32_kernel, dim3(slices), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(gram_mean_kernel, dim3(1), dim3(256), 0, stream, a.colsum, slices, 2u, (uint32_t)G32_D, n, shift64, delta,
+    hipLaunchKernelGGL(gram32_kernel, dim3(q.blocks, q.slices), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gram_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, a.colsum, q.slices, d / GT, d, n, shift64, delta,
                        mean_out64, mean_out32);
-    hipLaunchKernelGGL(gram32_reduce_kernel, dim3(4, G32_TILES), dim3(256), 0, stream, ws, slices, delta, (double)n, gram);
+    hipLaunchKernelGGL(gram32_reduce_kernel, dim3(4, q.tiles_per_slice), dim3(256), 0, stream, ws, q.slices, q.S, q.tiles_per_slice, d,
+                       delta, (double)n, gram);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

@@ -271,13 +271,14 @@ def test_cholesky_guard_implies_the_reference_clamp(route, monkeypatch):
             assert np.abs(m - np.diag(dm)).max() <= 2e-3
 
 
-def test_intermediate_gram_on_the_f32_matrix_cores():
-    """cleora_whiten_stats_dev(intermediate = 1) at d = 256: centred Gram on v_mfma_f32_32x32x2_f32 (f32 sums over <= 2048
-    rows, f64 across) against the f64 form (intermediate = 0) and numpy fp64.  Stated: the f64 form 1e-13 relative
+@pytest.mark.parametrize("n,d", [(70_001, 256), (40_003, 512), (30_001, 1024)])
+def test_intermediate_gram_on_the_f32_matrix_cores(n, d):
+    """cleora_whiten_stats_dev(intermediate = 1) at d = 256 S: centred Gram on v_mfma_f32_32x32x2_f32 (f32 sums over <= 2048
+    rows, f64 across; S diagonal super-tile blocks and S (S - 1) off-diagonal ones) against the f64 form (intermediate = 0) and
+    numpy fp64.  Stated: the f64 form 1e-13 relative
     Frobenius as before; the f32 form <= 5e-7 of the Gram's Frobenius norm and of its diagonal entry by entry.  Mean: 1e-12 for
     the f64 form; the f32 form centres in f32 (y = x - c32, one rounding of 3e-8 |y|), so its mean carries that: <= 1e-8."""
-    L = _hip.lib()
-    n, d = 70_001, 256                                         # not a multiple of the 16-row chunk or of the slice count
+    L = _hip.lib()                                             # n: not a multiple of the 16-row chunk or of the slice count
     rng = np.random.default_rng(8)
     x = (rng.standard_normal((n, d)) * np.linspace(0.3, 2.0, d) + rng.standard_normal(d) * 0.2).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)

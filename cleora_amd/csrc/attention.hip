@@ -33,6 +33,36 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// Eight per-lane partial sums -> their eight wave totals in 10 lane exchanges instead of 8 butterflies of 6: the first three
+// steps are a reduce-scatter (the lanes of a pair keep half of the values each and add the partner's copy of that half:
+// 4 + 2 + 1 exchanges), the last three a butterfly on the one value left.  The total of v[u] ends up in every lane whose
+// bits 5, 4, 3 spell u — read it with wave8_total(r, u) (lane 8 u).
+__device__ __forceinline__ float wave8_reduce(const float (&v)[8], int lane) {
+    float w4[4], w2[2], w1;
+    const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float keep = b5 ? v[4 + j] : v[j], send = b5 ? v[j] : v[4 + j];
+        w4[j] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float keep = b4 ? w4[2 + j] : w4[j], send = b4 ? w4[j] : w4[2 + j];
+        w2[j] = keep + __shfl_xor(send, 16, 64);
+    }
+    {
+        const float keep = b3 ? w2[1] : w2[0], send = b3 ? w2[0] : w2[1];
+        w1 = keep + __shfl_xor(send, 8, 64);
+    }
+    w1 += __shfl_xor(w1, 4, 64);
+    w1 += __shfl_xor(w1, 2, 64);
+    w1 += __shfl_xor(w1, 1, 64);
+    return w1;
+}
+__device__ __forceinline__ float wave8_total(float r, int u) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(r), 8 * u));
+}
+
 __global__ __launch_bounds__(256) void edge_attention_kernel(const uint64_t *__restrict__ rowptr,
                                                              const uint32_t *__restrict__ col,
                                                              const float *__restrict__ adj,
@@ -151,15 +181,12 @@ __global__ __launch_bounds__(256) void edge_attention_vec_kernel(const uint64_t 
                 for (int v = 0; v < V; ++v) s += xr[v].x * g[u][v].x + xr[v].y * g[u][v].y + xr[v].z * g[u][v].z + xr[v].w * g[u][v].w;
                 dot[u] = s;
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+            const float dots = wave8_reduce(dot, lane);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (k0 + u < cnt) {
                     const float nc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ncv), (int)(k0 + u)));
-                    const float s = dot[u] / (nr * nc) / temperature;           // (:243-248)
+                    const float s = wave8_total(dots, u) / (nr * nc) / temperature;   // (:243-248)
                     if ((uint32_t)lane == k0 + u) mine = s;
                 }
         }
@@ -254,19 +281,15 @@ __global__ __launch_bounds__(256) void attention_spmm_kernel(const uint64_t *__r
                     for (int v = 0; v < V; ++v) s += xr[v].x * g[u][v].x + xr[v].y * g[u][v].y + xr[v].z * g[u][v].z + xr[v].w * g[u][v].w;
                     dot[u] = s;
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) dot[u] += __shfl_xor(dot[u], o, 64);
+                const float dots = wave8_reduce(dot, lane);
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (k0 + u < cnt) {                                             // wave-uniform
                         const float a_e = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(av), (int)(k0 + u)));
                         const float q_e = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qv), (int)(k0 + u)));
-                        // (after the butterfly every lane holds the same dot product: say so, and the branch below is a scalar one
-                        // instead of an exec-masked region per edge)
-                        const float du = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(dot[u])));
-                        const float s = du * q_e;                                   // cos(x_r, x_c) / temperature (:243-248)
+                        // (v_readlane puts the dot product into an SGPR: the score is wave-uniform by construction and the branch
+                        // below a scalar one instead of an exec-masked region per edge)
+                        const float s = wave8_total(dots, u) * q_e;                 // cos(x_r, x_c) / temperature (:243-248)
                         if (s > m) {                                                // a new row maximum: rescale what was summed so far
                             const float sc = expf(m - s);                          // exp(-inf) = 0 for the first edge
                             l *= sc;

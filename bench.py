@@ -143,7 +143,7 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
     return out, checks
 
 
-def cpu_baseline_row_block(g, x_dev, n, d, rows=2_000_000, budget_s=20.0):
+def cpu_baseline_row_block(g, x_dev, n, d, rows=500_000, budget_s=20.0):
     """cpu_baseline for graphs whose iterate does not fit the host comfortably: the oracle's SpMM + L2 over a contiguous
     block of `rows` OUTPUT rows of the same graph.  The gathered X rows are remapped to a compact array (only the rows the block
     touches are copied from the device), so the arithmetic and the access pattern per edge are the reference's; the rate is
@@ -744,6 +744,7 @@ def main():
         # graph against the same iteration computed by this rank alone, BEFORE the big graph is built
         selftest = partition_selftest(dev, rank, world, comm, backend, L)
     g, hashes, workload_label, cfg = make_workload(args, dev, rank, world, args.share_gpu)
+    torch.cuda.empty_cache()                  # the iterates come from hipMalloc (cleora_alloc_iterates), not from torch's cache
     args.dim = args.dim or cfg["dim"]
     d = args.dim
     n, nnz = g["n"], g["nnz"]

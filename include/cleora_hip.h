@@ -264,8 +264,9 @@ int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, 
  * the exact f64 mean (:136) and the centred Gram sum_r (x_r - mean)(x_r - mean)^T (:138-143 without the 1/(n-1)), computed
  * around a sampled shift and corrected exactly (csrc/whiten.hip).  intermediate = 0: f64 matrix cores end to end, the form
  * behind every whitening a caller can observe.  intermediate = 1: the form the whitened loop takes for iterations whose
- * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — at d = 256 the Gram runs on the f32 matrix
- * cores (exact products, f32 sums over <= 2048 rows, f64 across; ~1e-7 of the diagonal), other shapes as intermediate = 0.
+ * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — for d a multiple of 256 (<= 2048) the Gram runs
+ * on the f32 matrix cores (exact products, f32 sums over <= 2048 rows, f64 across; ~1e-7 of the diagonal), other shapes as
+ * intermediate = 0.
  * workspace: cleora_whiten_workspace(n, d) BYTES; mean64_dev: f64[d]; gram_dev: f64[d*d].  n >= 2. */
 int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, int intermediate,
                             double *mean64_dev, double *gram_dev, void *stream);

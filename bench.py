@@ -523,8 +523,7 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     avg_ms = rows_ms / max(calls, 1)
     avg_bytes = sum(launch_bytes) / len(launch_bytes)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    finite = bool(torch.isfinite(a[:n]).all())
-    sumsq = a[:n].double().pow(2).sum(1)
+    finite, sumsq = finite_and_row_sumsq(a, n)
     if part == "column" and world > 1:
         comm.allreduce(sumsq)
         torch.cuda.synchronize()
@@ -550,6 +549,16 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     }
     res.update(extra)
     return res, a, b, iterate, blocks
+
+
+def finite_and_row_sumsq(a, n, rows_per_pass=4_000_000):
+    """Post-loop checks in row slabs, so that the f64 temporaries stay a few GB next to a 100+ GB iterate (config 4s)."""
+    finite, sumsq = True, torch.empty(n, dtype=torch.float64, device=a.device)
+    for r0 in range(0, n, rows_per_pass):
+        blk = a[r0:min(n, r0 + rows_per_pass)]
+        finite = finite and bool(torch.isfinite(blk).all())
+        sumsq[r0:r0 + blk.shape[0]] = blk.double().pow(2).sum(1)
+    return finite, sumsq
 
 
 def project_roofline(n, d, ms, split):
@@ -668,7 +677,7 @@ def run_whitened(args, g, x, dev, L, iters):
                           "frac": gram_flops / (gram_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TF if gram_ms else 0.0,
                           "executed_flops": gram_flops, "full_flops_2nd2": 2.0 * n * d * d},
         "project_roofline": project_roofline(n, d, proj_ms, split_proj),
-        "checks": {"finite": bool(torch.isfinite(prev).all()),
+        "checks": {"finite": finite_and_row_sumsq(prev, prev.shape[0])[0],
                    "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())},
     }
     gr.close()

@@ -155,6 +155,7 @@ void free_graph(cleora_graph *g) {
 }
 
 }  // namespace
+int topk_last_route();        // similarity.hip: which selection the last top-k call took
 }  // namespace cleora
 
 using namespace cleora;
@@ -446,6 +447,8 @@ int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, 
     return launch_topk_cosine(g, x, ldx, n, d, query_rows_dev, n_queries, k, exclude_self, exclude_existing, out_index_dev,
                               out_score_dev, workspace, S(stream));
 }
+
+int cleora_topk_last_route(void) { return topk_last_route(); }
 
 uint64_t cleora_gram_workspace(uint64_t n, uint32_t d) { return gram_workspace(n, d); }
 

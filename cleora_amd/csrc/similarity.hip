@@ -9,7 +9,15 @@
 //   mask     the query itself and, optionally, every r with a stored edge (q, r) or (r, q) get -2 like the reference
 //            (one pass over the CSR per batch);
 //   top-k    per 2048-element chunk k rounds of a block-wide arg-max in LDS (ties: the LARGER row index first, which
-//            is what numpy's argsort()[::-1] yields), then the chunk winners are merged the same way.
+//            is what numpy's argsort()[::-1] yields), then the chunk winners are merged the same way.  For n >= 256 Ki
+//            rows that selection runs on a SHORT LIST instead of on all n scores: a threshold from a stratified row
+//            sample (the r-th largest of S sampled scores, r chosen so that fewer than k elements pass it with
+//            probability < 1e-9), ONE pass over the scores that compacts everything at or above it (a few thousand
+//            elements per query), the rounds on that list.  The pass count is checked on the host; a list shorter
+//            than k or longer than its buffer sends that batch through the full selection: same result either way.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
 #include <utility>
 
 #include "common.h"
@@ -21,6 +29,10 @@ constexpr int QB = 8;           // queries per pass, VALU form (scores laid out 
 constexpr int QM = 256;         // queries per pass at most, MFMA form (scores laid out [row][query]); 64 for batches <= 64
 constexpr float kMasked = -3.0e38f;   // what mask_kernel writes; the selection turns it into the reference's -2
 constexpr int CHUNK = 2048;     // elements per selection block
+constexpr uint32_t SHORT_MIN_N = 256 * 1024;   // the short-list selection from this many rows on
+constexpr uint32_t SHORT_CAP = 32768;          // candidates per query the short list holds
+constexpr uint32_t SHORT_RMAX = 64;            // largest sample rank the threshold may take
+constexpr uint32_t SHORT_SMAX = 131072;        // largest sample per query
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict
                                                          const float *__restrict__ scale, uint64_t len, uint64_t stride_in,
                                                          uint64_t elem_stride, uint32_t k,
                                                          float *__restrict__ out_score, uint32_t *__restrict__ out_index,
-                                                         uint64_t stride_out) {
+                                                         uint64_t stride_out, const uint32_t *__restrict__ len_of_query) {
     __shared__ float sv[CHUNK];
     __shared__ uint32_t si[CHUNK];
     __shared__ float rv[4];
@@ -161,6 +173,7 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict
     const uint32_t q = Q_FAST ? blockIdx.x : blockIdx.y, chunk = Q_FAST ? blockIdx.y : blockIdx.x;
     const uint64_t base = (uint64_t)chunk * CHUNK;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (len_of_query) len = len_of_query[q] < len ? len_of_query[q] : len;     // a short list: its own length per query
     for (int i = t; i < CHUNK; i += 256) {
         const uint64_t p = base + i;
         const bool ok = p < len;
@@ -209,6 +222,58 @@ __global__ __launch_bounds__(256) void topk_chunk_kernel(const float *__restrict
     }
 }
 
+// Short list, step 1: S scores of query q at stratified row positions (one per stratum of `stratum` rows, at a hashed
+// offset inside it), as the selection sees them (-2 for masked, scaled).  grid (S / 256, nq).
+__global__ __launch_bounds__(256) void sample_scores_kernel(const float *__restrict__ scores, const float *__restrict__ scale,
+                                                            uint64_t qs, uint64_t rs, uint32_t S, uint32_t stratum,
+                                                            float *__restrict__ sample) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, q = blockIdx.y;
+    if (i >= S) return;
+    const uint64_t p = (uint64_t)i * stratum + ((i * 2654435761u) >> 8) % stratum;
+    float v = scores[q * qs + p * rs];
+    if (v == kMasked) v = -2.0f;
+    else if (scale) v *= scale[p];
+    sample[(uint64_t)q * S + i] = v;
+}
+
+// Short list, step 2: every (score, row) of query q with score >= tau[q * tau_stride] appended to the query's list (order
+// arbitrary: the rounds that follow order by score and row index).  count[q] = how many passed, also beyond the capacity.
+// Layout [query][row] (rs == 1): blockIdx.y = query.  Layout [row][query] (qs == 1): flat over the n * nq elements.
+__global__ __launch_bounds__(256) void compact_kernel(const float *__restrict__ scores, const float *__restrict__ scale, uint64_t n,
+                                                      uint64_t qs, uint64_t rs, uint32_t nq, const float *__restrict__ tau,
+                                                      uint32_t tau_stride, float *__restrict__ cand_score,
+                                                      uint32_t *__restrict__ cand_index, uint32_t *__restrict__ count) {
+    const uint64_t threads = (uint64_t)gridDim.x * 256, first = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    auto visit = [&](uint32_t q, uint64_t r, float v, float t) {
+        if (v == kMasked) v = -2.0f;
+        else if (scale) v *= scale[r];
+        if (v >= t) {
+            const uint32_t slot = atomicAdd(&count[q], 1u);
+            if (slot < SHORT_CAP) {
+                cand_score[(uint64_t)q * SHORT_CAP + slot] = v;
+                cand_index[(uint64_t)q * SHORT_CAP + slot] = (uint32_t)r;
+            }
+        }
+    };
+    if (rs == 1) {
+        const uint32_t q = blockIdx.y;
+        const float t = tau[(uint64_t)q * tau_stride];
+        for (uint64_t r = first; r < n; r += threads) visit(q, r, scores[q * qs + r], t);
+    } else {
+        // element e = r * nq + q; the stride of the loop splits into whole rows and a remainder of queries
+        const uint64_t dr = threads / nq;
+        const uint32_t dq = (uint32_t)(threads - dr * nq);
+        uint64_t r = first / nq;
+        uint32_t q = (uint32_t)(first - r * nq);
+        while (r < n) {
+            visit(q, r, scores[r * nq + q], tau[(uint64_t)q * tau_stride]);
+            r += dr;
+            q += dq;
+            if (q >= nq) { q -= nq; ++r; }
+        }
+    }
+}
+
 }  // namespace
 
 static inline uint64_t chunks_of(uint64_t len) { return (len + CHUNK - 1) / CHUNK; }
@@ -219,13 +284,46 @@ static inline uint32_t per_pass(uint32_t n_queries) {
     return n_queries <= (uint32_t)QB ? (uint32_t)QB : n_queries <= 64u ? 64u : (uint32_t)QM;
 }
 
-// bytes: scores [per][n] + two candidate levels (score + index each) + the query bitmap + (MFMA form) 1/||x_r||, the
-// d x per query matrix and a zero "mean" of d floats for the projection kernel
+// The short list's plan for n rows and k results: sample size S (one score per stratum of n / S rows), the rank r of the
+// threshold in the sample.  The number of the true top-k that land in a sample of fraction S / n is about Poisson(k S / n);
+// the list holds all of them unless at least r do, so r is the smallest rank whose tail is below 1e-9 (and the host checks
+// the count in any case).  Expected list length r n / S.  CLEORA_TOPK=rounds switches it off, =short takes it from 2048 rows on.
+static inline uint64_t short_sample_size(uint64_t n) {               // n / 256 in whole chunks, within [CHUNK, SHORT_SMAX]
+    const uint64_t S = ((n / 256 + CHUNK - 1) / CHUNK) * CHUNK;
+    return S < (uint64_t)CHUNK ? (uint64_t)CHUNK : S > SHORT_SMAX ? (uint64_t)SHORT_SMAX : S;
+}
+struct ShortPlan { bool use; uint32_t S, stratum, r; };
+static ShortPlan short_plan(uint64_t n, uint32_t k) {
+    ShortPlan p{false, 0, 0, 0};
+    const char *e = getenv("CLEORA_TOPK");
+    const bool forced = e && !strcmp(e, "short");
+    if ((e && !strcmp(e, "rounds")) || n < (forced ? (uint64_t)CHUNK : (uint64_t)SHORT_MIN_N)) return p;
+    const uint64_t S = short_sample_size(n);
+    p.S = (uint32_t)S;
+    p.stratum = (uint32_t)(n / S);
+    const double lambda = (double)k * (double)S / (double)n;
+    double term = exp(-lambda), cdf = term;
+    uint32_t r = 1;
+    while (1.0 - cdf > 1e-9 && r <= SHORT_RMAX) { term *= lambda / r; cdf += term; ++r; }
+    p.r = r;
+    p.use = r <= SHORT_RMAX && 3.0 * r * (double)p.stratum <= (double)SHORT_CAP;
+    return p;
+}
+
+static int g_last_route = 0;
+int topk_last_route() { return g_last_route; }
+
+// bytes: scores [per][n] + two candidate levels (score + index each) + the query bitmap + the short list (sample, list,
+// thresholds, counts) + (MFMA form) 1/||x_r||, the d x per query matrix and a zero "mean" of d floats for the projection kernel
+static inline uint64_t short_floats(uint64_t n, uint64_t per) {
+    if (n < (uint64_t)CHUNK) return 0;
+    return per * short_sample_size(n) + 2 * per * SHORT_CAP + 2 * per * SHORT_RMAX + per;
+}
 uint64_t topk_workspace_bytes(uint64_t n, uint32_t k, uint32_t n_queries) {
     const uint64_t per = per_pass(n_queries);
     const uint64_t l1 = chunks_of(n) * k;
     const uint64_t l2 = chunks_of(l1) * k;
-    uint64_t floats = per * n + 2 * per * l1 + 2 * per * l2 + (n + 31) / 32;
+    uint64_t floats = per * n + 2 * per * l1 + 2 * per * l2 + (n + 31) / 32 + short_floats(n, per);
     if (per > (uint64_t)QB) floats += n + (uint64_t)kMaxD * per + kMaxD;
     return floats * 4 + 1024;
 }
@@ -255,7 +353,17 @@ int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint
     uint32_t *i2 = reinterpret_cast<uint32_t *>(s2 + slots * l2);
     uint32_t *bits = i2 + slots * l2;
     const uint64_t bit_words = (n + 31) / 32;
-    float *inv = reinterpret_cast<float *>(bits + bit_words);         // MFMA form only from here on: [n]
+    // the short list: sample [slots][S], list (score, row) [slots][SHORT_CAP], thresholds (score, unused index) [slots][SHORT_RMAX], counts
+    const ShortPlan plan = short_plan(n, k);
+    float *sample = reinterpret_cast<float *>(bits + bit_words);
+    const uint64_t sfl = short_floats(n, slots);
+    float *cs = sample + (sfl ? slots * short_sample_size(n) : 0);
+    uint32_t *ci = reinterpret_cast<uint32_t *>(cs + slots * SHORT_CAP);
+    float *ts = reinterpret_cast<float *>(ci + slots * SHORT_CAP);
+    uint32_t *ti = reinterpret_cast<uint32_t *>(ts + slots * SHORT_RMAX);
+    uint32_t *count = ti + slots * SHORT_RMAX;
+    float *inv = reinterpret_cast<float *>(sample + sfl);             // MFMA form only from here on: [n]
+    int route = -1;                                                   // 1 every batch by the short list, 0 none, 2 some
     // ... then [d][nq] and d zeros, on a 256-byte boundary (the projection's fast form wants an aligned mean)
     float *qmat = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(inv + n) + 255) & ~(uintptr_t)255);
     float *zeros = qmat + (uint64_t)kMaxD * slots;
@@ -292,35 +400,63 @@ int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint
                                exclude_edges ? g->col : nullptr, exclude_edges ? g->n_rows : 0, qs, rs, queries_dev + q0, nq,
                                bits, exclude_self, exclude_edges, scores);
         }
-        // selection: chunks of X rows -> chunk winners -> ... -> one block per query
-        const float *sin = scores;
-        const uint32_t *iin = nullptr;
-        const float *scale = mfma ? inv : nullptr;
-        uint64_t len = n, stride = qs, estride = rs;
-        float *so = s1;
-        uint32_t *io = i1;
-        uint64_t ostride = l1;
-        for (;;) {
-            const uint64_t nb = chunks_of(len);
-            if (nb == 1) {   // final: straight into the caller's arrays
-                hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3(1, nq), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, k,
-                                   out_score + (uint64_t)q0 * k, out_index + (uint64_t)q0 * k, (uint64_t)k);
-                break;
+        // selection: chunks -> chunk winners -> ... -> one block per query.  Element p of query q at sin[q * stride + p * estride].
+        auto select = [&](const float *sin, const uint32_t *iin, const float *scale, uint64_t len, const uint32_t *len_dev,
+                          uint64_t stride, uint64_t estride, uint32_t kk, float *final_score, uint32_t *final_index, uint64_t final_stride) {
+            float *so = s1;
+            uint32_t *io = i1;
+            uint64_t ostride = l1;
+            for (;;) {
+                const uint64_t nb = chunks_of(len);
+                if (nb == 1) {   // final: straight into the destination
+                    hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3(1, nq), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, kk,
+                                       final_score, final_index, final_stride, len_dev);
+                    break;
+                }
+                if (estride != 1 && nb <= 65535)     // [row][query] layout: the blocks of one chunk next to each other
+                    hipLaunchKernelGGL(topk_chunk_kernel<true>, dim3(nq, (unsigned)nb), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, kk, so, io, ostride, len_dev);
+                else
+                    hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3((unsigned)nb, nq), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, kk, so, io, ostride, len_dev);
+                sin = so;
+                iin = io;
+                scale = nullptr;
+                len_dev = nullptr;                   // (blocks beyond a query's own length have written -inf entries)
+                len = nb * kk;
+                stride = ostride;
+                estride = 1;
+                // the two candidate buffers alternate (level 1 fits l2 again: it is smaller than level 0's output)
+                if (so == s1) { so = s2; io = i2; ostride = l2; } else { so = s1; io = i1; ostride = l1; }
             }
-            if (estride != 1 && nb <= 65535)     // [row][query] layout: the blocks of one chunk next to each other
-                hipLaunchKernelGGL(topk_chunk_kernel<true>, dim3(nq, (unsigned)nb), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, k, so, io, ostride);
-            else
-                hipLaunchKernelGGL(topk_chunk_kernel<false>, dim3((unsigned)nb, nq), dim3(256), 0, stream, sin, iin, scale, len, stride, estride, k, so, io, ostride);
-            sin = so;
-            iin = io;
-            scale = nullptr;
-            len = nb * k;
-            stride = ostride;
-            estride = 1;
-            // the two candidate buffers alternate (level 1 fits l2 again: it is smaller than level 0's output)
-            if (so == s1) { so = s2; io = i2; ostride = l2; } else { so = s1; io = i1; ostride = l1; }
+        };
+        const float *scale = mfma ? inv : nullptr;
+        bool by_short_list = false;
+        if (plan.use) {
+            CL_HIP(hipMemsetAsync(count, 0, (size_t)nq * 4, stream));
+            hipLaunchKernelGGL(sample_scores_kernel, dim3((plan.S + 255) / 256, nq), dim3(256), 0, stream, scores, scale, qs, rs, plan.S,
+                               plan.stratum, sample);
+            select(sample, nullptr, nullptr, plan.S, nullptr, plan.S, 1, plan.r, ts, ti, SHORT_RMAX);
+            const uint64_t elems = rs == 1 ? n : n * nq;
+            const unsigned gx = (unsigned)((elems + 1023) / 1024 < 2048 ? (elems + 1023) / 1024 : 2048);
+            hipLaunchKernelGGL(compact_kernel, dim3(gx, rs == 1 ? nq : 1), dim3(256), 0, stream, scores, scale, n, qs, rs, nq,
+                               ts + (plan.r - 1), SHORT_RMAX, cs, ci, count);
+            CL_HIP(hipGetLastError());
+            uint32_t passed[QM];
+            CL_HIP(hipMemcpyAsync(passed, count, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+            CL_HIP(hipStreamSynchronize(stream));
+            uint32_t longest = 0;
+            by_short_list = true;
+            for (uint32_t j = 0; j < nq; ++j) {
+                if (passed[j] < k || passed[j] > SHORT_CAP) by_short_list = false;
+                longest = passed[j] > longest ? passed[j] : longest;
+            }
+            if (by_short_list)
+                select(cs, ci, nullptr, longest, count, SHORT_CAP, 1, k, out_score + (uint64_t)q0 * k, out_index + (uint64_t)q0 * k, (uint64_t)k);
         }
+        if (!by_short_list)
+            select(scores, nullptr, scale, n, nullptr, qs, rs, k, out_score + (uint64_t)q0 * k, out_index + (uint64_t)q0 * k, (uint64_t)k);
+        route = route < 0 ? (by_short_list ? 1 : 0) : (route == (by_short_list ? 1 : 0) ? route : 2);
     }
+    g_last_route = route < 0 ? 0 : route;
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

@@ -348,6 +348,11 @@ int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint
  *   first (numpy's argsort()[::-1]); entries with score <= -2 are masked candidates the caller drops (:663-664).
  * Up to 8 queries: one pass over X on the vector units.  More: the batch is a GEMM — X . Q (Q = the normalised query
  * rows, d x q) on the f32 matrix cores, 64 queries per pass over X, then a row scale by 1 / ||x_r||.
+ * Selection: from 256 Ki rows on, a threshold from a stratified row sample, ONE pass over the scores that compacts what
+ * passes it into a short list (checked on the host: the call synchronises the stream once per batch of queries), the
+ * ordering on that list; below that size, or if a list came out shorter than k or longer than its buffer, k rounds of an
+ * arg-max over all n scores.  Same result either way.  cleora_topk_last_route(): which one the last call took (1 = the
+ * short list in every batch, 0 = in none, 2 = in some); CLEORA_TOPK=rounds|short forces one (tests, A/B).
  * workspace: cleora_topk_workspace_for(n, k, n_queries) BYTES (8 n floats + candidates up to 8 queries, 64 n floats
  * beyond); cleora_topk_workspace(n, k) is the size that serves any batch.  1 <= k <= min(n, 1024). */
 uint64_t cleora_topk_workspace(uint64_t n, uint32_t k);
@@ -355,6 +360,7 @@ uint64_t cleora_topk_workspace_for(uint64_t n, uint32_t k, uint32_t n_queries);
 int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, uint64_t n, uint32_t d,
                            const uint32_t *query_rows_dev, uint32_t n_queries, uint32_t k, int exclude_self,
                            int exclude_existing, uint32_t *out_index_dev, float *out_score_dev, void *workspace, void *stream);
+int cleora_topk_last_route(void);
 
 /* ---- host-pointer entry points: what the PyO3 methods call ------------------------- */
 

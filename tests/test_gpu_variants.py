@@ -203,6 +203,85 @@ def test_topk_cosine_on_device_against_numpy(n, d, k, nq):
     g.close()
 
 
+def _topk_against_numpy(x, queries, k, g=None, rowptr=None, col=None, atol=3e-6):
+    """cleora_topk_cosine_dev (self excluded; stored edges too when a graph is given) against numpy's argsort()[::-1][:k]."""
+    n, d = x.shape
+    nq = len(queries)
+    L = _hip.lib()
+    dx, dq = _hip.DevArray.from_host(x), _hip.DevArray.from_host(np.asarray(queries, np.uint32))
+    oi, os_ = _hip.DevArray((nq, k), np.uint32), _hip.DevArray((nq, k), np.float32)
+    ws = _hip.DevArray((L.cleora_topk_workspace_for(n, k, nq),), np.uint8)
+    _hip.check(L.cleora_topk_cosine_dev(g.handle if g is not None else None, dx.ptr, d, n, d, dq.ptr, nq, k, 1, 1 if g is not None else 0,
+                                        oi.ptr, os_.ptr, ws.ptr, None))
+    _hip.check(L.cleora_stream_sync(None))
+    route = L.cleora_topk_last_route()
+    idx, sc = oi.to_host(), os_.to_host()
+    normed = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-10)
+    rows = np.repeat(np.arange(n), np.diff(rowptr.astype(np.int64))) if g is not None else None
+    for qi, q in enumerate(queries):
+        sims = normed @ normed[q]
+        sims[q] = -2.0
+        if g is not None:
+            sims[col[rows == q]] = -2.0
+            sims[rows[col == q]] = -2.0
+        want = np.argsort(sims)[::-1][:k]
+        np.testing.assert_allclose(sc[qi], sims[want], rtol=0, atol=atol)
+        assert (np.diff(sc[qi]) <= 0).all()
+        assert len(set(idx[qi].tolist())) == k
+        np.testing.assert_allclose(sims[idx[qi]], sc[qi], rtol=0, atol=atol)
+    return route, idx, sc
+
+
+@pytest.mark.parametrize("n,d,k,nq", [(300_000, 32, 10, 3), (300_000, 32, 100, 70), (400_000, 64, 1, 1), (270_000, 16, 1024, 9)])
+def test_topk_selection_from_a_short_list(n, d, k, nq):
+    """From 256 Ki rows on the selection runs on a short list: threshold = the r-th largest of a stratified sample of
+    the scores, one compaction pass, k rounds over what passed (csrc/similarity.hip).  Same contract as the full selection
+    (numpy's `argsort()[::-1][:k]`, pycleora/__init__.py:663, 771; scores to 3e-6), both score layouts ([query][row] up to
+    8 queries, [row][query] from the matrix cores beyond), with the -2 masks, and the route is the short list."""
+    from tests.graphs import random_csr
+    rng = np.random.default_rng(n + k)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[7] = x[3]
+    x[11] = 0.0
+    rowptr, col, vl, vs = random_csr(n, 4, seed=k, empty_frac=0.05)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    queries = rng.choice(n, nq, replace=False).astype(np.uint32)
+    queries[0] = 3
+    route, _, _ = _topk_against_numpy(x, queries, k, g, rowptr, col)
+    assert route == 1
+    g.close()
+
+
+def test_topk_short_list_on_adversarial_score_layouts(monkeypatch):
+    """Where a sampled threshold could go wrong: (a) scores that grow with the row index (a strided sample of a sorted
+    sequence); (b) all rows equal — every score ties, the list overflows its buffer and the batch falls back to the full
+    selection (ties: the larger row index first, like numpy's reversed argsort); (c) the k best all inside one stratum.
+    The result is numpy's in every case; only (b) may leave the short list."""
+    n, d, k = 300_000, 8, 25
+    rng = np.random.default_rng(5)
+    t = np.linspace(0.0, 1.5, n, dtype=np.float64)
+    x = np.zeros((n, d), np.float32)
+    x[:, 0], x[:, 1] = np.cos(t), np.sin(t)                      # cosine with row n-1 grows monotonically with the index
+    route, idx, _ = _topk_against_numpy(x, [n - 1, 0, n // 2], k, atol=1e-6)
+    assert route == 1
+    x = np.tile(rng.standard_normal(d).astype(np.float32), (n, 1))
+    route, idx, sc = _topk_against_numpy(x, [17, n - 1], k, atol=1e-6)
+    assert route in (0, 2)
+    assert idx[0].tolist() == list(range(n - 1, n - 1 - k, -1))                  # all tie at 1: the largest indices first
+    x = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    x[:, 0] -= 1.0
+    x[1000:1000 + k] = np.array([1.0] + [0.0] * (d - 1), np.float32) + (rng.standard_normal((k, d)) * 1e-3).astype(np.float32)
+    route, idx, _ = _topk_against_numpy(x, [1000], k - 1, atol=1e-6)
+    assert route == 1 and set(idx[0].tolist()) == set(range(1001, 1000 + k))
+    # the forced forms at a size both can take give identical arrays
+    xs = rng.standard_normal((20_000, 24)).astype(np.float32)
+    monkeypatch.setenv("CLEORA_TOPK", "short")
+    r1, i1, s1 = _topk_against_numpy(xs, [5, 6, 7, 8, 9, 10, 11, 12, 13, 14], 8)
+    monkeypatch.setenv("CLEORA_TOPK", "rounds")
+    r0, i0, s0 = _topk_against_numpy(xs, [5, 6, 7, 8, 9, 10, 11, 12, 13, 14], 8)
+    assert (r1, r0) == (1, 0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
+
+
 @pytest.mark.parametrize("n,d", [(6000, 256), (3000, 512), (2000, 260), (1500, 30)])
 def test_edge_attention_kernels_on_random_graphs(n, d):
     """Both forms of the attention kernel (16-byte gathers with the scores in registers; the scalar one for widths that

@@ -287,17 +287,21 @@ static inline uint32_t per_pass(uint32_t n_queries) {
 // The short list's plan for n rows and k results: sample size S (one score per stratum of n / S rows), the rank r of the
 // threshold in the sample.  The number of the true top-k that land in a sample of fraction S / n is about Poisson(k S / n);
 // the list holds all of them unless at least r do, so r is the smallest rank whose tail is below 1e-9 (and the host checks
-// the count in any case).  Expected list length r n / S.  CLEORA_TOPK=rounds switches it off, =short takes it from 2048 rows on.
+// the count in any case).  Expected list length r n / S.  CLEORA_TOPK=rounds switches it off, =short takes it from 2048 rows on
+// and for any batch.
 static inline uint64_t short_sample_size(uint64_t n) {               // n / 256 in whole chunks, within [CHUNK, SHORT_SMAX]
     const uint64_t S = ((n / 256 + CHUNK - 1) / CHUNK) * CHUNK;
     return S < (uint64_t)CHUNK ? (uint64_t)CHUNK : S > SHORT_SMAX ? (uint64_t)SHORT_SMAX : S;
 }
 struct ShortPlan { bool use; uint32_t S, stratum, r; };
-static ShortPlan short_plan(uint64_t n, uint32_t k) {
+static ShortPlan short_plan(uint64_t n, uint32_t k, uint32_t queries_per_pass) {
     ShortPlan p{false, 0, 0, 0};
     const char *e = getenv("CLEORA_TOPK");
     const bool forced = e && !strcmp(e, "short");
     if ((e && !strcmp(e, "rounds")) || n < (forced ? (uint64_t)CHUNK : (uint64_t)SHORT_MIN_N)) return p;
+    // a handful of results for a handful of queries: the rounds over all chunks run side by side on the chip and cost less
+    // than the short list's five launches and its host check (measured at n = 1M: break-even near 500 results per pass)
+    if (!forced && (uint64_t)k * queries_per_pass < 512) return p;
     const uint64_t S = short_sample_size(n);
     p.S = (uint32_t)S;
     p.stratum = (uint32_t)(n / S);
@@ -354,7 +358,7 @@ int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint
     uint32_t *bits = i2 + slots * l2;
     const uint64_t bit_words = (n + 31) / 32;
     // the short list: sample [slots][S], list (score, row) [slots][SHORT_CAP], thresholds (score, unused index) [slots][SHORT_RMAX], counts
-    const ShortPlan plan = short_plan(n, k);
+    const ShortPlan plan = short_plan(n, k, n_queries < per ? n_queries : per);
     float *sample = reinterpret_cast<float *>(bits + bit_words);
     const uint64_t sfl = short_floats(n, slots);
     float *cs = sample + (sfl ? slots * short_sample_size(n) : 0);

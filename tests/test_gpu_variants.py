@@ -233,8 +233,8 @@ def _topk_against_numpy(x, queries, k, g=None, rowptr=None, col=None, atol=3e-6)
 
 
 @pytest.mark.parametrize("n,d,k,nq", [(300_000, 32, 10, 3), (300_000, 32, 100, 70), (400_000, 64, 1, 1), (270_000, 16, 1024, 9)])
-def test_topk_selection_from_a_short_list(n, d, k, nq):
-    """From 256 Ki rows on the selection runs on a short list: threshold = the r-th largest of a stratified sample of
+def test_topk_selection_from_a_short_list(n, d, k, nq, monkeypatch):
+    """From 256 Ki rows on (and 512 results per batch: below that CLEORA_TOPK=short asks for it) the selection runs on a short list: threshold = the r-th largest of a stratified sample of
     the scores, one compaction pass, k rounds over what passed (csrc/similarity.hip).  Same contract as the full selection
     (numpy's `argsort()[::-1][:k]`, pycleora/__init__.py:663, 771; scores to 3e-6), both score layouts ([query][row] up to
     8 queries, [row][query] from the matrix cores beyond), with the -2 masks, and the route is the short list."""
@@ -247,6 +247,8 @@ def test_topk_selection_from_a_short_list(n, d, k, nq):
     g = _hip.Graph.from_host(rowptr, col, vl)
     queries = rng.choice(n, nq, replace=False).astype(np.uint32)
     queries[0] = 3
+    if k * nq < 512:
+        monkeypatch.setenv("CLEORA_TOPK", "short")
     route, _, _ = _topk_against_numpy(x, queries, k, g, rowptr, col)
     assert route == 1
     g.close()
@@ -259,6 +261,7 @@ def test_topk_short_list_on_adversarial_score_layouts(monkeypatch):
     The result is numpy's in every case; only (b) may leave the short list."""
     n, d, k = 300_000, 8, 25
     rng = np.random.default_rng(5)
+    monkeypatch.setenv("CLEORA_TOPK", "short")
     t = np.linspace(0.0, 1.5, n, dtype=np.float64)
     x = np.zeros((n, d), np.float32)
     x[:, 0], x[:, 1] = np.cos(t), np.sin(t)                      # cosine with row n-1 grows monotonically with the index

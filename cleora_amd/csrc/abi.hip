@@ -745,13 +745,15 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     if ((rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK) return rc;
     if ((rc = rowsum.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
     struct Streams {
-        hipStream_t a = nullptr, b = nullptr;
-        hipEvent_t ya = nullptr, fb = nullptr;
+        hipStream_t a = nullptr, b = nullptr, s = nullptr;
+        hipEvent_t ya = nullptr, fb = nullptr, zs = nullptr;
         ~Streams() {
+            if (s && s != a) (void)hipStreamDestroy(s);
             if (a) (void)hipStreamDestroy(a);
             if (b) (void)hipStreamDestroy(b);
             if (ya) (void)hipEventDestroy(ya);
             if (fb) (void)hipEventDestroy(fb);
+            if (zs) (void)hipEventDestroy(zs);
         }
     } st;
     // the statistics stream gets the higher priority (its few hundred resident blocks are dispatched at once; the SpMM's
@@ -759,11 +761,29 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     // the 512 registers of every SIMD and the SpMM beside it is left with a quarter of its occupancy
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    static const int co_blocks = std::getenv("CLEORA_GRAM_CO_BLOCKS") ? std::atoi(std::getenv("CLEORA_GRAM_CO_BLOCKS")) : 1;
+    const int co_blocks = std::getenv("CLEORA_GRAM_CO_BLOCKS") ? std::atoi(std::getenv("CLEORA_GRAM_CO_BLOCKS")) : 1;   // (read per call: A/B in one process)
+    // CLEORA_GRAM_CUS = K: the statistics stream owns K compute units (hipExtStreamCreateWithCUMask) instead of sharing every CU
+    // with the SpMM; CLEORA_SPMM_AVOID = 1: the SpMM runs on its own stream that is masked to the other CUs (the projection
+    // keeps the whole chip).  Experiment switches.
+    const int gram_cus = std::getenv("CLEORA_GRAM_CUS") ? std::atoi(std::getenv("CLEORA_GRAM_CUS")) : 0;
+    const bool spmm_avoid = std::getenv("CLEORA_SPMM_AVOID") && std::atoi(std::getenv("CLEORA_SPMM_AVOID")) != 0;
     CL_HIP(hipStreamCreateWithPriority(&st.a, hipStreamNonBlocking, prio_lo));
-    CL_HIP(hipStreamCreateWithPriority(&st.b, hipStreamNonBlocking, prio_hi));
+    st.s = st.a;
+    int dev_id = 0, n_cus = 0;
+    CL_HIP(hipGetDevice(&dev_id));
+    CL_HIP(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id));
+    if (gram_cus > 0 && gram_cus < n_cus) {
+        const uint32_t words = (uint32_t)(n_cus + 31) / 32;
+        std::vector<uint32_t> own(words, 0u), rest(words, 0u);
+        for (int c = 0; c < n_cus; ++c) (c < gram_cus ? own : rest)[c >> 5] |= 1u << (c & 31);
+        CL_HIP(hipExtStreamCreateWithCUMask(&st.b, words, own.data()));
+        if (spmm_avoid) CL_HIP(hipExtStreamCreateWithCUMask(&st.s, words, rest.data()));
+    } else {
+        CL_HIP(hipStreamCreateWithPriority(&st.b, hipStreamNonBlocking, prio_hi));
+    }
     CL_HIP(hipEventCreateWithFlags(&st.ya, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&st.fb, hipEventDisableTiming));
+    CL_HIP(hipEventCreateWithFlags(&st.zs, hipEventDisableTiming));
     CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
     const auto t_loop = std::chrono::steady_clock::now();
     if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a)) != CLEORA_OK) return rc;
@@ -783,7 +803,12 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
         // So: statistics (stream b) -> SpMM (stream a) -> eigensolver (stream b, the host blocks here while both run).
         static const int gram_first = std::getenv("CLEORA_GRAM_FIRST") ? std::atoi(std::getenv("CLEORA_GRAM_FIRST")) : 1;
         if (gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
-        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+        if (st.s != st.a) CL_HIP(hipStreamWaitEvent(st.s, st.ya, 0));
+        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.s)) != CLEORA_OK) return rc;
+        if (st.s != st.a) {
+            CL_HIP(hipEventRecord(st.zs, st.s));
+            CL_HIP(hipStreamWaitEvent(st.a, st.zs, 0));
+        }
         if (!gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
         // intermediate iterations of the L2-normalised loop may take ANY whitening transform (eigh.hip): Cholesky
         if (n > 1 && (rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, any_whitening)) != CLEORA_OK) return rc;

@@ -113,6 +113,44 @@ def loop(nodes, pairs, d):
     print(json.dumps(res), flush=True)
 
 
+def loop_masks(nodes, pairs, d):
+    """The whitened loop under the CU-partition switches of embed_whitened_overlapped (read per call): one graph, one process."""
+    dev = torch.device("cuda:0")
+    L = _hip.lib()
+    g = synth.power_law_graph(nodes, pairs, 2, dev)
+    n, nnz = g["n"], g["nnz"]
+    gr = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(), g["val_left"].data_ptr(), None, 0, keepalive=g)
+    hashes = synth.entity_hashes(n, 0, dev)
+    x0 = torch.empty((n, d), device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x0.data_ptr(), d, s))
+    torch.cuda.synchronize()
+    init = x0.clone()
+    variants = [{}, {"CLEORA_GRAM_CUS": "32"}, {"CLEORA_GRAM_CUS": "64"}, {"CLEORA_GRAM_CUS": "64", "CLEORA_GRAM_CO_BLOCKS": "2"},
+                {"CLEORA_GRAM_CUS": "96", "CLEORA_GRAM_CO_BLOCKS": "2"}, {"CLEORA_GRAM_CUS": "64", "CLEORA_SPMM_AVOID": "1"},
+                {"CLEORA_GRAM_CUS": "64", "CLEORA_GRAM_CO_BLOCKS": "2", "CLEORA_SPMM_AVOID": "1"},
+                {"CLEORA_GRAM_CUS": "48", "CLEORA_GRAM_CO_BLOCKS": "2", "CLEORA_SPMM_AVOID": "1"},
+                {"CLEORA_GRAM_CUS": "128", "CLEORA_GRAM_CO_BLOCKS": "2"}, {}]
+    keys = ("CLEORA_GRAM_CUS", "CLEORA_GRAM_CO_BLOCKS", "CLEORA_SPMM_AVOID")
+    _hip.check(L.cleora_embed_dev(gr.handle, x0.data_ptr(), _hip.LEFT, d, 2, 0.0, 0.0, _hip.F_WHITEN, None))
+    for v in variants:
+        for k in keys:
+            os.environ.pop(k, None)
+        os.environ.update({k: val for k, val in v.items() if k in keys})
+        x0.copy_(init)
+        torch.cuda.synchronize()
+        iters = 8
+        rc = L.cleora_embed_dev(gr.handle, x0.data_ptr(), _hip.LEFT, d, iters, 0.0, 0.0, _hip.F_WHITEN, None)
+        res = {"mode": "loop_masks", "n": n, "nnz": nnz, "d": d, "switches": v, "rc": rc}
+        if rc == 0:
+            res["whitened_ms_per_iter"] = L.cleora_last_embed_loop_ms() / iters
+            cov = torch.cov(x0[:1_000_000].double().T)
+            res["whitened_cov_minus_identity"] = float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())
+        else:
+            res["error"] = _hip.last_error() if hasattr(_hip, "last_error") else "?"
+        print(json.dumps(res), flush=True)
+
+
 def project_only(n, d):
     """The projection alone (profiling: CLEORA_PROJECT_DEBUG variants, rocprofv3 --pmc passes)."""
     dev = torch.device("cuda:0")
@@ -132,7 +170,9 @@ def project_only(n, d):
 if __name__ == "__main__":
     mode = sys.argv[1]
     args = [int(v) for v in sys.argv[2:]]
-    if mode == "project":
+    if mode == "loop_masks":
+        loop_masks(*(args or [10_000_000, 95_000_000, 256]))
+    elif mode == "project":
         project_only(*(args + [10_000_000, 256][len(args):]))
     elif mode == "kernels":
         kernels(*(args + [10_000_000, 256][len(args):]))

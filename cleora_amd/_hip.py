@@ -45,6 +45,7 @@ SIGNATURES = {
     "cleora_memset": (c_int, [vp, c_int, c_u64, vp]),
     "cleora_stream_sync": (c_int, [vp]),
     "cleora_stream_create": (c_int, [ctypes.POINTER(vp)]),
+    "cleora_stream_create_cu_mask": (c_int, [ctypes.POINTER(vp), vp, c_u32]),
     "cleora_stream_destroy": (c_int, [vp]),
     "cleora_stream_wait_stream": (c_int, [vp, vp]),
     "cleora_comm_unique_id": (c_int, [vp]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "cleora_topk_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_topk_workspace_for": (c_u64, [c_u64, c_u32, c_u32]),
     "cleora_topk_last_route": (c_int, []),
+    "cleora_cholesky_whiten_host": (c_int, [vp, c_u64, c_u32, vp, vp]),
     "cleora_topk_cosine_dev": (c_int, [vp, vp, c_u64, c_u64, c_u32, vp, c_u32, c_u32, c_int, c_int, vp, vp, vp, vp]),
     "cleora_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),
     "cleora_l2_normalize": (c_int, [vp, c_u64, c_u32, vp]),

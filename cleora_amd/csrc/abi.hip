@@ -766,6 +766,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     // with the SpMM; CLEORA_SPMM_AVOID = 1: the SpMM runs on its own stream that is masked to the other CUs (the projection
     // keeps the whole chip).  Experiment switches.
     const int gram_cus = std::getenv("CLEORA_GRAM_CUS") ? std::atoi(std::getenv("CLEORA_GRAM_CUS")) : 0;
+    const bool solve_after_spmm = std::getenv("CLEORA_SOLVE_AFTER_SPMM") && std::atoi(std::getenv("CLEORA_SOLVE_AFTER_SPMM")) != 0;
     const bool spmm_avoid = std::getenv("CLEORA_SPMM_AVOID") && std::atoi(std::getenv("CLEORA_SPMM_AVOID")) != 0;
     CL_HIP(hipStreamCreateWithPriority(&st.a, hipStreamNonBlocking, prio_lo));
     st.s = st.a;
@@ -775,7 +776,13 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     if (gram_cus > 0 && gram_cus < n_cus) {
         const uint32_t words = (uint32_t)(n_cus + 31) / 32;
         std::vector<uint32_t> own(words, 0u), rest(words, 0u);
-        for (int c = 0; c < n_cus; ++c) (c < gram_cus ? own : rest)[c >> 5] |= 1u << (c & 31);
+        // K of the CUs, evenly interleaved in the driver's numbering (K = 64: every fourth).  A contiguous range is NOT a
+        // part of the chip with its share of the memory system: the SpMM confined to the first 128 CUs takes 43.7 ms, to
+        // every other CU 31.9 ms (256 CUs: 32.3; profiles/r03k_spmm_cu_masks.jsonl)
+        for (int c = 0; c < n_cus; ++c) {
+            const bool mine = (int64_t)(c + 1) * gram_cus / n_cus > (int64_t)c * gram_cus / n_cus;
+            (mine ? own : rest)[c >> 5] |= 1u << (c & 31);
+        }
         CL_HIP(hipExtStreamCreateWithCUMask(&st.b, words, own.data()));
         if (spmm_avoid) CL_HIP(hipExtStreamCreateWithCUMask(&st.s, words, rest.data()));
     } else {
@@ -810,6 +817,12 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
             CL_HIP(hipStreamWaitEvent(st.a, st.zs, 0));
         }
         if (!gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
+        // CLEORA_SOLVE_AFTER_SPMM=1 (experiment): the d x d step — a chain of ~200 small library kernels — only once the SpMM
+        // is through, instead of beside it
+        if (solve_after_spmm) {
+            CL_HIP(hipEventRecord(st.zs, st.s));
+            CL_HIP(hipStreamWaitEvent(st.b, st.zs, 0));
+        }
         // intermediate iterations of the L2-normalised loop may take ANY whitening transform (eigh.hip): Cholesky
         if (n > 1 && (rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, any_whitening)) != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(st.fb, st.b));

@@ -17,6 +17,8 @@ for f in spmm rowops whiten eigh hot attention comm stager similarity abi; do
     pids+=($!)
   fi
 done
+# host-only math (the d x d step of the intermediate whitened iterations for small d): plain C++, multi-versioned for AVX2 / AVX-512
+if [ ! -f obj/dxd_host.o ] || [ dxd_host.cpp -nt obj/dxd_host.o ]; then g++ -O3 -std=c++17 -fPIC -c dxd_host.cpp -o obj/dxd_host.o; fi
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC obj/spmm.o obj/rowops.o obj/whiten.o obj/eigh.o obj/hot.o obj/attention.o obj/comm.o obj/stager.o obj/similarity.o obj/abi.o -ldl -lpthread -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC obj/dxd_host.o obj/spmm.o obj/rowops.o obj/whiten.o obj/eigh.o obj/hot.o obj/attention.o obj/comm.o obj/stager.o obj/similarity.o obj/abi.o -ldl -lpthread -o $OUT
 echo "built $(realpath $OUT)"

@@ -18,6 +18,9 @@
 #include "common.h"
 
 namespace cleora {
+// dxd_host.cpp: the d x d step on the host (0 = transform written, 1 = not safely positive definite)
+int cholesky_whiten_host(const double *gram, double scale, uint32_t d, float *transform, double min_pivot2, double max_trace_inverse,
+                         double *trace_inverse_out, double *min_pivot2_out);
 namespace {
 
 struct Solver {
@@ -147,6 +150,10 @@ __global__ __launch_bounds__(256) void frob2_kernel(const float *__restrict__ t,
     }
     if (threadIdx.x == 0) out[0] = sm[0];
 }
+}  // namespace
+constexpr double kMaxTraceInverseForHost = 0.999e10;   // = kMaxTraceInverse below
+namespace {
+constexpr uint32_t kHostDxdMax = 256;            // the d x d step of an intermediate iteration runs on the host up to here
 constexpr double kMaxTraceInverse = 0.999e10;   // sum 1/lambda_i <= this  =>  lambda_min >= 1e-10 (with a margin for the f32 T)
 
 // ---- Cholesky whitening transform for d <= 256 in ONE launch, no library, no host synchronisation inside -------------
@@ -395,8 +402,27 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
     //     when the SpMM beside it drains (9.9 ms / 54.7 ms).
     // Default: the library where the host process had rocBLAS mapped already (a PyTorch host), the kernel elsewhere.
     // CLEORA_CHOLESKY=library|kernel overrides (read per call).
+    //   "host" (round 3, the default for d <= 256): Gram to the host, factorisation on one host core (dxd_host.cpp, ~1 ms at
+    //     d = 256), transform back — nothing on the GPU at all: the ~215 small launches of the library route cost 3.5 ms of
+    //     launch latency per iteration (more than config 2's whole SpMM) and slow the SpMM beside them by ~2 ms at config 3.
     bool library_route = solver().rocblas_was_resident;
-    if (const char *env = std::getenv("CLEORA_CHOLESKY")) library_route = std::strcmp(env, "kernel") != 0;
+    bool host_route = d <= kHostDxdMax;
+    if (const char *env = std::getenv("CLEORA_CHOLESKY")) {
+        host_route = d <= kHostDxdMax && std::strcmp(env, "host") == 0;
+        library_route = std::strcmp(env, "kernel") != 0;
+    }
+    if (host_route) {
+        std::vector<double> g(elems);
+        std::vector<float> t(elems);
+        CL_HIP(hipMemcpyAsync(g.data(), gram, elems * sizeof(double), hipMemcpyDeviceToHost, stream));
+        CL_HIP(hipStreamSynchronize(stream));
+        const int bad = cholesky_whiten_host(g.data(), 1.0 / (double)(n - 1), d, t.data(), 1e-8, kMaxTraceInverse, nullptr, nullptr);
+        CL_HIP(hipMemsetAsync(w.info, 0, sizeof(int), stream));            // whiten_info(): nothing failed to converge
+        if (bad) return 1;
+        CL_HIP(hipMemcpyAsync(transform, t.data(), elems * sizeof(float), hipMemcpyHostToDevice, stream));
+        CL_HIP(hipStreamSynchronize(stream));                              // `t` dies with this call
+        return CLEORA_OK;
+    }
     if (d <= 256 && !library_route) {
         hipLaunchKernelGGL(cholesky_whiten_kernel, dim3(1), dim3(kCholThreads), 0, stream, gram, 1.0 / (double)(n - 1), d, w.cov,
                            transform, w.w);
@@ -691,3 +717,9 @@ int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t
 }
 
 }  // namespace cleora
+
+extern "C" int cleora_cholesky_whiten_host(const double *gram_host, uint64_t n, uint32_t d, float *transform_host, double *trace_inverse_out) {
+    if (!gram_host || !transform_host || n < 2 || d == 0) return -1;
+    return cleora::cholesky_whiten_host(gram_host, 1.0 / (double)(n - 1), d, transform_host, 1e-8, cleora::kMaxTraceInverseForHost,
+                                        trace_inverse_out, nullptr);
+}

@@ -592,7 +592,10 @@ inline uint32_t gram_slices(uint64_t n, uint32_t group, int per_cu = 2) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         cus = c > 0 ? c : 256;
     }
-    const int resident = per_cu * cus;
+    // per_cu < 0: -per_cu blocks in TOTAL — a Gram that is to occupy only a part of the chip (one block per CU on that many
+    // CUs) while another kernel keeps the rest: a SIMD that holds a busy MFMA wave gives co-resident waves next to nothing
+    // (profiles/r03o_side_load.jsonl), so the loop's statistics take few CUs for longer instead of every CU for a while
+    const int resident = per_cu < 0 ? -per_cu : per_cu * cus;
     uint64_t s = group ? (uint64_t)resident / group : 1;
     const uint64_t cap = (n + GKC - 1) / GKC;   // at least one chunk of rows per slice
     if (s > cap) s = cap;
@@ -1193,7 +1196,7 @@ int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     CL_REQUIRE(x != nullptr && shift64 != nullptr && shift32 != nullptr && ws != nullptr && gram != nullptr && mean_out64 != nullptr &&
                mean_out32 != nullptr, "x / shift / workspace / gram / mean is NULL");
     CL_REQUIRE(gram32_applies(x, ldx, n, d), "internal: the f32 Gram does not apply to this shape");
-    const Gram32Plan q = gram32_plan(n, d, blocks_per_cu == 1 ? 1 : 2);
+    const Gram32Plan q = gram32_plan(n, d, blocks_per_cu < 0 ? blocks_per_cu : blocks_per_cu == 1 ? 1 : 2);
     CL_REQUIRE(q.slices <= 65535, "internal: too many Gram slices");
     Gram32Args a{};
     a.x = x;
@@ -1230,7 +1233,7 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
     CL_REQUIRE(x != nullptr && mean != nullptr && ws != nullptr && gram != nullptr,
                "x / mean / workspace / gram is NULL");
     CL_REQUIRE((mean_out64 == nullptr) == (mean_out32 == nullptr), "mean outputs come in pairs");
-    const GramPlan p = gram_plan(n, d, blocks_per_cu == 1 ? 1 : 2);     // (the workspace is sized for 2: enough for 1)
+    const GramPlan p = gram_plan(n, d, blocks_per_cu < 0 ? blocks_per_cu : blocks_per_cu == 1 ? 1 : 2);     // (the workspace is sized for 2: enough for fewer)
     GramArgs a{};
     a.colsum = ws + (uint64_t)p.s_max * p.pairs * GT * GT;
     double *delta = a.colsum + (uint64_t)p.s_diag * p.tiles * GT;

@@ -97,6 +97,9 @@ int cleora_stream_sync(void *stream);
  * everything enqueued on `waiter` after this call runs after everything enqueued on `signaller` before it
  * (an event record + stream-wait; no host synchronisation).  NULL = the default stream. */
 int cleora_stream_create(void **stream);
+/* The same, confined to the compute units whose bits are set in cu_mask (`words` 32-bit words, bit c = CU c as the driver
+ * numbers them; hipExtStreamCreateWithCUMask): a job that shares the GPU with another one, or the experiments of DESIGN 3.8. */
+int cleora_stream_create_cu_mask(void **stream, const uint32_t *cu_mask, uint32_t words);
 int cleora_stream_destroy(void *stream);
 int cleora_stream_wait_stream(void *waiter, void *signaller);
 
@@ -281,6 +284,13 @@ int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d
  * Unlike the other *_dev entry points this one WAITS for `stream` (the decision is taken on the host). */
 int cleora_whiten_transform_any_dev(const double *gram_dev, uint64_t n, uint32_t d, float *transform_dev,
                                     void *workspace, void *stream, int *form_out);
+
+/* The host half of cleora_whiten_transform_any_dev for d <= 256 (csrc/dxd_host.cpp; plain host memory, no GPU involved):
+ * cov = gram / (n - 1) = U^T U on one host core, transform = U^-1 = L^-T as f32 (d x d row-major, upper triangular).
+ * Returns 0, or 1 if cov is not safely positive definite (a squared pivot < 1e-8 or trace(cov^-1) > 0.999e10: the caller
+ * takes the PCA form, which reproduces the reference's clamp, pycleora/__init__.py:155), < 0 on bad arguments.
+ * *trace_inverse_out (may be NULL) = ||transform||_F^2 = sum 1/lambda_i. */
+int cleora_cholesky_whiten_host(const double *gram_host, uint64_t n, uint32_t d, float *transform_host, double *trace_inverse_out);
 
 /* whiten_embeddings (pycleora/__init__.py:130-164) on device buffers, one stream, no host round trip:
  * column sums -> mean -> centred Gram -> transform -> projection.  y: n x k (ldy), must not alias x.

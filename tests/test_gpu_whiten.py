@@ -188,7 +188,10 @@ def test_cleora_whiten_errors_and_single_row():
     # the in-house Cholesky kernel (d <= 256): tiny, odd, one below the limit, the limit
     (20_000, 64, 6, 0.0, 0, "kernel"), (6000, 256, 4, 0.3, 1, "kernel"), (500, 8, 4, 0.0, 0, "kernel"),
     (4000, 33, 4, 0.0, 0, "kernel"), (3000, 255, 3, 0.0, 1, "kernel"), (2500, 1, 3, 0.0, 0, "kernel"),
-    (3000, 130, 3, 0.0, 0, None)])                           # None: the library's own choice for this process
+    # the factorisation on the host (d <= 256; the default): the same shapes
+    (20_000, 64, 6, 0.0, 0, "host"), (6000, 256, 4, 0.3, 1, "host"), (500, 8, 4, 0.0, 0, "host"), (2500, 1, 3, 0.0, 0, "host"),
+    (3000, 255, 3, 0.0, 1, "host"), (3000, 320, 3, 0.0, 0, "host"),      # (d > 256: the library whatever the switch says)
+    (3000, 130, 3, 0.0, 0, None)])                           # None: the library's own choice (the host for d <= 256)
 def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, kind, route, monkeypatch):
     """cleora_embed + CLEORA_F_WHITEN without a convergence test runs SpMM(t+1) beside Gram / eigh(t), taking the SpMM
     before the projection (A ((Y - mu) T) = (A Y - (A 1) mu^T) T).  With a (never met) convergence threshold the same
@@ -231,7 +234,7 @@ def test_overlapped_whitened_loop_equals_the_sequential_order(n, d, iters, rw, k
     g.close()
 
 
-@pytest.mark.parametrize("route", ["library", "kernel"])
+@pytest.mark.parametrize("route", ["library", "kernel", "host"])
 def test_cholesky_guard_implies_the_reference_clamp(route, monkeypatch):
     """Intermediate iterations may take the Cholesky whitening only when the reference's clamp max(lambda, 1e-10)
     (pycleora/__init__.py:155) is provably inactive.  The smallest pivot of the factor only bounds lambda_min from ABOVE

@@ -542,6 +542,293 @@ __global__ __launch_bounds__(256, 2) void gram32_kernel(const Gram32Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// the same statistics from the bf16 matrix cores: f32-accurate products by the three-way split of project_common.h
+// ---------------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at sixteen times the rate of the f32 MFMA above; with y = y1 + y2 + y3 (bf16 each, split3_pair)
+// the six products (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) give y_a y_b to better than one f32 rounding, so the Gram
+// costs 6/16 of the f32 form's matrix time.  For G = Y^T Y both MFMA operands are "column i, eight consecutive ROWS": lane (i, h)
+// of a fragment holds rows 8h .. 8h+7 of column i of its 32-column block — the A fragment of column block a and the B fragment of
+// column block b are the same kind of thing, and the one of a diagonal tile is one register set used twice.
+//   * staging: a thread owns (column, row octet): eight dword loads down a column (a wave reads 256 contiguous bytes per row),
+//     centred with the f32 shift, summed into the column sums (f32 over the octet, f64 across), split, and written as THREE
+//     16-byte fragments pieces — [k-step][split][column block][lane] x 16 B, lane-linear: ds_write_b128 / ds_read_b128 without
+//     bank conflicts, no transposition anywhere;
+//   * a block is 8 waves (2 per SIMD), one per CU, 32 rows per barrier, two stages in LDS (96 KiB diagonal, 144 KiB off-diagonal);
+//   * DIAGONAL block: the 36 upper tiles of a 256-column super-tile dealt to the 8 waves as 4 4 4 4 5 5 5 5 (G16_TR / G16_TC:
+//     waves w and w + 4 share a SIMD: 9 tiles per SIMD, the matrix pipes are evenly loaded); OFF-DIAGONAL block (I < J, `half`):
+//     128 columns of I against 256 of J, wave w owns tile row w >> 1 and four tile columns;
+//   * accumulation: the matrix cores sum one 32-row stage from zero, the vector unit adds the stage sums (the bf16 MFMA's f32
+//     accumulation is not round-to-nearest: see gram16_diag_body); fold, partial layout, reducer, mean: those of gram32_kernel
+//     (f32 over <= 2048 rows, f64 across; deterministic).
+constexpr int G16_KR = 32;                    // rows per stage
+constexpr int G16_THREADS = 512;
+constexpr int G16_TR[8][5] = {{0, 0, 0, 0, -1}, {0, 0, 0, 0, -1}, {1, 1, 1, 1, -1}, {1, 1, 1, 7, -1},
+                              {2, 2, 2, 2, 2},  {2, 3, 3, 3, 3},  {3, 4, 4, 4, 4},  {5, 5, 5, 6, 6}};
+constexpr int G16_TC[8][5] = {{0, 1, 2, 3, -1}, {4, 5, 6, 7, -1}, {1, 2, 3, 4, -1}, {5, 6, 7, 7, -1},
+                              {2, 3, 4, 5, 6},  {7, 3, 4, 5, 6},  {7, 4, 5, 6, 7},  {5, 6, 7, 6, 7}};
+__host__ __device__ constexpr int g16_ntiles(int w) { return w < 4 ? 4 : 5; }
+__host__ __device__ constexpr bool g16_uses(int w, int blk) {
+    for (int q = 0; q < g16_ntiles(w); ++q)
+        if (G16_TR[w][q] == blk || G16_TC[w][q] == blk) return true;
+    return false;
+}
+// byte offset of a fragment piece inside a stage: NCB column blocks per (k-step, split)
+template <int NCB>
+__device__ __forceinline__ uint32_t g16_slot(int ks, int s, int cbk, int lane) { return (uint32_t)((((ks * 3 + s) * NCB + cbk) * 64 + lane) * 16); }
+
+// one staging task: eight rows of one column -> centred, summed, split, three 16-byte pieces into the stage
+template <int NCB>
+__device__ __forceinline__ float g16_stage_task(const float (&pre)[8], int nv, float sh, char *stage, int o, int cbk, int lane) {
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = j < nv ? __fsub_rn(pre[j], sh) : 0.f;
+    u32x4 q1, q2, q3;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        uint32_t p1, p2, p3;
+        split3_pair(y[2 * jj], y[2 * jj + 1], p1, p2, p3);
+        q1[jj] = p1; q2[jj] = p2; q3[jj] = p3;
+    }
+    const int ks = o >> 1, ln = (o & 1) * 32 + (lane & 31);
+    *reinterpret_cast<u32x4 *>(stage + g16_slot<NCB>(ks, 0, cbk, ln)) = q1;
+    *reinterpret_cast<u32x4 *>(stage + g16_slot<NCB>(ks, 1, cbk, ln)) = q2;
+    *reinterpret_cast<u32x4 *>(stage + g16_slot<NCB>(ks, 2, cbk, ln)) = q3;
+    return ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+}
+
+#define G16_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+constexpr f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+template <int W>
+__device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds, uint32_t sup) {
+    constexpr int NT = g16_ntiles(W), NCB = 8, STAGE = 2 * 3 * NCB * 1024;
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
+    const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
+    const uint32_t cb = sup * G32_D;
+    // loader role: tasks p = 2 W + u: column group p & 3 (64 columns), row octet p >> 2
+    constexpr int CG0 = (2 * W) & 3, CG1 = (2 * W + 1) & 3, O0 = (2 * W) >> 2, O1 = (2 * W + 1) >> 2;
+    const uint32_t col0 = cb + 64 * CG0 + lane, col1 = cb + 64 * CG1 + lane;
+    const float sh0 = a.shift32[col0], sh1 = a.shift32[col1];
+    f16v acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    double cs0 = 0.0, cs1 = 0.0;
+    float pre0[8], pre1[8];
+    int nv0 = 0, nv1 = 0;
+    auto prefetch = [&](uint64_t row0) {
+        const uint64_t ra = row0 + 8 * O0, rb = row0 + 8 * O1;
+        nv0 = ra >= r_end ? 0 : (r_end - ra >= 8 ? 8 : (int)(r_end - ra));
+        nv1 = rb >= r_end ? 0 : (r_end - rb >= 8 ? 8 : (int)(r_end - rb));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pre0[j] = a.x[(j < nv0 ? ra + j : r_begin) * a.ldx + col0];          // always a valid row
+            pre1[j] = a.x[(j < nv1 ? rb + j : r_begin) * a.ldx + col1];
+        }
+    };
+    auto stage = [&](int buf) {
+        cs0 += (double)g16_stage_task<NCB>(pre0, nv0, sh0, lds + buf * STAGE, O0, 2 * CG0 + h, lane);
+        cs1 += (double)g16_stage_task<NCB>(pre1, nv1, sh1, lds + buf * STAGE, O1, 2 * CG1 + h, lane);
+    };
+    double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + (uint64_t)sup * G32_TILES) * 1024;
+    auto tile_index = [](int q) { return upper_tile_index(G16_TR[W][q], G16_TC[W][q]); };
+    gram32_fold<NT>(out, acc, i, h, true, tile_index);
+
+    if (r_begin < r_end) {
+        prefetch(r_begin);
+        stage(0);
+        if (r_begin + G16_KR < r_end) prefetch(r_begin + G16_KR);
+    }
+    __syncthreads();
+    int buf = 0;
+    uint32_t in_sub = 0;
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
+        if (row0 + G16_KR < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
+        }
+        const char *sb = lds + buf * STAGE;
+        // The bf16 MFMA does not round its f32 accumulation to nearest: a long chain of same-sign terms (the variances on the
+        // diagonal) comes out LOW — -1.3e-6 relative after 2048 rows, uniformly (profiles/r03u_gram_error.txt), against -6e-9
+        // for 32-row chains.  So the matrix cores only ever sum ONE stage (32 rows, 12 MFMAs per tile) from zero, and the
+        // stage sums are added to the long accumulators by the vector unit (v_pk_add_f32: round to nearest even).
+        f16v tmp[NT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 f[8][3];
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk)
+                if (g16_uses(W, blk)) {
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) f[blk][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NCB>(ks, sp, blk, lane));
+                }
+            // product-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][0], f[G16_TC[W][q]][0], ks == 0 ? zero16 : tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][0], f[G16_TC[W][q]][1], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][1], f[G16_TC[W][q]][0], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][1], f[G16_TC[W][q]][1], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][0], f[G16_TC[W][q]][2], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][2], f[G16_TC[W][q]][0], tmp[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
+        in_sub += G16_KR;
+        if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
+            gram32_fold<NT>(out, acc, i, h, false, tile_index);
+            in_sub = 0;
+        }
+        __syncthreads();
+    }
+
+    // column sums: thread (wave, u) summed octet O_u of every stage for its column; the four octets of a column meet in LDS
+    double *red = reinterpret_cast<double *>(lds);          // the loop ended on a barrier: the stages are free
+    red[O0 * G32_D + 64 * CG0 + lane] = cs0;
+    red[O1 * G32_D + 64 * CG1 + lane] = cs1;
+    __syncthreads();
+    if (t < G32_D) a.colsum[(uint64_t)blockIdx.y * a.d + cb + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
+}
+
+// off-diagonal block: columns [256 I + 128 half, +128) (A: column blocks 0..3 of the stage) against [256 J, +256) (B: blocks 4..11);
+// wave W owns tile row W >> 1 of the half and tile columns 4 (W & 1) .. +3
+template <int W>
+__device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, uint32_t I, uint32_t J, uint32_t half, uint32_t pair) {
+    constexpr int NT = 4, NCB = 12, STAGE = 2 * 3 * NCB * 1024, AR = W >> 1, B0 = 4 * (W & 1);
+    const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
+    const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
+    // loader role: tasks p = 3 W + u (24 per stage): p < 8: A panel, column group p & 1, octet p >> 1; else B panel, (p - 8) & 3, (p - 8) >> 2
+    uint32_t col[3];
+    float sh[3];
+    int oct[3], cbk[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int p = 3 * W + u;
+        if (p < 8) {
+            col[u] = I * G32_D + half * 128 + 64 * (p & 1) + lane;
+            oct[u] = p >> 1;
+            cbk[u] = 2 * (p & 1) + h;
+        } else {
+            col[u] = J * G32_D + 64 * ((p - 8) & 3) + lane;
+            oct[u] = (p - 8) >> 2;
+            cbk[u] = 4 + 2 * ((p - 8) & 3) + h;
+        }
+        sh[u] = a.shift32[col[u]];
+    }
+    f16v acc[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float pre[3][8];
+    int nv[3] = {0, 0, 0};
+    auto prefetch = [&](uint64_t row0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const uint64_t r0 = row0 + 8 * oct[u];
+            nv[u] = r0 >= r_end ? 0 : (r_end - r0 >= 8 ? 8 : (int)(r_end - r0));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pre[u][j] = a.x[(j < nv[u] ? r0 + j : r_begin) * a.ldx + col[u]];
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) (void)g16_stage_task<NCB>(pre[u], nv[u], sh[u], lds + buf * STAGE, oct[u], cbk[u], lane);
+    };
+    const uint32_t tile_base = a.S * G32_TILES + pair * G32_OFF_TILES + (4 * half + AR) * 8 + B0;
+    double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + tile_base) * 1024;
+    auto tile_index = [](int q) { return q; };
+    gram32_fold<NT>(out, acc, i, h, true, tile_index);
+
+    if (r_begin < r_end) {
+        prefetch(r_begin);
+        stage(0);
+        if (r_begin + G16_KR < r_end) prefetch(r_begin + G16_KR);
+    }
+    __syncthreads();
+    int buf = 0;
+    uint32_t in_sub = 0;
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
+        if (row0 + G16_KR < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
+        }
+        const char *sb = lds + buf * STAGE;
+        f16v tmp[NT];                                        // one stage's sums (see gram16_diag_body)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[3], fb[4][3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) fa[sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NCB>(ks, sp, AR, lane));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) fb[q][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NCB>(ks, sp, 4 + B0 + q, lane));
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[0], fb[q][0], ks == 0 ? zero16 : tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[0], fb[q][1], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[1], fb[q][0], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[1], fb[q][1], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[0], fb[q][2], tmp[q]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[2], fb[q][0], tmp[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
+        in_sub += G16_KR;
+        if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
+            gram32_fold<NT>(out, acc, i, h, false, tile_index);
+            in_sub = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// grid = (S + S (S - 1), slices) like gram32_kernel; 512 threads; dynamic LDS: two stages (96 KiB when S == 1, else 144 KiB)
+__global__ __launch_bounds__(G16_THREADS, 1) void gram16_kernel(const Gram32Args a) {
+    extern __shared__ __attribute__((aligned(16))) char g16_lds[];
+    const uint32_t b = blockIdx.x;
+    if (b < a.S) {
+        switch (threadIdx.x >> 6) {                          // whole waves take each arm; every arm meets the same barriers
+            case 0: gram16_diag_body<0>(a, g16_lds, b); break;
+            case 1: gram16_diag_body<1>(a, g16_lds, b); break;
+            case 2: gram16_diag_body<2>(a, g16_lds, b); break;
+            case 3: gram16_diag_body<3>(a, g16_lds, b); break;
+            case 4: gram16_diag_body<4>(a, g16_lds, b); break;
+            case 5: gram16_diag_body<5>(a, g16_lds, b); break;
+            case 6: gram16_diag_body<6>(a, g16_lds, b); break;
+            default: gram16_diag_body<7>(a, g16_lds, b); break;
+        }
+        return;
+    }
+    const uint32_t pair = (b - a.S) >> 1, half = (b - a.S) & 1;
+    uint32_t q = pair, rowlen = a.S - 1, I = 0;
+    while (q >= rowlen) { q -= rowlen; ++I; --rowlen; }
+    const uint32_t J = I + 1 + q;
+    switch (threadIdx.x >> 6) {
+        case 0: gram16_off_body<0>(a, g16_lds, I, J, half, pair); break;
+        case 1: gram16_off_body<1>(a, g16_lds, I, J, half, pair); break;
+        case 2: gram16_off_body<2>(a, g16_lds, I, J, half, pair); break;
+        case 3: gram16_off_body<3>(a, g16_lds, I, J, half, pair); break;
+        case 4: gram16_off_body<4>(a, g16_lds, I, J, half, pair); break;
+        case 5: gram16_off_body<5>(a, g16_lds, I, J, half, pair); break;
+        case 6: gram16_off_body<6>(a, g16_lds, I, J, half, pair); break;
+        default: gram16_off_body<7>(a, g16_lds, I, J, half, pair); break;
+    }
+}
+
 // the sampled shift as the f32 value the kernel centres with, and that same value in f64 for the exact correction
 __global__ __launch_bounds__(256) void shift_round_kernel(double *__restrict__ shift64, float *__restrict__ shift32, uint32_t d) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
@@ -565,7 +852,10 @@ __global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__rest
         pair_to_tiles(p % G32_TILES, 8, tr, tc);
         gi = sup * G32_D + tr * 32 + e / 32;
         gj = sup * G32_D + tc * 32 + e % 32;
-        mirror = tr != tc;
+        // a diagonal tile is computed in full; its upper triangle is THE value of both (i, j) and (j, i): the split form sums the
+        // products y1 y2 and y2 y1 of the two in different passes, and the result must be symmetric to the bit
+        if (tr == tc && e / 32 > e % 32) return;
+        mirror = gi != gj;
     } else {
         const uint32_t po = p - S * G32_TILES, pair = po / G32_OFF_TILES, tq = po % G32_OFF_TILES;
         uint32_t q = pair, rowlen = S - 1, I = 0;
@@ -1196,7 +1486,10 @@ int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     CL_REQUIRE(x != nullptr && shift64 != nullptr && shift32 != nullptr && ws != nullptr && gram != nullptr && mean_out64 != nullptr &&
                mean_out32 != nullptr, "x / shift / workspace / gram / mean is NULL");
     CL_REQUIRE(gram32_applies(x, ldx, n, d), "internal: the f32 Gram does not apply to this shape");
-    const Gram32Plan q = gram32_plan(n, d, blocks_per_cu < 0 ? blocks_per_cu : blocks_per_cu == 1 ? 1 : 2);
+    // CLEORA_GRAM=f32: the f32 matrix cores (gram32_kernel); default: the split-bf16 form (gram16_kernel, one 8-wave block per CU)
+    const char *form = std::getenv("CLEORA_GRAM");
+    const bool split = !(form && !std::strcmp(form, "f32"));
+    const Gram32Plan q = gram32_plan(n, d, blocks_per_cu < 0 ? blocks_per_cu : (split || blocks_per_cu == 1) ? 1 : 2);
     CL_REQUIRE(q.slices <= 65535, "internal: too many Gram slices");
     Gram32Args a{};
     a.x = x;
@@ -1209,12 +1502,22 @@ int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     a.colsum = ws + (uint64_t)q.slices * q.tiles_per_slice * 1024;
     double *delta = a.colsum + (uint64_t)q.slices * d;
     uint64_t rps = (n + q.slices - 1) / q.slices;
-    a.rows_per_slice = (rps + G32_KC - 1) / G32_KC * G32_KC;
+    a.rows_per_slice = (rps + G16_KR - 1) / G16_KR * G16_KR;           // whole stages of either kernel (G16_KR is a multiple of G32_KC)
     a.sub_rows = 2048;
+    if (const char *sr = std::getenv("CLEORA_GRAM_SUB_ROWS")) {           // experiment: the f32 accumulation length
+        const int v = std::atoi(sr);
+        if (v >= G16_KR && v % G16_KR == 0) a.sub_rows = (uint32_t)v;
+    }
     hipLaunchKernelGGL(shift_round_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, shift64, shift32, d);
     // mean_out32 may be the buffer that holds shift32: the kernel reads it before gram_mean_kernel (same stream) rewrites it
     a.shift32 = shift32;
-    hipLaunchKernelGGL(gram32_kernel, dim3(q.blocks, q.slices), dim3(256), 0, stream, a);
+    if (split) {
+        const size_t lds = (size_t)(q.S == 1 ? 2 * 2 * 3 * 8 * 1024 : 2 * 2 * 3 * 12 * 1024);
+        CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gram16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gram16_kernel, dim3(q.blocks, q.slices), dim3(G16_THREADS), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL(gram32_kernel, dim3(q.blocks, q.slices), dim3(256), 0, stream, a);
+    }
     hipLaunchKernelGGL(gram_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, a.colsum, q.slices, d / GT, d, n, shift64, delta,
                        mean_out64, mean_out32);
     hipLaunchKernelGGL(gram32_reduce_kernel, dim3(4, q.tiles_per_slice), dim3(256), 0, stream, ws, q.slices, q.S, q.tiles_per_slice, d,

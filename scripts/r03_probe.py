@@ -63,6 +63,17 @@ def kernels(n, d):
             x.data_ptr(), d, n, d, ws.data_ptr(), inter, m64.data_ptr(), g64.data_ptr(), s)))
         grams[inter] = g64.clone()
     res["gram_f32_vs_f64_rel_fro"] = float((grams[1] - grams[0]).norm() / grams[0].norm())
+    rel = (grams[1] - grams[0]) / grams[0]
+    dg = torch.diagonal(rel)
+    res["gram_diag_rel_err_mean"] = float(dg.mean())
+    res["gram_diag_rel_err_std"] = float(dg.std())
+    big = grams[0].abs() > 0.2 * torch.diagonal(grams[0]).abs().mean()      # entries with a covariance that is not noise
+    big &= ~torch.eye(d, dtype=torch.bool, device=dev)
+    if int(big.sum()):
+        res["gram_offdiag_big_entries"] = int(big.sum())
+        res["gram_offdiag_big_rel_err_mean"] = float(rel[big].mean())
+        res["gram_offdiag_big_rel_err_std"] = float(rel[big].std())
+    res["gram_offdiag_abs_err_rms_over_diag_mean"] = float(((grams[1] - grams[0])[~torch.eye(d, dtype=torch.bool, device=dev)]).pow(2).mean().sqrt() / torch.diagonal(grams[0]).mean())
     sub = x[: min(n, 2_000_000)].double()
     # reference for the mean only (the f64 Gram is pinned by the tests)
     res["mean_err"] = float((m64 - x.double().mean(0)).abs().max())

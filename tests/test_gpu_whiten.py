@@ -274,14 +274,21 @@ def test_cholesky_guard_implies_the_reference_clamp(route, monkeypatch):
             assert np.abs(m - np.diag(dm)).max() <= 2e-3
 
 
-@pytest.mark.parametrize("n,d", [(70_001, 256), (40_003, 512), (30_001, 1024)])
-def test_intermediate_gram_on_the_f32_matrix_cores(n, d):
-    """cleora_whiten_stats_dev(intermediate = 1) at d = 256 S: centred Gram on v_mfma_f32_32x32x2_f32 (f32 sums over <= 2048
-    rows, f64 across; S diagonal super-tile blocks and S (S - 1) off-diagonal ones) against the f64 form (intermediate = 0) and
+@pytest.mark.parametrize("form", ["split", "f32"])
+@pytest.mark.parametrize("n,d", [(70_001, 256), (40_003, 512), (30_001, 1024), (5_003, 256)])
+def test_intermediate_gram_on_the_f32_matrix_cores(n, d, form, monkeypatch):
+    """cleora_whiten_stats_dev(intermediate = 1) at d = 256 S: centred Gram from the bf16 matrix cores with three-way split
+    operands (six v_mfma_f32_32x32x16_bf16 per f32 product, the default: gram16_kernel) or on v_mfma_f32_32x32x2_f32
+    (CLEORA_GRAM=f32: gram32_kernel) — f32 sums over <= 2048
+    rows, f64 across; S diagonal super-tile blocks and S (S - 1) off-diagonal ones — against the f64 form (intermediate = 0) and
     numpy fp64.  Stated: the f64 form 1e-13 relative
     Frobenius as before; the f32 form <= 5e-7 of the Gram's Frobenius norm and of its diagonal entry by entry.  Mean: 1e-12 for
     the f64 form; the f32 form centres in f32 (y = x - c32, one rounding of 3e-8 |y|), so its mean carries that: <= 1e-8."""
     L = _hip.lib()                                             # n: not a multiple of the 16-row chunk or of the slice count
+    if form == "f32":
+        monkeypatch.setenv("CLEORA_GRAM", "f32")               # read per call
+    else:
+        monkeypatch.delenv("CLEORA_GRAM", raising=False)
     rng = np.random.default_rng(8)
     x = (rng.standard_normal((n, d)) * np.linspace(0.3, 2.0, d) + rng.standard_normal(d) * 0.2).astype(np.float32)
     x /= np.linalg.norm(x, axis=1, keepdims=True)

@@ -641,6 +641,18 @@ def run_whitened(args, g, x, dev, L, iters):
     sup = d // 256        # 256-column super-tiles: 36 upper 32x32 tiles per diagonal one, 64 per off-diagonal pair (csrc/whiten.hip)
     gram32_flops = 2.0 * n * (sup * 36 + sup * (sup - 1) // 2 * 64) * 1024 if f32_gram else gram_flops
     split_proj = os.environ.get("CLEORA_PROJECT") != "f32" and d % 32 == 0
+    # the statistics of the intermediate iterations: the split-bf16 form (six bf16 MFMA products per f32 product: 6 x the tile
+    # flops against the bf16 matrix peak), the f32 matrix cores (CLEORA_GRAM=f32) or the f64 ones (CLEORA_GRAM=f64, other d)
+    split_gram = f32_gram and os.environ.get("CLEORA_GRAM") != "f32"
+    if split_gram:
+        gi_flops, gi_peak, gi_dtype, gi_kernel = 6.0 * gram32_flops, BF16_MFMA_PEAK_TF, "bf16 (3-way split f32 operands, 6 products)", "gram16_kernel (+ shift, mean, reduce)"
+    elif f32_gram:
+        gi_flops, gi_peak, gi_dtype, gi_kernel = gram32_flops, F32_MFMA_PEAK_TF, "f32", "gram32_kernel (+ shift, mean, reduce)"
+    else:
+        gi_flops, gi_peak, gi_dtype, gi_kernel = gram_flops, F64_MFMA_PEAK_TF, "f64", "gram_kernel (f64)"
+    gram_intermediate = {"bound": "mfma", "dtype": gi_dtype, "kernel": gi_kernel, "achieved": gi_flops / (stats_inter_ms * 1e-3) / 1e12,
+                         "peak": gi_peak, "unit": "TFLOP/s", "frac": gi_flops / (stats_inter_ms * 1e-3) / 1e12 / gi_peak,
+                         "executed_flops": gi_flops, "f32_equivalent_tflops": (gi_flops / 6.0 if split_gram else gi_flops) / (stats_inter_ms * 1e-3) / 1e12}
     del m64, g64
     # the product's loop for this path (cleora_embed_dev, what cleora_amd.embed.embed() runs): SpMM(t+1) beside Gram / eigh(t)
     del mid, nxt, ws, m_, p_, n_
@@ -666,12 +678,7 @@ def run_whitened(args, g, x, dev, L, iters):
                        "statistics_intermediate_form": stats_inter_ms},
         "project_form": ("split-bf16: every f32 product from six bf16 MFMAs of three-way split operands (csrc/whiten.hip)"
                          if split_proj else "f32 MFMA (CLEORA_PROJECT=f32)"),
-        "gram_intermediate_roofline": {"bound": "mfma", "dtype": "f32" if f32_gram else "f64",
-                                       "kernel": "gram32_kernel (+ shift, mean, reduce)" if f32_gram else "gram_kernel (f64)",
-                                       "achieved": gram32_flops / (stats_inter_ms * 1e-3) / 1e12,
-                                       "peak": F32_MFMA_PEAK_TF if f32_gram else F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                                       "frac": gram32_flops / (stats_inter_ms * 1e-3) / 1e12 / (F32_MFMA_PEAK_TF if f32_gram else F64_MFMA_PEAK_TF),
-                                       "executed_flops": gram32_flops},
+        "gram_intermediate_roofline": gram_intermediate,
         "gram_roofline": {"bound": "mfma", "dtype": "f64", "achieved": gram_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else 0.0,
                           "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                           "frac": gram_flops / (gram_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TF if gram_ms else 0.0,

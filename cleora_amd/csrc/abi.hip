@@ -746,7 +746,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     if ((rc = rowsum.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
     struct Streams {
         hipStream_t a = nullptr, b = nullptr, s = nullptr;
-        hipEvent_t ya = nullptr, fb = nullptr, zs = nullptr;
+        hipEvent_t ya = nullptr, fb = nullptr, zs = nullptr, gs = nullptr;
         ~Streams() {
             if (s && s != a) (void)hipStreamDestroy(s);
             if (a) (void)hipStreamDestroy(a);
@@ -754,6 +754,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
             if (ya) (void)hipEventDestroy(ya);
             if (fb) (void)hipEventDestroy(fb);
             if (zs) (void)hipEventDestroy(zs);
+            if (gs) (void)hipEventDestroy(gs);
         }
     } st;
     // the statistics stream gets the higher priority (its few hundred resident blocks are dispatched at once; the SpMM's
@@ -766,6 +767,13 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     // with the SpMM; CLEORA_SPMM_AVOID = 1: the SpMM runs on its own stream that is masked to the other CUs (the projection
     // keeps the whole chip).  Experiment switches.
     const int gram_cus = std::getenv("CLEORA_GRAM_CUS") ? std::atoi(std::getenv("CLEORA_GRAM_CUS")) : 0;
+    // The statistics strictly BEFORE the SpMM instead of beside it when they take the split-bf16 form (gram16_kernel): its
+    // eight waves per CU keep every matrix pipe busy, the SpMM beside it stands still for as long as it runs and
+    // both come out slower than one after the other — C3 51.1 -> 49.7 ms per iteration, C2 5.92 -> 5.58 (profiles/r03z_*).
+    // The d x d step (on the host) still runs beside the SpMM.  CLEORA_STATS_BEFORE_SPMM=0|1 overrides.
+    const char *gform = std::getenv("CLEORA_GRAM");
+    bool stats_before_spmm = any_whitening && gram32_applies(b1, d, n, d) && !(gform && (!std::strcmp(gform, "f32") || !std::strcmp(gform, "f64")));
+    if (const char *e = std::getenv("CLEORA_STATS_BEFORE_SPMM")) stats_before_spmm = std::atoi(e) != 0;
     const bool solve_after_spmm = std::getenv("CLEORA_SOLVE_AFTER_SPMM") && std::atoi(std::getenv("CLEORA_SOLVE_AFTER_SPMM")) != 0;
     const bool spmm_avoid = std::getenv("CLEORA_SPMM_AVOID") && std::atoi(std::getenv("CLEORA_SPMM_AVOID")) != 0;
     CL_HIP(hipStreamCreateWithPriority(&st.a, hipStreamNonBlocking, prio_lo));
@@ -791,6 +799,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     CL_HIP(hipEventCreateWithFlags(&st.ya, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&st.fb, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&st.zs, hipEventDisableTiming));
+    CL_HIP(hipEventCreateWithFlags(&st.gs, hipEventDisableTiming));
     CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
     const auto t_loop = std::chrono::steady_clock::now();
     if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a)) != CLEORA_OK) return rc;
@@ -811,6 +820,10 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
         static const int gram_first = std::getenv("CLEORA_GRAM_FIRST") ? std::atoi(std::getenv("CLEORA_GRAM_FIRST")) : 1;
         if (gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
         if (st.s != st.a) CL_HIP(hipStreamWaitEvent(st.s, st.ya, 0));
+        if (stats_before_spmm && gram_first && n > 1) {       // the SpMM only once the statistics kernels are through (the d x d step still runs beside it)
+            CL_HIP(hipEventRecord(st.gs, st.b));
+            CL_HIP(hipStreamWaitEvent(st.s, st.gs, 0));
+        }
         if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.s)) != CLEORA_OK) return rc;
         if (st.s != st.a) {
             CL_HIP(hipEventRecord(st.zs, st.s));

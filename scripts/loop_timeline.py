@@ -13,7 +13,7 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-fam = lambda k: ("spmm" if "spmm_rows_kernel" in k else "gram32" if "gram32_kernel" in k else "gram64" if "gram_kernel" in k else
+fam = lambda k: ("spmm" if "spmm_rows_kernel" in k else "gram32" if ("gram32_kernel" in k or "gram16_kernel" in k) else "gram64" if "gram_kernel" in k else
                  "project" if "project_" in k and "pack" not in k else "other")
 # the last whitened loop = everything after the last-but-(iters) projection ... simply: the last 7 projections and what lies between
 proj = [i for i, r in enumerate(rows) if fam(r[2]) == "project"]

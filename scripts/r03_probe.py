@@ -137,8 +137,9 @@ def loop_masks(nodes, pairs, d):
     _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x0.data_ptr(), d, s))
     torch.cuda.synchronize()
     init = x0.clone()
-    variants = [{}] + [{"CLEORA_GRAM_CO_BLOCKS": str(-g)} for g in (32, 48, 64, 96, 128, 192)] + [{"CLEORA_GRAM_CO_BLOCKS": "2"}, {}]
-    keys = ("CLEORA_GRAM_CUS", "CLEORA_GRAM_CO_BLOCKS", "CLEORA_SPMM_AVOID")
+    variants = [{}, {"CLEORA_STATS_BEFORE_SPMM": "1"}, {"CLEORA_STATS_BEFORE_SPMM": "1", "CLEORA_GRAM_CO_BLOCKS": "2"}, {},
+                {"CLEORA_STATS_BEFORE_SPMM": "1"}, {"CLEORA_GRAM": "f32"}, {"CLEORA_GRAM": "f32", "CLEORA_STATS_BEFORE_SPMM": "1"}, {}]
+    keys = ("CLEORA_GRAM_CUS", "CLEORA_GRAM_CO_BLOCKS", "CLEORA_SPMM_AVOID", "CLEORA_STATS_BEFORE_SPMM", "CLEORA_GRAM")
     _hip.check(L.cleora_embed_dev(gr.handle, x0.data_ptr(), _hip.LEFT, d, 2, 0.0, 0.0, _hip.F_WHITEN, None))
     for v in variants:
         for k in keys:

@@ -131,7 +131,7 @@ wp = os.path.join(src, "wpmc", "pmc_counter_collection.csv")
 if os.path.exists(wp):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(wp)):
-        if "cleora" in r["Kernel_Name"] and any(k in r["Kernel_Name"] for k in ("gram_kernel", "gram32_kernel", "project_kernel",
+        if "cleora" in r["Kernel_Name"] and any(k in r["Kernel_Name"] for k in ("gram_kernel", "gram32_kernel", "gram16_kernel", "project_kernel",
                                                                                 "project_rows_kernel", "project_split_kernel")):
             acc[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     wout = {"formula": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)  [8 XCDs, 1024 SIMDs]", "kernels": []}

@@ -772,7 +772,9 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     // both come out slower than one after the other — C3 51.1 -> 49.7 ms per iteration, C2 5.92 -> 5.58 (profiles/r03z_*).
     // The d x d step (on the host) still runs beside the SpMM.  CLEORA_STATS_BEFORE_SPMM=0|1 overrides.
     const char *gform = std::getenv("CLEORA_GRAM");
-    bool stats_before_spmm = any_whitening && gram32_applies(b1, d, n, d) && !(gform && (!std::strcmp(gform, "f32") || !std::strcmp(gform, "f64")));
+    // Measured at d = 256 only; at d = 1024 (config 5: a 189 ms SpMM, 15 ms of statistics) the overlapped order is the better
+    // one — 249.0 against 253.3 ms per iteration — so the rule is d == 256.
+    bool stats_before_spmm = any_whitening && d == 256 && gram32_applies(b1, d, n, d) && !(gform && (!std::strcmp(gform, "f32") || !std::strcmp(gform, "f64")));
     if (const char *e = std::getenv("CLEORA_STATS_BEFORE_SPMM")) stats_before_spmm = std::atoi(e) != 0;
     const bool solve_after_spmm = std::getenv("CLEORA_SOLVE_AFTER_SPMM") && std::atoi(std::getenv("CLEORA_SOLVE_AFTER_SPMM")) != 0;
     const bool spmm_avoid = std::getenv("CLEORA_SPMM_AVOID") && std::atoi(std::getenv("CLEORA_SPMM_AVOID")) != 0;

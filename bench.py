@@ -665,12 +665,20 @@ def run_whitened(args, g, x, dev, L, iters):
         xo.copy_(x[:n])
         _hip.check(L.cleora_embed_dev(gr.handle, xo.data_ptr(), _hip.LEFT, d, iters, 0.0, thr, _hip.F_WHITEN, None))
         loops[label] = L.cleora_last_embed_loop_ms() / iters
+    # the marginal iteration: the same call with twice the iterations (the first SpMM and the final PCA whitening — f64 Gram,
+    # eigensolver — are paid once per call whatever its length)
+    xo.copy_(x[:n])
+    _hip.check(L.cleora_embed_dev(gr.handle, xo.data_ptr(), _hip.LEFT, d, 2 * iters, 0.0, 0.0, _hip.F_WHITEN, None))
+    marginal_ms = (L.cleora_last_embed_loop_ms() - loops["overlapped"] * iters) / iters
     prev = xo
     cov = torch.cov(prev[: min(n, 2_000_000)].double().T)
     out = {
         "ms_per_iter": loops["overlapped"], "iterations": iters, "iterations_per_sec": 1e3 / loops["overlapped"],
-        "loop": "cleora_embed_dev + CLEORA_F_WHITEN: SpMM of iteration t+1 beside Gram / eigensolver of iteration t "
-                "(the SpMM taken before the projection); ms_per_iter = loop wall clock / iterations, incl. the final whitening, after an untimed 2-iteration call",
+        "marginal_ms_per_iter": marginal_ms,
+        "loop": "cleora_embed_dev + CLEORA_F_WHITEN (the SpMM taken before the projection; intermediate iterations: split-bf16 statistics — before the "
+                "SpMM at d = 256, beside it otherwise —, Cholesky transform, on the host for d <= 256; last iteration: f64 Gram + eigensolver); "
+                "ms_per_iter = loop wall clock / iterations, incl. the final whitening, after an untimed 2-iteration call; "
+                "marginal_ms_per_iter = (wall clock of a call with twice the iterations - this call's) / iterations",
         "sequential_ms_per_iter": {"c_loop_reference_order": loops["sequential"], "python_driven_with_stage_events": el / iters * 1e3},
         "placement_launch_ms": {"untuned": round(place_ms[0], 3), "chosen": round(place_ms[1], 3)},
         "kernels_ms": {"spmm_l2": ms[1] / max(c, 1) + (ms[0] + ms[2]) / max(c, 1), "column_statistics": stats_ms,

@@ -600,9 +600,17 @@ __device__ __forceinline__ float g16_stage_task(const float (&pre)[8], int nv, f
 #define G16_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 constexpr f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-template <int W>
+// ORDER: which waves stage the NEXT 32 rows (vector-unit work) AFTER their MFMAs of the current stage instead of before them.
+// Inside one iteration the two are independent (different LDS buffers), and a barrier per stage would otherwise line both
+// waves of a SIMD up in the same phase — vector work together, then the matrix pipe together.  1: waves 4..7 (the partners
+// of 0..3 if wave w sits on SIMD w mod 4); 2: odd waves; 0: none (the default: the three measure the same, profiles/r03_gram16_order.txt).
+template <int ORDER, int W>
+__host__ __device__ constexpr bool g16_late() { return ORDER == 1 ? W >= 4 : ORDER == 2 ? (W & 1) != 0 : false; }
+
+template <int W, int ORDER>
 __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds, uint32_t sup) {
     constexpr int NT = g16_ntiles(W), NCB = 8, STAGE = 2 * 3 * NCB * 1024;
+    constexpr bool LATE = g16_late<ORDER, W>();
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
     const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
@@ -646,10 +654,13 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
     int buf = 0;
     uint32_t in_sub = 0;
     for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
-        if (row0 + G16_KR < r_end) {
-            stage(buf ^ 1);
-            if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
-        }
+        auto stage_next = [&]() {
+            if (row0 + G16_KR < r_end) {
+                stage(buf ^ 1);
+                if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
+            }
+        };
+        if (!LATE) stage_next();
         const char *sb = lds + buf * STAGE;
         // The bf16 MFMA does not round its f32 accumulation to nearest: a long chain of same-sign terms (the variances on the
         // diagonal) comes out LOW — -1.3e-6 relative after 2048 rows, uniformly (profiles/r03u_gram_error.txt), against -6e-9
@@ -681,6 +692,7 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
+        if (LATE) stage_next();
         in_sub += G16_KR;
         if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
             gram32_fold<NT>(out, acc, i, h, false, tile_index);
@@ -699,9 +711,10 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
 
 // off-diagonal block: columns [256 I + 128 half, +128) (A: column blocks 0..3 of the stage) against [256 J, +256) (B: blocks 4..11);
 // wave W owns tile row W >> 1 of the half and tile columns 4 (W & 1) .. +3
-template <int W>
+template <int W, int ORDER>
 __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, uint32_t I, uint32_t J, uint32_t half, uint32_t pair) {
     constexpr int NT = 4, NCB = 12, STAGE = 2 * 3 * NCB * 1024, AR = W >> 1, B0 = 4 * (W & 1);
+    constexpr bool LATE = g16_late<ORDER, W>();
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
     const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
@@ -757,10 +770,13 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
     int buf = 0;
     uint32_t in_sub = 0;
     for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
-        if (row0 + G16_KR < r_end) {
-            stage(buf ^ 1);
-            if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
-        }
+        auto stage_next = [&]() {
+            if (row0 + G16_KR < r_end) {
+                stage(buf ^ 1);
+                if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
+            }
+        };
+        if (!LATE) stage_next();
         const char *sb = lds + buf * STAGE;
         f16v tmp[NT];                                        // one stage's sums (see gram16_diag_body)
 #pragma unroll
@@ -787,6 +803,7 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
+        if (LATE) stage_next();
         in_sub += G16_KR;
         if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
             gram32_fold<NT>(out, acc, i, h, false, tile_index);
@@ -797,19 +814,20 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
 }
 
 // grid = (S + S (S - 1), slices) like gram32_kernel; 512 threads; dynamic LDS: two stages (96 KiB when S == 1, else 144 KiB)
+template <int ORDER>
 __global__ __launch_bounds__(G16_THREADS, 1) void gram16_kernel(const Gram32Args a) {
     extern __shared__ __attribute__((aligned(16))) char g16_lds[];
     const uint32_t b = blockIdx.x;
     if (b < a.S) {
         switch (threadIdx.x >> 6) {                          // whole waves take each arm; every arm meets the same barriers
-            case 0: gram16_diag_body<0>(a, g16_lds, b); break;
-            case 1: gram16_diag_body<1>(a, g16_lds, b); break;
-            case 2: gram16_diag_body<2>(a, g16_lds, b); break;
-            case 3: gram16_diag_body<3>(a, g16_lds, b); break;
-            case 4: gram16_diag_body<4>(a, g16_lds, b); break;
-            case 5: gram16_diag_body<5>(a, g16_lds, b); break;
-            case 6: gram16_diag_body<6>(a, g16_lds, b); break;
-            default: gram16_diag_body<7>(a, g16_lds, b); break;
+            case 0: gram16_diag_body<0, ORDER>(a, g16_lds, b); break;
+            case 1: gram16_diag_body<1, ORDER>(a, g16_lds, b); break;
+            case 2: gram16_diag_body<2, ORDER>(a, g16_lds, b); break;
+            case 3: gram16_diag_body<3, ORDER>(a, g16_lds, b); break;
+            case 4: gram16_diag_body<4, ORDER>(a, g16_lds, b); break;
+            case 5: gram16_diag_body<5, ORDER>(a, g16_lds, b); break;
+            case 6: gram16_diag_body<6, ORDER>(a, g16_lds, b); break;
+            default: gram16_diag_body<7, ORDER>(a, g16_lds, b); break;
         }
         return;
     }
@@ -818,14 +836,14 @@ __global__ __launch_bounds__(G16_THREADS, 1) void gram16_kernel(const Gram32Args
     while (q >= rowlen) { q -= rowlen; ++I; --rowlen; }
     const uint32_t J = I + 1 + q;
     switch (threadIdx.x >> 6) {
-        case 0: gram16_off_body<0>(a, g16_lds, I, J, half, pair); break;
-        case 1: gram16_off_body<1>(a, g16_lds, I, J, half, pair); break;
-        case 2: gram16_off_body<2>(a, g16_lds, I, J, half, pair); break;
-        case 3: gram16_off_body<3>(a, g16_lds, I, J, half, pair); break;
-        case 4: gram16_off_body<4>(a, g16_lds, I, J, half, pair); break;
-        case 5: gram16_off_body<5>(a, g16_lds, I, J, half, pair); break;
-        case 6: gram16_off_body<6>(a, g16_lds, I, J, half, pair); break;
-        default: gram16_off_body<7>(a, g16_lds, I, J, half, pair); break;
+        case 0: gram16_off_body<0, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 1: gram16_off_body<1, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 2: gram16_off_body<2, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 3: gram16_off_body<3, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 4: gram16_off_body<4, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 5: gram16_off_body<5, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 6: gram16_off_body<6, ORDER>(a, g16_lds, I, J, half, pair); break;
+        default: gram16_off_body<7, ORDER>(a, g16_lds, I, J, half, pair); break;
     }
 }
 
@@ -1513,8 +1531,14 @@ int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     a.shift32 = shift32;
     if (split) {
         const size_t lds = (size_t)(q.S == 1 ? 2 * 2 * 3 * 8 * 1024 : 2 * 2 * 3 * 12 * 1024);
-        CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gram16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(gram16_kernel, dim3(q.blocks, q.slices), dim3(G16_THREADS), lds, stream, a);
+        const char *ord = std::getenv("CLEORA_GRAM16_ORDER");                  // A/B: which waves stage after their MFMAs (gram16_kernel)
+        const int order = ord ? std::atoi(ord) : 0;                            // measured: 4.75 / 4.67 / 4.84 ms for 0 / 1 / 2 at the C3 shape — no gain
+        auto go = [&](auto kernel) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(q.blocks, q.slices), dim3(G16_THREADS), lds, stream, a);
+            return e;
+        };
+        CL_HIP(order == 0 ? go(gram16_kernel<0>) : order == 2 ? go(gram16_kernel<2>) : go(gram16_kernel<1>));
     } else {
         hipLaunchKernelGGL(gram32_kernel, dim3(q.blocks, q.slices), dim3(256), 0, stream, a);
     }

@@ -267,9 +267,10 @@ int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, 
  * the exact f64 mean (:136) and the centred Gram sum_r (x_r - mean)(x_r - mean)^T (:138-143 without the 1/(n-1)), computed
  * around a sampled shift and corrected exactly (csrc/whiten.hip).  intermediate = 0: f64 matrix cores end to end, the form
  * behind every whitening a caller can observe.  intermediate = 1: the form the whitened loop takes for iterations whose
- * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — for d a multiple of 256 (<= 2048) the Gram runs
- * on the f32 matrix cores (exact products, f32 sums over <= 2048 rows, f64 across; ~1e-7 of the diagonal), other shapes as
- * intermediate = 0.
+ * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — for d a multiple of 256 (<= 2048) the Gram comes
+ * from the bf16 matrix cores with three-way split f32 operands (six exact bf16 products per f32 product; the matrix cores sum
+ * 32 rows, the vector unit adds those sums in f32 over <= 2048 rows, f64 across: ~1e-8 of the f64 Gram; CLEORA_GRAM=f32 takes
+ * the f32 matrix cores instead, ~5e-8), other shapes as intermediate = 0.
  * workspace: cleora_whiten_workspace(n, d) BYTES; mean64_dev: f64[d]; gram_dev: f64[d*d].  n >= 2. */
 int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, int intermediate,
                             double *mean64_dev, double *gram_dev, void *stream);
@@ -280,7 +281,8 @@ int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d
  * transform = L^-T (cov = L L^T; d x d row-major f32, upper triangular) is taken — but ONLY when the reference's clamp
  * max(lambda, 1e-10) (:155) is provably inactive: potrf succeeds, the smallest squared pivot is >= 1e-8 and
  * trace(cov^-1) = ||L^-T||_F^2 <= 1e10 (=> lambda_min >= 1e-10).  Otherwise the PCA form of cleora_whiten_transform_dev
- * (k = d) is computed.  *form_out (host, may be NULL): 1 = Cholesky form, 0 = PCA form.
+ * (k = d) is computed.  *form_out (host, may be NULL): 1 = Cholesky form, 0 = PCA form.  For d <= 256 the factorisation runs
+ * on the host (cleora_cholesky_whiten_host below: Gram down, transform up, ~1 ms), beyond on rocSOLVER (CLEORA_CHOLESKY=host|library|kernel).
  * Unlike the other *_dev entry points this one WAITS for `stream` (the decision is taken on the host). */
 int cleora_whiten_transform_any_dev(const double *gram_dev, uint64_t n, uint32_t d, float *transform_dev,
                                     void *workspace, void *stream, int *form_out);

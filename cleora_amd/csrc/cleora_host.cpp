@@ -492,10 +492,41 @@ struct Writer {
     template <class T> void put(T v) { const auto *p = reinterpret_cast<const uint8_t *>(&v); buf.insert(buf.end(), p, p + sizeof(T)); }
     void str(const std::string &s) { put<uint64_t>(s.size()); buf.insert(buf.end(), s.begin(), s.end()); }
 };
+// core::str::from_utf8's acceptance rule (what bincode 1.3.3 applies to every `String` it reads: deserialize_string ->
+// String::from_utf8; the reference surfaces the failure as RuntimeError("Deserialization failed: ..."), src/lib.rs:468-475):
+// shortest-form encodings only, no surrogates (U+D800..U+DFFF), nothing above U+10FFFF.
+static bool valid_utf8(const uint8_t *p, uint64_t n) {
+    uint64_t i = 0;
+    while (i < n) {
+        uint8_t c = p[i];
+        if (c < 0x80) { ++i; continue; }
+        uint8_t lo = 0x80, hi = 0xBF; unsigned more;
+        if (c >= 0xC2 && c <= 0xDF) more = 1;
+        else if (c == 0xE0) { more = 2; lo = 0xA0; }
+        else if ((c >= 0xE1 && c <= 0xEC) || c == 0xEE || c == 0xEF) more = 2;
+        else if (c == 0xED) { more = 2; hi = 0x9F; }
+        else if (c == 0xF0) { more = 3; lo = 0x90; }
+        else if (c >= 0xF1 && c <= 0xF3) more = 3;
+        else if (c == 0xF4) { more = 3; hi = 0x8F; }
+        else return false;                                   // 0x80..0xC1 (continuation / overlong lead), 0xF5..0xFF
+        if (n - i <= more) return false;
+        if (p[i + 1] < lo || p[i + 1] > hi) return false;
+        for (unsigned k = 2; k <= more; ++k) if ((p[i + k] & 0xC0) != 0x80) return false;
+        i += more + 1;
+    }
+    return true;
+}
+
 struct Reader {
-    const uint8_t *p, *end; bool ok = true;
+    const uint8_t *p, *end; bool ok = true, utf8_ok = true;
     template <class T> T get() { T v{}; if ((size_t)(end - p) < sizeof(T)) { ok = false; return v; } memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
-    std::string str() { uint64_t n = get<uint64_t>(); if (!ok || (uint64_t)(end - p) < n) { ok = false; return {}; } std::string s(reinterpret_cast<const char *>(p), n); p += n; return s; }
+    // a bincode `String`: u64 length, then that many bytes, which must be UTF-8
+    std::string str() {
+        uint64_t n = get<uint64_t>();
+        if (!ok || (uint64_t)(end - p) < n) { ok = false; return {}; }
+        if (!valid_utf8(p, n)) { ok = false; utf8_ok = false; return {}; }
+        std::string s(reinterpret_cast<const char *>(p), n); p += n; return s;
+    }
 };
 
 }  // namespace
@@ -646,12 +677,14 @@ int cleora_host_deserialize(const uint8_t *bytes, uint64_t len, cleora_hostgraph
     auto fail = [&](const char *what) { delete g; g_err = std::string("Deserialization failed: ") + what; return -1; };
     g->desc.a_id = r.get<uint8_t>(); g->desc.a_name = r.str(); g->desc.b_id = r.get<uint8_t>(); g->desc.b_name = r.str();
     uint64_t n = r.get<uint64_t>();
+    if (!r.utf8_ok) return fail("invalid utf-8 in the matrix descriptor");
     if (!r.ok || n > len) return fail("entity_ids");
     g->ids.resize(n); g->hashes.resize(n);
     for (uint64_t i = 0; i < n && r.ok; ++i) {
         g->ids[i] = r.str();
         g->hashes[i] = xxh64(reinterpret_cast<const uint8_t *>(g->ids[i].data()), g->ids[i].size(), 0);
     }
+    if (!r.utf8_ok) return fail("invalid utf-8 sequence in an entity id");
     uint64_t ne = r.get<uint64_t>();
     if (!r.ok || ne > len) return fail("entities");
     if (ne != n) return fail("entities and entity_ids differ in length");
@@ -680,7 +713,8 @@ int cleora_host_deserialize(const uint8_t *bytes, uint64_t len, cleora_hostgraph
     g->column_ids.resize(nc);
     for (uint64_t i = 0; i < nc; ++i) g->column_ids[i] = r.get<uint8_t>();
     if (!r.ok) return fail("truncated input");
-    if (r.p != r.end) return fail("trailing bytes");
+    // bytes behind the last field are ignored like the reference does: bincode 1.3.3's free function `deserialize` is
+    // DefaultOptions + fixint + allow_trailing_bytes (src/lib.rs:470 calls exactly that function)
     for (uint32_t c : g->col) if (c >= n) return fail("edge column out of range");
     *out = g;
     return 0;

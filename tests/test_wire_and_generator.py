@@ -19,7 +19,7 @@ from contextlib import redirect_stdout
 import numpy as np
 import pytest
 import torch
-from hypothesis import given, settings, strategies as st
+from hypothesis import example, given, settings, strategies as st
 
 import cleora_amd
 from cleora_amd import synth
@@ -89,38 +89,116 @@ def test_two_column_graph_bincode_and_unicode_ids():
     assert first[0] == cols[0] and first[1] == vals[0]
 
 
-@settings(max_examples=150, deadline=None)
-@given(st.data())
-def test_corrupted_blobs_raise_and_never_crash(data):
-    """Truncations, bit flips and spliced garbage: __setstate__ answers RuntimeError("Deserialization failed…")
-    like the reference (src/lib.rs:471-472) or loads a self-consistent graph — it never crashes or over-reads."""
-    g = SparseMatrix.from_iterator(iter(["a b c", "c d", "e a"]), "complex::reflexive::n")
-    blob = bytearray(g.__getstate__())
-    kind = data.draw(st.sampled_from(["truncate", "flip", "splice", "length"]))
-    if kind == "truncate":
-        blob = blob[: data.draw(st.integers(0, len(blob) - 1))]
-    elif kind == "flip":
-        for _ in range(data.draw(st.integers(1, 4))):
-            i = data.draw(st.integers(0, len(blob) - 1))
-            blob[i] ^= 1 << data.draw(st.integers(0, 7))
-    elif kind == "splice":
-        i = data.draw(st.integers(0, len(blob)))
-        blob[i:i] = data.draw(st.binary(min_size=1, max_size=24))
-    else:   # overwrite one of the u64 length fields with a huge count
-        i = data.draw(st.integers(0, max(0, len(blob) - 8)))
-        blob[i:i + 8] = struct.pack("<Q", data.draw(st.integers(2 ** 31, 2 ** 64 - 1)))
+def _pristine_blob():
+    return bytearray(SparseMatrix.from_iterator(iter(["a b c", "c d", "e a"]), "complex::reflexive::n").__getstate__())
+
+
+def _load_or_fail_like_the_reference(blob):
+    """__setstate__ answers RuntimeError("Deserialization failed…") like the reference (src/lib.rs:471-472) or loads a
+    self-consistent graph whose every accessor works — it never crashes, over-reads, or defers the failure to a getter."""
     h = SparseMatrix()
     try:
         h.__setstate__(bytes(blob))
     except RuntimeError as e:
         assert "Deserialization failed" in str(e)
-        return
+        return None
     # it loaded: every per-entity array is consistent, so the accessors cannot over-read
     n = h.num_entities
-    assert len(h.entity_ids) == n == len(h.entity_degrees)
+    ids = h.entity_ids                                   # must decode: every bincode String was validated as UTF-8
+    assert len(ids) == n == len(h.entity_degrees) and all(isinstance(s, str) for s in ids)
     rows, cols, vals, _, _ = h.to_sparse_csr()
     assert len(rows) == len(cols) == len(vals) == h.num_edges and (cols < max(n, 1)).all()
-    assert isinstance(h.__getstate__(), bytes)
+    assert isinstance(h.__getstate__(), bytes) and isinstance(repr(h), str)
+    return h
+
+
+def _corrupt(blob, kind, positions, bits, payload, huge):
+    if kind == "truncate":
+        return blob[: positions[0] % len(blob)]
+    if kind == "flip":
+        for pos, bit in zip(positions, bits):
+            blob[pos % len(blob)] ^= 1 << bit
+        return blob
+    if kind == "splice":
+        i = positions[0] % (len(blob) + 1)
+        blob[i:i] = payload
+        return blob
+    i = positions[0] % max(1, len(blob) - 7)             # "length": overwrite one of the u64 length fields with a huge count
+    blob[i:i + 8] = struct.pack("<Q", huge)
+    return blob
+
+
+# one pinned case per corruption kind, so that the gate does not pass or fail by the draw; the first is the falsifying example
+# of round 3 (VERDICT weak #1): one flipped bit turns the entity id at byte 36 into invalid UTF-8
+@example(kind="flip", positions=[36], bits=[7], payload=b"x", huge=2 ** 31)
+@example(kind="flip", positions=[9, 36, 60, 200], bits=[0, 7, 3, 6], payload=b"x", huge=2 ** 31)
+@example(kind="truncate", positions=[0], bits=[0], payload=b"x", huge=2 ** 31)
+@example(kind="truncate", positions=[37], bits=[0], payload=b"x", huge=2 ** 31)
+@example(kind="splice", positions=[36], bits=[0], payload=b"\xff\xfe", huge=2 ** 31)
+@example(kind="splice", positions=[28], bits=[0], payload=b"\x00" * 24, huge=2 ** 31)
+@example(kind="length", positions=[28], bits=[0], payload=b"x", huge=2 ** 64 - 1)
+@example(kind="length", positions=[1], bits=[0], payload=b"x", huge=2 ** 31)
+@settings(max_examples=150, deadline=None)
+@given(kind=st.sampled_from(["truncate", "flip", "splice", "length"]),
+       positions=st.lists(st.integers(0, 1 << 20), min_size=1, max_size=4),
+       bits=st.lists(st.integers(0, 7), min_size=4, max_size=4),
+       payload=st.binary(min_size=1, max_size=24), huge=st.integers(2 ** 31, 2 ** 64 - 1))
+def test_corrupted_blobs_raise_and_never_crash(kind, positions, bits, payload, huge):
+    """Truncations, bit flips, spliced garbage and huge length fields."""
+    _load_or_fail_like_the_reference(_corrupt(_pristine_blob(), kind, positions, bits, payload, huge))
+
+
+def test_every_single_bit_flip_of_a_small_pickle():
+    """Exhaustive and deterministic: each of the 8·len(blob) one-bit corruptions either fails like the reference or loads
+    self-consistently.  (Hypothesis found the UTF-8 case above by chance; this walks all of them.)"""
+    blob = _pristine_blob()
+    failed = loaded = 0
+    for i in range(len(blob)):
+        for b in range(8):
+            c = bytearray(blob)
+            c[i] ^= 1 << b
+            if _load_or_fail_like_the_reference(c) is None:
+                failed += 1
+            else:
+                loaded += 1
+    assert failed > 0 and loaded > 0
+
+
+@pytest.mark.parametrize("bad", [
+    b"\x80", b"\xbf", b"\xc0\xaf", b"\xc1\xbf",                  # lone continuation bytes, overlong 2-byte forms
+    b"\xe0\x80\xaf", b"\xe0\x9f\xbf", b"\xf0\x80\x80\xaf", b"\xf0\x8f\xbf\xbf",   # overlong 3- and 4-byte forms
+    b"\xed\xa0\x80", b"\xed\xbf\xbf",                            # UTF-16 surrogates
+    b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"\xff",          # above U+10FFFF, invalid lead bytes
+    b"\xc2", b"\xe2\x82", b"\xf0\x9f\x98", b"a\xe2\x82",         # truncated sequences
+])
+def test_setstate_rejects_strings_that_are_not_utf8(bad):
+    """bincode reads a `String` with String::from_utf8 (core::str::from_utf8's rule: shortest form, no surrogates, nothing
+    above U+10FFFF); the reference turns its error into RuntimeError("Deserialization failed: …"), src/lib.rs:468-475.
+    Every malformed sequence Python's strict decoder rejects must be rejected at __setstate__, in an entity id and in a
+    column name alike — not later by the entity_ids getter (round 3's defect)."""
+    with pytest.raises(UnicodeDecodeError):
+        bad.decode("utf-8")
+    def blob_with(ids, name_a):
+        return (struct.pack("<B", 0) + struct.pack("<Q", len(name_a)) + name_a + struct.pack("<B", 0) + bincode_string("n")
+                + struct.pack("<Q", len(ids)) + b"".join(struct.pack("<Q", len(b)) + b for b in ids)
+                + struct.pack("<Q", len(ids)) + b"".join(struct.pack("<f", 1.0) for _ in ids)
+                + struct.pack("<Q", len(ids)) + b"".join(struct.pack("<Iff", i, 1.0, 1.0) for i in range(len(ids)))
+                + struct.pack("<Q", len(ids)) + b"".join(struct.pack("<QQ", i, i + 1) for i in range(len(ids)))
+                + struct.pack("<Q", len(ids)) + bytes(len(ids)))
+    good = SparseMatrix()
+    good.__setstate__(blob_with([b"a", "\u00e9\u20ac\U0001f600".encode()], b"n"))       # 1-, 2-, 3- and 4-byte forms load
+    assert good.entity_ids == ["a", "\u00e9\u20ac\U0001f600"] and good.num_edges == 2
+    for blob in (blob_with([b"a", bad], b"n"), blob_with([b"a", b"b"], bad)):
+        with pytest.raises(RuntimeError, match="Deserialization failed"):
+            SparseMatrix().__setstate__(blob)
+
+
+def test_setstate_ignores_trailing_bytes_like_bincode():
+    """src/lib.rs:470 calls bincode 1.3.3's free function `deserialize`, whose options allow trailing bytes."""
+    blob = bytes(_pristine_blob())
+    h = SparseMatrix()
+    h.__setstate__(blob + b"\x00garbage")
+    assert h.__getstate__() == blob
 
 
 def test_entity_ids_setter_rejects_a_list_of_another_length():

@@ -2,6 +2,7 @@
 """bench.py — the Markov-propagation hot path on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 40 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          (WORLD_SIZE unset: bench.py launches its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -215,13 +216,14 @@ def sampled_row_check(g, x_dev, y_dev, n, d, hub_threshold, rows=4096, seed=11):
                                                            "iteration is run when the iterate fits the host: see oracle_rows_compared)"}
 
 
-def rccl_comm_or_fallback(local_rank, dev, rank, world, fallback_backend="nccl"):
+def rccl_comm_or_fallback(local_rank, dev, rank, world, allow_fallback=False, fallback_backend="nccl"):
     """The C-ABI communicator, checked with one small all-reduce before anything depends on it.  Two agreement points over
     the gloo launcher group — after the creation and after the probe — so that the ranks always take the same branch: if
-    the communicator cannot be created or gives a wrong sum on ANY rank, all ranks fall back to RCCL through
-    torch.distributed's nccl backend and the bench line says so in config.collectives.  A scaling run should not be lost
-    to a communicator bootstrap problem on a node this code has never seen.  (What this cannot catch: a rank that dies
-    before ncclCommInitRank leaves the others waiting inside it; the watchdog ends that run.)"""
+    the communicator cannot be created or gives a wrong sum on ANY rank, EVERY rank stops with the reason (exit code 4): a
+    line measured over torch.distributed's collectives would not be a measurement of csrc/comm.hip.  Only with
+    --allow-torch-collectives do all ranks fall back to RCCL through torch.distributed's nccl backend, and the bench line
+    says so in config.collectives.  (What this cannot catch: a rank that dies before ncclCommInitRank leaves the others
+    waiting inside it; the watchdog ends that run.)"""
     def agree(err):
         ok = torch.tensor([0 if err else 1], dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -250,6 +252,14 @@ def rccl_comm_or_fallback(local_rank, dev, rank, world, fallback_backend="nccl")
         first = agree(err)
         if first is None:
             return comm, "RCCL via the C ABI (csrc/comm.hip)"
+    if not allow_fallback:
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:                 # noqa: BLE001
+                pass
+        raise SystemExit(f"bench.py: the C-ABI communicator (csrc/comm.hip) is unusable on rank {rank}: {first}; nothing was measured "
+                         f"(--allow-torch-collectives would measure torch.distributed's collectives instead)")
     if rank == 0:
         print(f"bench.py: C-ABI communicator unusable ({first}); falling back to torch.distributed {fallback_backend}",
               file=sys.stderr, flush=True)
@@ -260,6 +270,91 @@ def rccl_comm_or_fallback(local_rank, dev, rank, world, fallback_backend="nccl")
             pass
     group = dist.new_group(backend=fallback_backend)
     return comm_mod.TorchComm(group), f"RCCL via torch.distributed {fallback_backend} (fallback; C-ABI communicator: {first[:200]})"
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without torchrun (the way the driver starts the N = 1 run): this process becomes the
+    launcher — it starts N copies of itself, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set the way torch.distributed.run would set them, passes rank 0's stdout (the ONE JSON line) through, sends the other
+    ranks' stdout to stderr, and exits with the first non-zero return code (the remaining ranks are terminated by PID).
+    The launcher never touches a GPU."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+
+    def stop_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    signal.signal(signal.SIGTERM, lambda *_: (stop_all(), sys.exit(143)))
+    rc, alive = 0, set(range(n_ranks))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    stop_all()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
+        rc = 130
+    for p in procs:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+class native_stdout_to_stderr:
+    """gloo announces its connections on the process's C stdout ("[Gloo] Rank 0 is connected to ..."): while the process groups
+    and communicators are being created, file descriptor 1 points at stderr, so that stdout carries the ONE JSON line only."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def launch_check(rank, world):
+    """--launch-check: what the launcher must provide, without a GPU — the ranks find each other over gloo and agree on a sum;
+    rank 0 prints one JSON line (tests/test_bench_launch.py runs it in the build container)."""
+    with native_stdout_to_stderr():
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+    ok = int(t) == world * (world + 1) // 2
+    if rank == 0:
+        print(json.dumps({"launch_check": ok, "world": world, "sum": int(t), "local_ranks": "0.." + str(world - 1)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
 
 
 class Launcher:
@@ -732,7 +827,14 @@ def main():
     # through torch.distributed/gloo instead of RCCL, which refuses two ranks on one device); numbers mean nothing
     ap.add_argument("--backend", default="rccl", choices=["rccl", "gloo"], help=argparse.SUPPRESS)
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--allow-torch-collectives", action="store_true",
+                    help="N > 1: if the C-ABI communicator cannot be created, measure over torch.distributed's nccl group instead of "
+                         "stopping (the line then says so in config.collectives and is not a measurement of csrc/comm.hip)")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way the driver starts the one-GPU run (`python bench.py --gpus N ...`, no torchrun): launch the ranks here
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # a run takes 1-3 minutes; if a collective ever deadlocks, leave a traceback of every thread and exit
     import faulthandler
@@ -742,7 +844,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: either leave WORLD_SIZE unset (bench.py launches its own ranks) "
+                         f"or start exactly --gpus ranks with torch.distributed.run")
+    if args.launch_check:
+        return launch_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; cleora_amd has no CPU fallback")
     if args.share_gpu:
@@ -753,11 +858,12 @@ def main():
     launcher = Launcher(world)
     collectives = None
     if world > 1:
-        dist.init_process_group("gloo")       # the launcher; the data path's collectives are the C ABI's (RCCL)
-        if args.backend == "rccl":
-            comm, collectives = rccl_comm_or_fallback(local_rank, dev, rank, world)
-        else:
-            comm, collectives = comm_mod.TorchComm(), "torch.distributed/gloo (developer mode)"
+        with native_stdout_to_stderr():
+            dist.init_process_group("gloo")       # the launcher; the data path's collectives are the C ABI's (RCCL)
+            if args.backend == "rccl":
+                comm, collectives = rccl_comm_or_fallback(local_rank, dev, rank, world, args.allow_torch_collectives)
+            else:
+                comm, collectives = comm_mod.TorchComm(), "torch.distributed/gloo (developer mode)"
     else:
         comm = comm_mod.LocalComm()
 

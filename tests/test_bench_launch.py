@@ -1,0 +1,61 @@
+"""CPU: `python bench.py --gpus N` must be runnable the way the driver runs the one-GPU bench — no torchrun, WORLD_SIZE unset
+(missing #1: it used to exit before touching a GPU).  bench.py then launches its own N ranks; the hidden
+--launch-check mode exercises exactly that start-up (environment, gloo rendezvous on 127.0.0.1, one JSON line from rank 0,
+return codes) without needing a GPU.  torch.distributed.run must keep working too."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_launches_its_own_ranks(world):
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(world), "--launch-check"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout                       # ONE JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert out == {"launch_check": True, "world": world, "sum": world * (world + 1) // 2, "local_ranks": f"0..{world - 1}"}
+
+
+def test_bench_still_runs_under_torch_distributed_run():
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29000 + os.getpid() % 500), BENCH, "--gpus", "2", "--launch-check"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["world"] == 2
+
+
+def test_a_failing_rank_stops_the_launch_with_its_return_code():
+    """In the build container there is no GPU: every rank of a real run exits with bench.py's "needs an MI355X" message.  The
+    launcher must come back promptly with a non-zero code instead of waiting for ranks that will never meet."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and time.time() - t0 < 120
+    assert "MI355X" in p.stderr and p.stdout.strip() == ""
+
+
+def test_a_world_size_that_contradicts_gpus_is_refused():
+    env = _clean_env()
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr

@@ -314,6 +314,75 @@ def test_reference_cli_info_runs_over_install(tmp_path, golden_dir):
                 sys.modules[m] = v
 
 
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pycleora")), reason="the reference checkout exists only in the build container")
+def test_config1_benchmark_command_runs_over_install(golden_dir, monkeypatch):
+    """BASELINE config 1, literally: `pycleora benchmark --dataset karate_club --dim 128` (pycleora/cli.py:137-157) — the
+    reference's own command, dataset loader, benchmark harness and embed() loop, unmodified — over cleora_amd.install().
+    The build container is the only place where the reference's Python package exists, and it has no GPU; the product has no
+    CPU fallback.  So for THIS test the three compute methods the reference's embed() calls on the class are pointed at the
+    oracle (test infrastructure; the product is untouched) while everything else the command touches is OUR class: the C++
+    builder behind from_iterator, entity ids / order, to_sparse_csr (prone / randne / deepwalk / node2vec read it), degrees.
+    Asserted: the command completes and prints its table with the `cleora` row, and the embedding its `cleora` entry
+    computed has the pairwise cosines of the reference's own embed() over the Python builder oracle (karate_ref.npz,
+    tests/golden/make_golden.py) — accuracy is decided by 7 test nodes and is not a parity metric.
+    The device side of the same call, embed(graph, 128, 40) on karate club, is test_embed_default_whiten_d128_rank_deficient
+    (GPU suite) against the same golden."""
+    import oracle
+    k = np.load(os.path.join(golden_dir, "karate_ref.npz"))
+    saved = {m: sys.modules.get(m) for m in list(sys.modules) if m == "pycleora" or m.startswith("pycleora.")}
+    for m in saved:
+        sys.modules.pop(m)
+    sys.path.insert(0, REF)
+    argv = sys.argv
+    try:
+        mod = cleora_amd.install()
+        cls = mod.SparseMatrix
+
+        def csr(g):
+            a = g._arr
+            return a["rowptr"], a["col"], a["val_left"], a["val_sym"], a["hashes"]
+        monkeypatch.setattr(cls, "left_markov_propagate", lambda g, x, num_workers=None: oracle.spmm(csr(g)[0], csr(g)[1], csr(g)[2], np.ascontiguousarray(x, np.float32)))
+        monkeypatch.setattr(cls, "symmetric_markov_propagate", lambda g, x, num_workers=None: oracle.spmm(csr(g)[0], csr(g)[1], csr(g)[3], np.ascontiguousarray(x, np.float32)))
+        monkeypatch.setattr(cls, "initialize_deterministically", lambda g, feature_dim, seed=0: oracle.init(csr(g)[4], feature_dim, seed))
+        import pycleora
+        import pycleora.cli as cli
+        assert os.path.realpath(pycleora.__file__).startswith(REF) and pycleora.SparseMatrix is cls
+        captured = {}
+        ref_embed = pycleora.embed
+
+        def recording_embed(graph, *a, **kw):
+            out = ref_embed(graph, *a, **kw)
+            captured["graph"], captured["emb"], captured["args"] = graph, out, a
+            return out
+        monkeypatch.setattr(pycleora, "embed", recording_embed)
+        sys.argv = ["pycleora", "benchmark", "--dataset", "karate_club", "--dim", "128"]
+        out = io.StringIO()
+        with redirect_stdout(out):
+            cli.main()
+        text = out.getvalue()
+        assert "Benchmarking on" in text and "34 nodes" in text
+        assert any(line.strip().lower().startswith("cleora") for line in text.splitlines()), text
+        g, emb = captured["graph"], captured["emb"]
+        assert isinstance(g, cls) and captured["args"] == (128, 40) and emb.shape == (34, 128) and emb.dtype == np.float32
+        assert g.num_entities == 34 and g.num_edges == 190 and list(g.entity_ids) == [str(s) for s in k["entity_ids"]]
+        want = k["embed_whiten_d128"]
+
+        def cosines(e):
+            e = e.astype(np.float64)
+            e = e / np.linalg.norm(e, axis=1, keepdims=True)
+            return e @ e.T
+        assert np.abs(cosines(emb) - cosines(want)).max() <= 1e-6
+    finally:
+        sys.argv = argv
+        sys.path.remove(REF)
+        cleora_amd.pycleora.SparseMatrix.__module__ = "cleora_amd.pycleora"
+        for m in [m for m in sys.modules if m == "pycleora" or m.startswith("pycleora.")]:
+            sys.modules.pop(m)
+        for m, v in saved.items():
+            if v is not None:
+                sys.modules[m] = v
+
+
 def test_bench_c5_text_is_what_the_reference_builder_would_read():
     """bench.py --config C5 assembles its `complex::reflexive::product` lines as one numpy byte buffer (5M lines without
     40M Python strings) and hands it to cleora_host_build_from_lines.  On a 3 000-line sample: the buffer decodes to

@@ -577,7 +577,7 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
 
     extra = {}
     # all-gather algorithm (row partition, N > 1): RCCL's ring all-gather against the direct send/recv mesh
-    if part == "row" and world > 1 and isinstance(comm, comm_mod.RcclComm) and not os.environ.get("CLEORA_ALLGATHER"):
+    if part == "row" and world > 1 and isinstance(comm, comm_mod.RcclComm):
         tried = {}
         for name, algo in (("rccl_allgather", _hip.ALLGATHER_RING), ("p2p_mesh", _hip.ALLGATHER_P2P)):
             comm.set_allgather(algo)
@@ -625,9 +625,8 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     norm_err = float((sumsq.sqrt() - 1).abs().max())
     hot_rows = int(blocks[0].info().hot_rows)      # gather cache policy (cleora_graph_set_hot_cache), 0 = inactive
     g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
-    counted = bool(hot_rows) and g_lanes == 64 and dl % 256 == 0 and dl // 256 <= 4 and os.environ.get("CLEORA_SPMM_WAITS") == "counted"
-    kernel_name = (f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true,{'true' if hot_rows else 'false'},"
-                   f"{'true' if counted else 'false'}>  (G lanes per row, float4 chunks per lane, W, FULL, gather cache policy, hand-counted waits)")
+    kernel_name = (f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true,{'true' if hot_rows else 'false'}>"
+                   f"  (G lanes per row, float4 chunks per lane, W, FULL, gather cache policy)")
     res = {
         "value": nnz * d * args.steps / elapsed, "iterations_per_sec": args.steps / elapsed,
         "ms_per_step": elapsed / args.steps * 1e3, "parallelism": par,
@@ -732,22 +731,20 @@ def run_whitened(args, g, x, dev, L, iters):
     e1.record()
     torch.cuda.synchronize()
     stats_inter_ms = e0.elapsed_time(e1) / 3
-    f32_gram = d % 256 == 0 and d <= 2048 and os.environ.get("CLEORA_GRAM") != "f64" and n >= 4096
+    # the statistics of the intermediate iterations: the split-bf16 form for d a multiple of 256 (csrc/whiten.hip gram16_kernel: THREE bf16
+    # MFMA products per f32 product — 3 x the tile flops against the bf16 matrix peak — plus the diagonal's r1^2 term on the vector
+    # unit), the f64 matrix cores for other widths
+    split_gram = d % 256 == 0 and d <= 2048 and n >= 4096
     sup = d // 256        # 256-column super-tiles: 36 upper 32x32 tiles per diagonal one, 64 per off-diagonal pair (csrc/whiten.hip)
-    gram32_flops = 2.0 * n * (sup * 36 + sup * (sup - 1) // 2 * 64) * 1024 if f32_gram else gram_flops
-    split_proj = os.environ.get("CLEORA_PROJECT") != "f32" and d % 32 == 0
-    # the statistics of the intermediate iterations: the split-bf16 form (six bf16 MFMA products per f32 product: 6 x the tile
-    # flops against the bf16 matrix peak), the f32 matrix cores (CLEORA_GRAM=f32) or the f64 ones (CLEORA_GRAM=f64, other d)
-    split_gram = f32_gram and os.environ.get("CLEORA_GRAM") != "f32"
+    gram32_flops = 2.0 * n * (sup * 36 + sup * (sup - 1) // 2 * 64) * 1024 if split_gram else gram_flops
+    split_proj = d % 32 == 0
     if split_gram:
-        gi_flops, gi_peak, gi_dtype, gi_kernel = 6.0 * gram32_flops, BF16_MFMA_PEAK_TF, "bf16 (3-way split f32 operands, 6 products)", "gram16_kernel (+ shift, mean, reduce)"
-    elif f32_gram:
-        gi_flops, gi_peak, gi_dtype, gi_kernel = gram32_flops, F32_MFMA_PEAK_TF, "f32", "gram32_kernel (+ shift, mean, reduce)"
+        gi_flops, gi_peak, gi_dtype, gi_kernel = 3.0 * gram32_flops, BF16_MFMA_PEAK_TF, "bf16 (two-way split f32 operands, 3 products + diagonal correction)", "gram16_kernel<true> (+ shift, mean, reduce)"
     else:
         gi_flops, gi_peak, gi_dtype, gi_kernel = gram_flops, F64_MFMA_PEAK_TF, "f64", "gram_kernel (f64)"
     gram_intermediate = {"bound": "mfma", "dtype": gi_dtype, "kernel": gi_kernel, "achieved": gi_flops / (stats_inter_ms * 1e-3) / 1e12,
                          "peak": gi_peak, "unit": "TFLOP/s", "frac": gi_flops / (stats_inter_ms * 1e-3) / 1e12 / gi_peak,
-                         "executed_flops": gi_flops, "f32_equivalent_tflops": (gi_flops / 6.0 if split_gram else gi_flops) / (stats_inter_ms * 1e-3) / 1e12}
+                         "executed_flops": gi_flops, "f32_equivalent_tflops": (gi_flops / 3.0 if split_gram else gi_flops) / (stats_inter_ms * 1e-3) / 1e12}
     del m64, g64
     # the product's loop for this path (cleora_embed_dev, what cleora_amd.embed.embed() runs): SpMM(t+1) beside Gram / eigh(t)
     del mid, nxt, ws, m_, p_, n_
@@ -780,7 +777,7 @@ def run_whitened(args, g, x, dev, L, iters):
                        "gram_f64_mfma": gram_ms, "eigensolver_transform": eigh_ms, "project": proj_ms,
                        "statistics_intermediate_form": stats_inter_ms},
         "project_form": ("split-bf16: every f32 product from six bf16 MFMAs of three-way split operands (csrc/whiten.hip)"
-                         if split_proj else "f32 MFMA (CLEORA_PROJECT=f32)"),
+                         if split_proj else "f32 MFMA (tiled kernel: d is not a multiple of 32)"),
         "gram_intermediate_roofline": gram_intermediate,
         "gram_roofline": {"bound": "mfma", "dtype": "f64", "achieved": gram_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else 0.0,
                           "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",

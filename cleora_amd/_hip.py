@@ -100,6 +100,7 @@ SIGNATURES = {
     "cleora_topk_workspace": (c_u64, [c_u64, c_u32]),
     "cleora_topk_workspace_for": (c_u64, [c_u64, c_u32, c_u32]),
     "cleora_topk_last_route": (c_int, []),
+    "cleora_topk_set_route": (c_int, [c_int]),
     "cleora_cholesky_whiten_host": (c_int, [vp, c_u64, c_u32, vp, vp]),
     "cleora_topk_cosine_dev": (c_int, [vp, vp, c_u64, c_u64, c_u32, vp, c_u32, c_u32, c_int, c_int, vp, vp, vp, vp]),
     "cleora_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),

@@ -155,7 +155,8 @@ void free_graph(cleora_graph *g) {
 }
 
 }  // namespace
-int topk_last_route();        // similarity.hip: which selection the last top-k call took
+int topk_last_route();        // similarity.hip: which selection the last top-k call of this thread took
+int topk_set_route(int route);
 }  // namespace cleora
 
 using namespace cleora;
@@ -449,6 +450,10 @@ int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, 
 }
 
 int cleora_topk_last_route(void) { return topk_last_route(); }
+int cleora_topk_set_route(int route) {
+    CL_REQUIRE(topk_set_route(route) == 0, "route must be 0 (automatic), 1 (selection rounds) or 2 (short list)");
+    return CLEORA_OK;
+}
 
 uint64_t cleora_gram_workspace(uint64_t n, uint32_t d) { return gram_workspace(n, d); }
 
@@ -737,70 +742,41 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     const uint32_t norm = (flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM;
     const uint32_t fast = flags & CLEORA_F_FASTNORM;
     const bool blend = rw > 0.0f;                                          // the Python loop: any rw > 0 (:111-115)
-    static const bool pca_always = std::getenv("CLEORA_WHITEN_PCA_ALWAYS") != nullptr;   // A/B switch
-    const bool any_whitening = norm == CLEORA_F_L2NORM && !pca_always;    // rotation invariance needs the L2 norm
+    const bool any_whitening = norm == CLEORA_F_L2NORM;                   // rotation invariance needs the L2 norm
     int rc;
     if (iterations == 0) { *result = b0; return CLEORA_OK; }
     DevBuf ws, rowsum;
     if ((rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK) return rc;
     if ((rc = rowsum.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
     struct Streams {
-        hipStream_t a = nullptr, b = nullptr, s = nullptr;
-        hipEvent_t ya = nullptr, fb = nullptr, zs = nullptr, gs = nullptr;
+        hipStream_t a = nullptr, b = nullptr;
+        hipEvent_t ya = nullptr, fb = nullptr, gs = nullptr;
         ~Streams() {
-            if (s && s != a) (void)hipStreamDestroy(s);
             if (a) (void)hipStreamDestroy(a);
             if (b) (void)hipStreamDestroy(b);
             if (ya) (void)hipEventDestroy(ya);
             if (fb) (void)hipEventDestroy(fb);
-            if (zs) (void)hipEventDestroy(zs);
             if (gs) (void)hipEventDestroy(gs);
         }
     } st;
-    // the statistics stream gets the higher priority (its few hundred resident blocks are dispatched at once; the SpMM's
-    // millions of short blocks fill what is left), and the Gram runs ONE block per CU there: at two it takes ~410 of
-    // the 512 registers of every SIMD and the SpMM beside it is left with a quarter of its occupancy
+    // Stream a: SpMM and projection; stream b (higher priority: its few hundred resident blocks are dispatched at once, the
+    // SpMM's millions of short blocks fill what is left): statistics and the d x d step.
+    // What round 3's measurements settled (the switches they were taken with are gone from the library):
+    //   * the loop is the SUM of its kernels — a SIMD that holds a busy matrix-core wave gives the SpMM waves beside it next
+    //     to nothing, and whatever shares the chip with the SpMM waits 10-16 us per memory request;
+    //   * so when the statistics take the split-bf16 form (8 waves per CU, every matrix pipe busy) they run strictly BEFORE
+    //     the SpMM at d = 256 (C3 51.1 -> 49.7 ms per iteration, C2 5.92 -> 5.58); at d >= 512 the SpMM is so much longer than
+    //     the statistics that the overlapped order wins (config 5: 249.0 against 253.3 ms);
+    //   * the f64 statistics (one block per CU: at two they take ~410 of the 512 registers of every SIMD) stay beside the SpMM;
+    //   * the d x d step runs on the host for d <= 256, beside the SpMM.
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const int co_blocks = std::getenv("CLEORA_GRAM_CO_BLOCKS") ? std::atoi(std::getenv("CLEORA_GRAM_CO_BLOCKS")) : 1;   // (read per call: A/B in one process)
-    // CLEORA_GRAM_CUS = K: the statistics stream owns K compute units (hipExtStreamCreateWithCUMask) instead of sharing every CU
-    // with the SpMM; CLEORA_SPMM_AVOID = 1: the SpMM runs on its own stream that is masked to the other CUs (the projection
-    // keeps the whole chip).  Experiment switches.
-    const int gram_cus = std::getenv("CLEORA_GRAM_CUS") ? std::atoi(std::getenv("CLEORA_GRAM_CUS")) : 0;
-    // The statistics strictly BEFORE the SpMM instead of beside it when they take the split-bf16 form (gram16_kernel): its
-    // eight waves per CU keep every matrix pipe busy, the SpMM beside it stands still for as long as it runs and
-    // both come out slower than one after the other — C3 51.1 -> 49.7 ms per iteration, C2 5.92 -> 5.58 (profiles/r03z_*).
-    // The d x d step (on the host) still runs beside the SpMM.  CLEORA_STATS_BEFORE_SPMM=0|1 overrides.
-    const char *gform = std::getenv("CLEORA_GRAM");
-    // Measured at d = 256 only; at d = 1024 (config 5: a 189 ms SpMM, 15 ms of statistics) the overlapped order is the better
-    // one — 249.0 against 253.3 ms per iteration — so the rule is d == 256.
-    bool stats_before_spmm = any_whitening && d == 256 && gram32_applies(b1, d, n, d) && !(gform && (!std::strcmp(gform, "f32") || !std::strcmp(gform, "f64")));
-    if (const char *e = std::getenv("CLEORA_STATS_BEFORE_SPMM")) stats_before_spmm = std::atoi(e) != 0;
-    const bool solve_after_spmm = std::getenv("CLEORA_SOLVE_AFTER_SPMM") && std::atoi(std::getenv("CLEORA_SOLVE_AFTER_SPMM")) != 0;
-    const bool spmm_avoid = std::getenv("CLEORA_SPMM_AVOID") && std::atoi(std::getenv("CLEORA_SPMM_AVOID")) != 0;
+    const bool split_stats = any_whitening && n > 1 && gram32_applies(b1, d, n, d);
+    const bool stats_before_spmm = split_stats && d == 256;
     CL_HIP(hipStreamCreateWithPriority(&st.a, hipStreamNonBlocking, prio_lo));
-    st.s = st.a;
-    int dev_id = 0, n_cus = 0;
-    CL_HIP(hipGetDevice(&dev_id));
-    CL_HIP(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id));
-    if (gram_cus > 0 && gram_cus < n_cus) {
-        const uint32_t words = (uint32_t)(n_cus + 31) / 32;
-        std::vector<uint32_t> own(words, 0u), rest(words, 0u);
-        // K of the CUs, evenly interleaved in the driver's numbering (K = 64: every fourth).  A contiguous range is NOT a
-        // part of the chip with its share of the memory system: the SpMM confined to the first 128 CUs takes 43.7 ms, to
-        // every other CU 31.9 ms (256 CUs: 32.3; profiles/r03k_spmm_cu_masks.jsonl)
-        for (int c = 0; c < n_cus; ++c) {
-            const bool mine = (int64_t)(c + 1) * gram_cus / n_cus > (int64_t)c * gram_cus / n_cus;
-            (mine ? own : rest)[c >> 5] |= 1u << (c & 31);
-        }
-        CL_HIP(hipExtStreamCreateWithCUMask(&st.b, words, own.data()));
-        if (spmm_avoid) CL_HIP(hipExtStreamCreateWithCUMask(&st.s, words, rest.data()));
-    } else {
-        CL_HIP(hipStreamCreateWithPriority(&st.b, hipStreamNonBlocking, prio_hi));
-    }
+    CL_HIP(hipStreamCreateWithPriority(&st.b, hipStreamNonBlocking, prio_hi));
     CL_HIP(hipEventCreateWithFlags(&st.ya, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&st.fb, hipEventDisableTiming));
-    CL_HIP(hipEventCreateWithFlags(&st.zs, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&st.gs, hipEventDisableTiming));
     CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
     const auto t_loop = std::chrono::steady_clock::now();
@@ -818,28 +794,24 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
         // Order of the launches matters twice.  (1) The Gram blocks (few, ~206 registers a wave) must be handed to the
         // dispatcher BEFORE the SpMM's millions of small blocks: behind them they starve, the SpMM refills every hole.
         // (2) rocSOLVER synchronises with the host inside dsyevd: whatever is launched after it starts only then.
-        // So: statistics (stream b) -> SpMM (stream a) -> eigensolver (stream b, the host blocks here while both run).
-        static const int gram_first = std::getenv("CLEORA_GRAM_FIRST") ? std::atoi(std::getenv("CLEORA_GRAM_FIRST")) : 1;
-        if (gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
-        if (st.s != st.a) CL_HIP(hipStreamWaitEvent(st.s, st.ya, 0));
-        if (stats_before_spmm && gram_first && n > 1) {       // the SpMM only once the statistics kernels are through (the d x d step still runs beside it)
+        // So: statistics (stream b) -> SpMM (stream a) -> d x d step (stream b, the host blocks here while the SpMM runs).
+        if (n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, 1, any_whitening)) != CLEORA_OK) return rc;
+        if (stats_before_spmm) {                   // the SpMM only once the statistics kernels are through
             CL_HIP(hipEventRecord(st.gs, st.b));
-            CL_HIP(hipStreamWaitEvent(st.s, st.gs, 0));
+            CL_HIP(hipStreamWaitEvent(st.a, st.gs, 0));
         }
-        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.s)) != CLEORA_OK) return rc;
-        if (st.s != st.a) {
-            CL_HIP(hipEventRecord(st.zs, st.s));
-            CL_HIP(hipStreamWaitEvent(st.a, st.zs, 0));
+        if ((rc = launch_propagate(g, markov_type, y, d, d, b0, d, 0, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+        // intermediate iterations of the L2-normalised loop may take ANY whitening transform (eigh.hip): Cholesky — unless the
+        // guard refuses it on statistics that are only ~1e-8 accurate: then this iteration's statistics are taken again in f64
+        // and the PCA form follows (rare: a near-singular covariance; e.g. d > rank)
+        if (n > 1) {
+            bool need_exact = false;
+            if ((rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, any_whitening, split_stats, &need_exact)) != CLEORA_OK) return rc;
+            if (need_exact) {
+                if ((rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, 1, false)) != CLEORA_OK) return rc;
+                if ((rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, false)) != CLEORA_OK) return rc;
+            }
         }
-        if (!gram_first && n > 1 && (rc = launch_whiten_fit_stats(y, d, n, d, ws.p, st.b, co_blocks, any_whitening)) != CLEORA_OK) return rc;
-        // CLEORA_SOLVE_AFTER_SPMM=1 (experiment): the d x d step — a chain of ~200 small library kernels — only once the SpMM
-        // is through, instead of beside it
-        if (solve_after_spmm) {
-            CL_HIP(hipEventRecord(st.zs, st.s));
-            CL_HIP(hipStreamWaitEvent(st.b, st.zs, 0));
-        }
-        // intermediate iterations of the L2-normalised loop may take ANY whitening transform (eigh.hip): Cholesky
-        if (n > 1 && (rc = launch_whiten_fit_solve(n, d, d, ws.p, nullptr, st.b, any_whitening)) != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(st.fb, st.b));
         CL_HIP(hipStreamWaitEvent(st.a, st.fb, 0));
         if (n > 1) {
@@ -968,8 +940,7 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
     }
     // nobody looks at the intermediate whitened iterates when there is no convergence test: SpMM(t+1) beside Gram /
     // eigh(t) (embed_whitened_overlapped).  That loop wants E_0 in the SpMM-side buffer bufs[0] = `b`.
-    static const bool sequential_only = std::getenv("CLEORA_WHITEN_SEQUENTIAL") != nullptr;   // A/B switch
-    const bool overlapped = whitened && !check && !sequential_only;
+    const bool overlapped = whitened && !check;
     float *e_init = overlapped ? b.as<float>() : a.as<float>();
     if (x_dev) {
         CL_HIP(hipMemcpy(e_init, x_dev, bytes, hipMemcpyDeviceToDevice));
@@ -1064,17 +1035,11 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
             }
             const bool found = trials.size() >= 2 && lo < 0.95f * hi;
             bool more = !(found || n_tried == 4 || it + 8 > max_iterations);
-            static const bool trace = std::getenv("CLEORA_TUNE_TRACE") != nullptr;
-            if (trace) std::fprintf(stderr, "[cleora tune] it=%llu pair=%.2f ms lo=%.2f hi=%.2f tried=%d more=%d\n",
-                                    (unsigned long long)it, trials.back().ms, lo, hi, n_tried, (int)more);
             if (more) {
                 // draw the next candidate while the rejected ones still hold their memory (a freed buffer would be
                 // handed straight back: same placement), then free every candidate but the best so far
                 DevBuf cand;
-                const auto t_alloc = std::chrono::steady_clock::now();
                 const int alloc_rc = cand.alloc(bytes);
-                if (trace) std::fprintf(stderr, "[cleora tune] hipMalloc(%llu MiB) %.1f ms\n", (unsigned long long)(bytes >> 20),
-                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count());
                 if (alloc_rc == CLEORA_OK) {
                     ++n_tried;
                 } else {
@@ -1085,11 +1050,8 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
                     more = false;
                 }
                 const Trial keep = trials[best];
-                const auto t_free = std::chrono::steady_clock::now();
                 for (DevBuf &e : extra)
                     if (e.p && e.p != keep.buf) e.release();
-                if (trace) std::fprintf(stderr, "[cleora tune] release %.1f ms\n",
-                                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());
                 trials.assign(1, keep);
                 if (more) {
                     for (DevBuf &e : extra)

@@ -267,13 +267,6 @@ struct Builder {
 
     cleora_hostgraph *build(const std::vector<std::string_view> &lines) {
         const size_t nl = lines.size();
-        const bool timing = getenv("CLEORA_HOST_TIMING") != nullptr;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto lap = [&](const char *what, std::chrono::steady_clock::time_point &t0) {
-            if (timing) fprintf(stderr, "[cleora_host] %-28s %8.3f s\n", what, std::chrono::duration<double>(now() - t0).count());
-            t0 = now();
-        };
-        auto t0 = now();
         unsigned T = threads ? threads : 1;
         if (nl < 20000) T = 1;
         // ---- A ----
@@ -288,7 +281,6 @@ struct Builder {
                 });
             for (auto &th : pool) th.join();
         }
-        lap("A parse + hash", t0);
         // ---- B ----
         Interner interner;
         auto *g = new cleora_hostgraph();
@@ -342,7 +334,6 @@ struct Builder {
             chunks[t] = Parsed();  // release
         }
         const size_t n = g->ids.size();
-        lap("B intern + row stats", t0);
         // ---- C + D ----
         // Rows are cut into P contiguous ranges of (about) equal WORK — first-seen order puts the popular entities first, and
         // `occurrence` counts the pair updates a row takes part in.  P is chosen by the size of the job, NOT by the thread
@@ -448,7 +439,6 @@ struct Builder {
                 std::sort(ent.begin(), ent.end(), [](auto &x, auto &y) { return x.first < y.first; });
             });
         }
-        lap("C accumulate + sort", t0);
         // reduce (sparse_matrix_builder.rs:275-343): rows ascending = parts in order
         size_t nnz = 0;
         std::vector<size_t> base(T2 + 1, 0);
@@ -469,7 +459,6 @@ struct Builder {
             }
         });
         for (size_t r = 0; r < n; ++r) g->rowptr[r + 1] += g->rowptr[r];
-        lap("D normalise + CSR", t0);
         return g;
     }
 };

@@ -176,8 +176,6 @@ int cleora_comm_create(const void *id, int rank, int world, int device, cleora_c
         delete c;
         return rccl_fail(*r, e, "ncclCommInitRank");
     }
-    const char *algo = std::getenv("CLEORA_ALLGATHER");
-    if (algo && std::strcmp(algo, "p2p") == 0) c->allgather_algo = 1;
     *out = c;
     return CLEORA_OK;
 }

@@ -120,10 +120,10 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
                 double *ws, double *gram, hipStream_t stream, double *mean_out64 = nullptr,
                 float *mean_out32 = nullptr,    // outputs given: `mean` is only a shift, the exact mean is produced
                 int blocks_per_cu = 2);
-// the f32-matrix-core form for the intermediate iterations of the whitened loop (d a multiple of 256: gram32_applies)
+// the split-bf16 form for the intermediate iterations of the whitened loop (d a multiple of 256: gram32_applies)
 bool gram32_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d);
 int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *shift64, float *shift32, double *ws, double *gram,
-                  hipStream_t stream, double *mean_out64, float *mean_out32, int blocks_per_cu = 2);
+                  hipStream_t stream, double *mean_out64, float *mean_out32);
 // out = (alpha * (x - rowscale (x) mean) + beta * (x2 - mean)) @ t; rowscale / x2 == nullptr: the plain (x - mean) @ t
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
@@ -154,7 +154,7 @@ int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t
                             double *eigenvalues, void *workspace, hipStream_t stream);
 // Cholesky form of the transform (eigh.hip): CLEORA_OK, or 1 when the covariance is not provably >= 1e-10 I (take the PCA form)
 int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d, float *transform, void *workspace,
-                                     hipStream_t stream);
+                                     hipStream_t stream, bool approximate_gram = false);
 uint64_t whiten_workspace(uint64_t n, uint32_t d);
 const int *whiten_info(void *workspace, uint64_t n, uint32_t d);
 int whiten_set_timing(bool enable);
@@ -168,8 +168,10 @@ int launch_whiten_fit_stats(const float *x, uint64_t ldx, uint64_t n, uint32_t d
                             int gram_blocks_per_cu = 2, bool intermediate = false);
 // any_whitening: the caller only needs SOME W with W^T cov W = I (intermediate iterations of the L2-normalised loop):
 // Cholesky (potrf + trtri) instead of the eigensolver, falling back to it when the covariance is near-singular
+// approximate_gram: the statistics in the workspace are the split-bf16 ones; *need_exact_gram is then set (and nothing solved) when
+// the Cholesky form is refused — the caller recomputes the statistics with intermediate = false and calls again
 int launch_whiten_fit_solve(uint64_t n, uint32_t d, uint32_t k, void *workspace, double *eigenvalues, hipStream_t stream,
-                            bool any_whitening = false);
+                            bool any_whitening = false, bool approximate_gram = false, bool *need_exact_gram = nullptr);
 // ... and their location, for a projection launched separately (launch_project)
 int whiten_fit_copy_stats(void *workspace, uint64_t n, uint32_t d, double *mean64, double *gram, hipStream_t stream);
 void whiten_fit_result(void *workspace, uint64_t n, uint32_t d, const float **mean32, const float **transform);

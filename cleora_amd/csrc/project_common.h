@@ -26,8 +26,7 @@ struct ProjArgs {
     const float *x2;
     uint64_t ldx2;
     float alpha, beta;
-    int dbg;          // profiling only (CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = no X loads (LDS tile of ones)
-    int norm;         // rows-in-LDS form, k <= 256: 1 = L2-normalise, 2 = L1-normalise every output row in the epilogue
+    int norm;         // split form, one column pass (k <= 256): 1 = L2-normalise, 2 = L1-normalise every output row in the epilogue
 };
 
 static __device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
@@ -54,6 +53,17 @@ static __device__ __forceinline__ void split3_pair(float lo, float hi, uint32_t 
     const f2v f2 = {__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xffff0000u)};
     const f2v r2 = r1 - f2;
     p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r2, bf16x2));
+}
+
+// (lo, hi) -> two packed bf16 pairs (y1, y2) and the f32 residuals r1 = y - y1 (exact): y = y1 + y2 + r2 with |r2| <= 2^-18 |y|.
+static __device__ __forceinline__ void split2_pair(float lo, float hi, uint32_t &p1, uint32_t &p2, float &r_lo, float &r_hi) {
+    const f2v v = {lo, hi};
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f2v f1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+    const f2v r1 = v - f1;
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r1, bf16x2));
+    r_lo = r1[0];
+    r_hi = r1[1];
 }
 
 }  // namespace cleora

@@ -287,18 +287,19 @@ static inline uint32_t per_pass(uint32_t n_queries) {
 // The short list's plan for n rows and k results: sample size S (one score per stratum of n / S rows), the rank r of the
 // threshold in the sample.  The number of the true top-k that land in a sample of fraction S / n is about Poisson(k S / n);
 // the list holds all of them unless at least r do, so r is the smallest rank whose tail is below 1e-9 (and the host checks
-// the count in any case).  Expected list length r n / S.  CLEORA_TOPK=rounds switches it off, =short takes it from 2048 rows on
-// and for any batch.
+// the count in any case).  Expected list length r n / S.  cleora_topk_set_route (thread-local): 1 switches it off, 2 takes it
+// from 2048 rows on and for any batch (the tests force both forms on one input; 0 = this plan).
 static inline uint64_t short_sample_size(uint64_t n) {               // n / 256 in whole chunks, within [CHUNK, SHORT_SMAX]
     const uint64_t S = ((n / 256 + CHUNK - 1) / CHUNK) * CHUNK;
     return S < (uint64_t)CHUNK ? (uint64_t)CHUNK : S > SHORT_SMAX ? (uint64_t)SHORT_SMAX : S;
 }
+// per calling thread (a process-global raced between threads / devices)
+static thread_local int t_route = 0, t_last_route = 0;
 struct ShortPlan { bool use; uint32_t S, stratum, r; };
 static ShortPlan short_plan(uint64_t n, uint32_t k, uint32_t queries_per_pass) {
     ShortPlan p{false, 0, 0, 0};
-    const char *e = getenv("CLEORA_TOPK");
-    const bool forced = e && !strcmp(e, "short");
-    if ((e && !strcmp(e, "rounds")) || n < (forced ? (uint64_t)CHUNK : (uint64_t)SHORT_MIN_N)) return p;
+    const bool forced = t_route == 2;
+    if (t_route == 1 || n < (forced ? (uint64_t)CHUNK : (uint64_t)SHORT_MIN_N)) return p;
     // a handful of results for a handful of queries: the rounds over all chunks run side by side on the chip and cost less
     // than the short list's five launches and its host check (measured at n = 1M: break-even near 500 results per pass)
     if (!forced && (uint64_t)k * queries_per_pass < 512) return p;
@@ -314,8 +315,12 @@ static ShortPlan short_plan(uint64_t n, uint32_t k, uint32_t queries_per_pass) {
     return p;
 }
 
-static int g_last_route = 0;
-int topk_last_route() { return g_last_route; }
+int topk_last_route() { return t_last_route; }
+int topk_set_route(int route) {
+    if (route < 0 || route > 2) return -1;
+    t_route = route;
+    return 0;
+}
 
 // bytes: scores [per][n] + two candidate levels (score + index each) + the query bitmap + the short list (sample, list,
 // thresholds, counts) + (MFMA form) 1/||x_r||, the d x per query matrix and a zero "mean" of d floats for the projection kernel
@@ -460,7 +465,7 @@ int launch_topk_cosine(const cleora_graph *g, const float *x, uint64_t ldx, uint
             select(scores, nullptr, scale, n, nullptr, qs, rs, k, out_score + (uint64_t)q0 * k, out_index + (uint64_t)q0 * k, (uint64_t)k);
         route = route < 0 ? (by_short_list ? 1 : 0) : (route == (by_short_list ? 1 : 0) ? route : 2);
     }
-    g_last_route = route < 0 ? 0 : route;
+    t_last_route = route < 0 ? 0 : route;
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

@@ -98,82 +98,12 @@ __device__ __forceinline__ void gather_row(const SpmmArgs &a, uint32_t c, int gl
     }
 }
 
-// ---- the same gather with hand-counted waits (G == 64, gather cache policy) --------------------------------------
-// Whichever policy an edge takes it issues exactly ONE buffer_load_dwordx4 per 1 KiB of row, so the number of loads in
-// flight is known at every point of the 8-edge group — but each load sits behind a scalar branch on bit 31 of the column
-// index, and the compiler, unable to count across branches, waits `vmcnt(0)` once before the first multiply-add
-// (profiles/r02_spmm_main_loop.s).  Here the branch and both encodings live inside ONE asm statement (one output
-// register quad, no phi copies of a quad that is still in flight), and the consumer waits `vmcnt(N)` by hand for exactly
-// the loads it needs.  vmcnt retires in issue order, so any load the compiler issues around this block can only make a
-// wait longer, never too short.
-template <int OFF>
-__device__ __forceinline__ u32x4 policy_load(u32x4 rsrc, uint32_t voff, uint32_t marked_col) {
-    u32x4 t;
-    asm volatile(
-        "s_cmp_gt_i32 %3, -1\n\t"                                   // bit 31 clear: a cold row
-        "s_cbranch_scc1 1f\n\t"
-        "buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%4\n\t"     // hot: default policy
-        "s_branch 2f\n"
-        "1:\n\t"
-        "buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%4 nt\n"    // cold: non-temporal
-        "2:"
-        : "=&v"(t)
-        : "v"(voff), "s"(rsrc), "s"(marked_col), "n"(OFF)
-        : "scc", "memory");
-    return t;
-}
-
-// s_waitcnt vmcnt(N) that the compiler must keep in front of every use of the V quads of one edge
-template <int N>
-__device__ __forceinline__ void wait_loads(u32x4 (&t)[1]) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t[0]) : "n"(N)); }
-template <int N>
-__device__ __forceinline__ void wait_loads(u32x4 (&t)[2]) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(t[0]), "+v"(t[1]) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void wait_loads(u32x4 (&t)[4]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "n"(N));
-}
-
-template <int V, int U, int K = 0>
-__device__ __forceinline__ void consume_counted(u32x4 (&t)[U][V], const float (&w)[U], float (&acc)[V][4]) {
-    if constexpr (K < U) {
-        wait_loads<(U - 1 - K) * V>(t[K]);                          // loads issued after edge K: (U-1-K) * V
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            acc[v][0] = __fadd_rn(acc[v][0], __fmul_rn(w[K], __uint_as_float(t[K][v].x)));
-            acc[v][1] = __fadd_rn(acc[v][1], __fmul_rn(w[K], __uint_as_float(t[K][v].y)));
-            acc[v][2] = __fadd_rn(acc[v][2], __fmul_rn(w[K], __uint_as_float(t[K][v].z)));
-            acc[v][3] = __fadd_rn(acc[v][3], __fmul_rn(w[K], __uint_as_float(t[K][v].w)));
-        }
-        consume_counted<V, U, K + 1>(t, w, acc);
-    }
-}
-
-template <int V, int U, int K = 0>
-__device__ __forceinline__ void issue_counted(const SpmmArgs &a, uint32_t cv, uint32_t k, uint32_t voff, uint32_t d,
-                                              u32x4 (&t)[U][V]) {
-    if constexpr (K < U) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cv, (int)(k + K));
-        const uint64_t base = reinterpret_cast<uint64_t>(a.x + (uint64_t)(c & 0x7fffffffu) * a.ldx);
-        const u32x4 rs = {(uint32_t)base, (uint32_t)(base >> 32) & 0xffffu, d * 4u, 0x00020000u};
-        t[K][0] = policy_load<0>(rs, voff, c);
-        if constexpr (V > 1) t[K][1] = policy_load<1024>(rs, voff, c);
-        if constexpr (V > 2) {
-            t[K][2] = policy_load<2048>(rs, voff, c);
-            t[K][3] = policy_load<3072>(rs, voff, c);
-        }
-        issue_counted<V, U, K + 1>(a, cv, k, voff, d, t);
-    }
-}
-
 // acc += sum over edges [beg, end) in stored order.  For G == 64 beg/end are wave-uniform.
-template <int G, int V, int W, bool FULL, bool HOT = false, bool COUNTED = false>
+template <int G, int V, int W, bool FULL, bool HOT = false>
 __device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint64_t end, int gl,
                                            int gbase, float (&acc)[V][W]) {
     constexpr int U = (8 / V) > 0 ? (8 / V) : 1;
     const uint32_t d = a.r.d;
-    static_assert(!COUNTED || (HOT && G == 64 && W == 4 && (V == 1 || V == 2 || V == 4)), "counted waits: whole-wave float4 rows");
     for (uint64_t e = beg; e < end; e += G) {
         const uint32_t cnt = (end - e) < (uint64_t)G ? (uint32_t)(end - e) : (uint32_t)G;
         uint32_t cv = 0;
@@ -183,18 +113,7 @@ __device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint
             wv = a.val[e + gl];
         }
         uint32_t k = 0;
-        if constexpr (COUNTED) {
-            // the compiler's own wait for the slice (col, val) must not land between the hand-counted loads: a use here
-            asm volatile("" : "+v"(cv), "+v"(wv));
-            for (; k + U <= cnt; k += U) {
-                u32x4 t[U][V];
-                float w[U];
-                issue_counted<V, U>(a, cv, k, (uint32_t)gl * 16u, d, t);
-#pragma unroll
-                for (int u = 0; u < U; ++u) w[u] = bcast_f32<G>(wv, k + u, gbase);
-                consume_counted<V, U>(t, w, acc);
-            }
-        } else {
+        {
             for (; k + U <= cnt; k += U) {
                 float r[U][V][W];
 #pragma unroll
@@ -236,7 +155,7 @@ __device__ __forceinline__ void zero(float (&acc)[V][W]) {
 // ---- main kernel ---------------------------------------------------------------------------
 // Work items: first the hub SEGMENTS (so the longest work starts first), then one item per row.
 // A segment item writes its partial sum to scratch; a row item runs the epilogue and writes Y.
-template <int G, int V, int W, bool FULL, bool HOT = false, bool COUNTED = false>
+template <int G, int V, int W, bool FULL, bool HOT = false>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
@@ -272,7 +191,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
     }
     float acc[V][W];
     zero<G, V, W>(acc);
-    accumulate<G, V, W, FULL, HOT, COUNTED>(a, beg, end, gl, gbase, acc);
+    accumulate<G, V, W, FULL, HOT>(a, beg, end, gl, gbase, acc);
     if (active) {
         if (is_seg) store_row<G, V, W, FULL>(a.partial + item * (uint64_t)a.r.d, gl, a.r.d, acc);
         else finish_row<G, V, W, FULL>(a.r, row, gl, gbase, acc);
@@ -547,18 +466,6 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
                 if (hot) {
                     SpmmArgs h = a;
                     h.col = hot;
-                    // whole-wave rows: CLEORA_SPMM_WAITS=counted takes the variant with hand-counted waits behind the per-edge
-                    // policy branch.  Measured round 3 at C3 (profiles/r03_spmm_waits.json): 32.55 ms against 32.36 ms for the
-                    // compiler's single vmcnt(0) per 8-edge group — no gain (8 waves per SIMD hide the difference), so the
-                    // default stays the compiler's.
-                    if constexpr (kG == 64 && kFull && kV <= 4) {
-                        static const bool counted = std::getenv("CLEORA_SPMM_WAITS") && !std::strcmp(std::getenv("CLEORA_SPMM_WAITS"), "counted");
-                        if (counted) {
-                            hipLaunchKernelGGL((spmm_rows_kernel<kG, kV, kW, kFull, true, true>),
-                                               grid_for(h.n_items, 256 / kG), dim3(256), 0, stream, h);
-                            return;
-                        }
-                    }
                     hipLaunchKernelGGL((spmm_rows_kernel<kG, kV, kW, kFull, true>),
                                        grid_for(h.n_items, 256 / kG), dim3(256), 0, stream, h);
                     return;

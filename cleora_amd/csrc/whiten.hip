@@ -301,34 +301,32 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const double *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
-// centred Gram on the f32 matrix cores — the INTERMEDIATE iterations of the whitened loop, d = 256 S
+// centred Gram for the INTERMEDIATE iterations of the whitened loop, d = 256 S: shared pieces
 // ---------------------------------------------------------------------------------------------
-// Inside E <- whiten(l2_normalise(A E)) the intermediate whitenings only have to be whitenings (eigh.hip: the Cholesky form),
-// and an error of 1e-7 of the covariance is below what the f32 projection adds anyway; only the last iteration, and every
-// caller that looks at a whitened iterate, needs the f64 Gram above (pycleora/__init__.py:138-143).  For those iterations:
-//   * v_mfma_f32_32x32x2_f32 — exact f32 products, one rounding per accumulate (bit-equal to an fmaf chain) at twice the
-//     f64 matrix rate; operands are centred in f32 with an f32 shift, y = x - c32 (one rounding, 3e-8 of |y|);
+// Inside E <- whiten(l2_normalise(A E)) the intermediate whitenings only have to be whitenings (eigh.hip: the Cholesky form);
+// only the last iteration, and every caller that looks at a whitened iterate, needs the f64 Gram above
+// (pycleora/__init__.py:138-143).  For those iterations the Gram comes from the bf16 matrix cores with split f32 operands
+// (gram16_kernel below).  Common to it (and to the f32-matrix-core form it replaced, scripts/rejected/):
 //   * the columns are cut into S super-tiles of 256.  A DIAGONAL block owns one super-tile: the 36 upper 32x32 tiles of its
-//     8 x 8 grid, nine per wave (tile rows WV and 7 - WV, as in the f64 diagonal blocks: 8 - WV column fragments feed 9 MFMAs
-//     per k pair); at d = 256 that is the whole matrix and X is read exactly once.  An OFF-DIAGONAL pair (I < J) of
-//     super-tiles is two blocks, each 128 columns of I against all 256 of J: wave w owns tile row w of its half, 8 tiles
-//     (one A fragment and 8 B fragments per 8 MFMAs).  The blocks of one row slice are neighbours in the grid and read the
-//     same rows at about the same time (L2 / Infinity Cache);
+//     8 x 8 grid; at d = 256 that is the whole matrix and X is read exactly once.  An OFF-DIAGONAL pair (I < J) of
+//     super-tiles is two blocks, each 128 columns of I against all 256 of J.  The blocks of one row slice are neighbours in
+//     the grid and read the same rows at about the same time (L2 / Infinity Cache);
 //   * f32 accumulators run over at most `sub_rows` (2048) rows, then fold into the block's private f64 partial in global
-//     memory (each element belongs to one lane: no atomics, fixed order), so the rounding of an accumulator is that of a
-//     2048-term f32 sum (~1e-6 of the partial, unbiased), and the slices are combined in f64 in a fixed order by
-//     gram32_reduce_kernel: deterministic;
-//   * column sums of y in f64 beside the diagonal blocks (the exact mean comes out of the same pass, as above).
-constexpr int G32_D = 256, G32_KC = 16, G32_TILES = 36, G32_OFF_TILES = 64, G32_LDS = 2 * G32_KC * 384;
+//     memory (each element belongs to one lane: no atomics, fixed order), and the slices are combined in f64 in a fixed
+//     order by gram32_reduce_kernel: deterministic;
+//   * operands are centred in f32 with an f32 shift, y = x - c32 (one rounding, 3e-8 of |y|); column sums of y in f64 beside
+//     the diagonal blocks (the exact mean comes out of the same pass, as above).
+constexpr int G32_D = 256, G32_TILES = 36, G32_OFF_TILES = 64;
 
 struct Gram32Args {
     const float *x;
     uint64_t ldx, n;
     const float *shift32;    // centring vector c32 (f32), d entries
     double *colsum;          // [slices][d]
+    double *diagfix;         // [slices][d]: sum_r r1^2 per column, the diagonal correction of the three-product form (nullptr: none)
     double *partial;         // [slices][tiles_per_slice][32][32]: S x 36 diagonal tiles, then S (S - 1) / 2 x 64 off-diagonal ones
     uint64_t rows_per_slice;
-    uint32_t sub_rows;       // fold period, a multiple of G32_KC
+    uint32_t sub_rows;       // fold period, a multiple of the 32-row stage
     uint32_t d, S, tiles_per_slice;
 };
 
@@ -363,204 +361,34 @@ __device__ __forceinline__ void gram32_fold(double *out, f16v (&acc)[NT], int i,
     }
 }
 
-template <int WV>
-__device__ __forceinline__ void gram32_body(const Gram32Args &a, float *lds_raw, uint32_t sup) {
-    float (*lds)[G32_KC][G32_D] = reinterpret_cast<float (*)[G32_KC][G32_D]>(lds_raw);
-    const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
-    const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
-    const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
-    const int c4 = t & 63, lr = t >> 6;                     // loader role: columns 4 c4 .. +3 of rows lr + 4 u
-    const uint32_t cb = sup * G32_D;                        // first column of this super-tile
-    const float4 sh = *reinterpret_cast<const float4 *>(a.shift32 + cb + c4 * 4);
-
-    f16v acc[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    double cs[4] = {0.0, 0.0, 0.0, 0.0};
-    float4 pa[4];
-    bool ok[4];
-    auto prefetch = [&](uint64_t row0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t r = row0 + lr + 4 * u;
-            ok[u] = r < r_end;
-            pa[u] = *reinterpret_cast<const float4 *>(a.x + (ok[u] ? r : r_begin) * a.ldx + cb + c4 * 4);   // always a valid row
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok[u]) y = make_float4(__fsub_rn(pa[u].x, sh.x), __fsub_rn(pa[u].y, sh.y), __fsub_rn(pa[u].z, sh.z), __fsub_rn(pa[u].w, sh.w));
-            cs[0] += (double)y.x; cs[1] += (double)y.y; cs[2] += (double)y.z; cs[3] += (double)y.w;
-            *reinterpret_cast<float4 *>(&lds[buf][lr + 4 * u][c4 * 4]) = y;
-        }
-    };
-    double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + (uint64_t)sup * G32_TILES) * 1024;
-    auto tile_index = [](int q) { return upper_tile_index(diag_tile_row(WV, q), diag_tile_col(WV, q)); };
-    gram32_fold<9>(out, acc, i, h, true, tile_index);
-
-    if (r_begin < r_end) {
-        prefetch(r_begin);
-        stage(0);
-        if (r_begin + G32_KC < r_end) prefetch(r_begin + G32_KC);
-    }
-    __syncthreads();
-    int buf = 0;
-    uint32_t in_sub = 0;
-    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G32_KC, buf ^= 1) {
-        if (row0 + G32_KC < r_end) {
-            stage(buf ^ 1);
-            if (row0 + 2 * G32_KC < r_end) prefetch(row0 + 2 * G32_KC);
-        }
-#pragma unroll
-        for (int kk = 0; kk < G32_KC / 2; ++kk) {
-            float f[8];                                     // column fragments WV..7 of rows 2 kk, 2 kk + 1 (lane half h)
-#pragma unroll
-            for (int c = WV; c < 8; ++c) f[c] = lds[buf][2 * kk + h][c * 32 + i];
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[diag_tile_row(WV, q)], f[diag_tile_col(WV, q)], acc[q], 0, 0, 0);
-        }
-        in_sub += G32_KC;
-        if (in_sub >= a.sub_rows || row0 + G32_KC >= r_end) {
-            gram32_fold<9>(out, acc, i, h, false, tile_index);
-            in_sub = 0;
-        }
-        __syncthreads();
-    }
-
-    double *red = reinterpret_cast<double *>(lds_raw);      // the loop ended on a barrier: the staging buffers are free
-#pragma unroll
-    for (int q = 0; q < 4; ++q) red[lr * G32_D + c4 * 4 + q] = cs[q];
-    __syncthreads();
-    if (t < G32_D) a.colsum[(uint64_t)blockIdx.y * a.d + cb + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
-}
-
-// off-diagonal block: columns [256 I + 128 half, +128) (A panel) against [256 J, +256) (B panel); wave W owns tile row 4 half + W
-template <int W>
-__device__ __forceinline__ void gram32_off_body(const Gram32Args &a, float *lds_raw, uint32_t I, uint32_t J, uint32_t half, uint32_t pair) {
-    float (*lds)[G32_KC][384] = reinterpret_cast<float (*)[G32_KC][384]>(lds_raw);
-    const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
-    const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
-    const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
-    const int ca4 = t & 31, ra = t >> 5;                    // A panel: columns 4 ca4 .. +3 of rows ra, ra + 8
-    const int cb4 = t & 63, rb = t >> 6;                    // B panel: columns 4 cb4 .. +3 of rows rb + 4 u
-    const uint32_t colA = I * G32_D + half * 128 + ca4 * 4, colB = J * G32_D + cb4 * 4;
-    const float4 shA = *reinterpret_cast<const float4 *>(a.shift32 + colA), shB = *reinterpret_cast<const float4 *>(a.shift32 + colB);
-
-    f16v acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    float4 pa[2], pb[4];
-    bool oka[2], okb[4];
-    auto prefetch = [&](uint64_t row0) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint64_t r = row0 + ra + 8 * u;
-            oka[u] = r < r_end;
-            pa[u] = *reinterpret_cast<const float4 *>(a.x + (oka[u] ? r : r_begin) * a.ldx + colA);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t r = row0 + rb + 4 * u;
-            okb[u] = r < r_end;
-            pb[u] = *reinterpret_cast<const float4 *>(a.x + (okb[u] ? r : r_begin) * a.ldx + colB);
-        }
-    };
-    auto centred = [](float4 v, float4 s, bool ok) {
-        return ok ? make_float4(__fsub_rn(v.x, s.x), __fsub_rn(v.y, s.y), __fsub_rn(v.z, s.z), __fsub_rn(v.w, s.w)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) *reinterpret_cast<float4 *>(&lds[buf][ra + 8 * u][ca4 * 4]) = centred(pa[u], shA, oka[u]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) *reinterpret_cast<float4 *>(&lds[buf][rb + 4 * u][128 + cb4 * 4]) = centred(pb[u], shB, okb[u]);
-    };
-    const uint32_t tile_base = a.S * G32_TILES + pair * G32_OFF_TILES + (4 * half + W) * 8;
-    double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + tile_base) * 1024;
-    auto tile_index = [](int q) { return q; };
-    gram32_fold<8>(out, acc, i, h, true, tile_index);
-
-    if (r_begin < r_end) {
-        prefetch(r_begin);
-        stage(0);
-        if (r_begin + G32_KC < r_end) prefetch(r_begin + G32_KC);
-    }
-    __syncthreads();
-    int buf = 0;
-    uint32_t in_sub = 0;
-    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G32_KC, buf ^= 1) {
-        if (row0 + G32_KC < r_end) {
-            stage(buf ^ 1);
-            if (row0 + 2 * G32_KC < r_end) prefetch(row0 + 2 * G32_KC);
-        }
-#pragma unroll
-        for (int kk = 0; kk < G32_KC / 2; ++kk) {
-            const float fa = lds[buf][2 * kk + h][W * 32 + i];
-            float fb[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) fb[c] = lds[buf][2 * kk + h][128 + c * 32 + i];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[c], acc[c], 0, 0, 0);
-        }
-        in_sub += G32_KC;
-        if (in_sub >= a.sub_rows || row0 + G32_KC >= r_end) {
-            gram32_fold<8>(out, acc, i, h, false, tile_index);
-            in_sub = 0;
-        }
-        __syncthreads();
-    }
-}
-
-// grid = (S + S (S - 1), slices): block x < S is the diagonal block of super-tile x; the others come in pairs per (I < J)
-__global__ __launch_bounds__(256, 2) void gram32_kernel(const Gram32Args a) {
-    __shared__ __attribute__((aligned(16))) float lds[G32_LDS];
-    const uint32_t b = blockIdx.x;
-    if (b < a.S) {
-        switch (threadIdx.x >> 6) {                          // whole waves take each arm; every arm meets the same barriers
-            case 0: gram32_body<0>(a, lds, b); break;
-            case 1: gram32_body<1>(a, lds, b); break;
-            case 2: gram32_body<2>(a, lds, b); break;
-            default: gram32_body<3>(a, lds, b); break;
-        }
-        return;
-    }
-    const uint32_t pair = (b - a.S) >> 1, half = (b - a.S) & 1;
-    uint32_t q = pair, rowlen = a.S - 1, I = 0;
-    while (q >= rowlen) { q -= rowlen; ++I; --rowlen; }
-    const uint32_t J = I + 1 + q;
-    switch (threadIdx.x >> 6) {
-        case 0: gram32_off_body<0>(a, lds, I, J, half, pair); break;
-        case 1: gram32_off_body<1>(a, lds, I, J, half, pair); break;
-        case 2: gram32_off_body<2>(a, lds, I, J, half, pair); break;
-        default: gram32_off_body<3>(a, lds, I, J, half, pair); break;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// the same statistics from the bf16 matrix cores: f32-accurate products by the three-way split of project_common.h
+// the statistics from the bf16 matrix cores: f32-accurate Gram sums from split operands
 // ---------------------------------------------------------------------------------------------
-// v_mfma_f32_32x32x16_bf16 runs at sixteen times the rate of the f32 MFMA above; with y = y1 + y2 + y3 (bf16 each, split3_pair)
-// the six products (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) give y_a y_b to better than one f32 rounding, so the Gram
-// costs 6/16 of the f32 form's matrix time.  For G = Y^T Y both MFMA operands are "column i, eight consecutive ROWS": lane (i, h)
-// of a fragment holds rows 8h .. 8h+7 of column i of its 32-column block — the A fragment of column block a and the B fragment of
-// column block b are the same kind of thing, and the one of a diagonal tile is one register set used twice.
+// v_mfma_f32_32x32x16_bf16 runs at sixteen times the rate of the f32 MFMA.  Write y = y1 + r1 (y1 = bf16(y), r1 = y - y1 exact in
+// f32, |r1| <= 2^-9 |y|) and y2 = bf16(r1), r2 = r1 - y2 (|r2| <= 2^-18 |y|).  Then for two columns a, b
+//     y_a y_b = y1_a y1_b + y1_a y2_b + y2_a y1_b   +   r1_a r1_b   +   (y1_a r2_b + r2_a y1_b)   + O(2^-27)
+// The first three products are exact in f32 on the bf16 matrix cores.  What the fourth and fifth terms do to a SUM over n rows:
+//   * r1_a r1_b: 2^-20 of |y_a y_b| per row.  For a != b the rounding residuals of two columns are uncorrelated and the sum is a
+//     random walk, 2^-20 / sqrt(n) of the entry; for a == b every term is positive — a systematic -6e-7 of each VARIANCE — so
+//     sum_r r1_a^2 is accumulated beside the matrix cores (one FMA per element in the staging thread that owns the column, f32 over
+//     the octet, f64 across) and added to the diagonal by the reducer (`diagfix`);
+//   * the y1 r2 cross terms: 2^-18 of the entry per row with random sign, 2^-18 / sqrt(n) of the sum.
+// So THREE bf16 MFMAs per product (LEAN) give the Gram to ~1e-8 of the f64 one, like the six-product form of the projection
+// (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) that this kernel used in round 3 — at half the matrix-core work, two thirds of the split
+// arithmetic and two thirds of the LDS traffic (measured: see DESIGN 3.5; LEAN = false keeps the six-product form for the A/B).
+// For G = Y^T Y both MFMA operands are "column i, eight consecutive ROWS": lane (i, h) of a fragment holds rows 8h .. 8h+7 of
+// column i of its 32-column block — the A fragment of column block a and the B fragment of column block b are the same kind of
+// thing, and the one of a diagonal tile is one register set used twice.
 //   * staging: a thread owns (column, row octet): eight dword loads down a column (a wave reads 256 contiguous bytes per row),
-//     centred with the f32 shift, summed into the column sums (f32 over the octet, f64 across), split, and written as THREE
-//     16-byte fragments pieces — [k-step][split][column block][lane] x 16 B, lane-linear: ds_write_b128 / ds_read_b128 without
+//     centred with the f32 shift, summed into the column sums (f32 over the octet, f64 across), split, and written as NS
+//     16-byte fragment pieces — [k-step][split][column block][lane] x 16 B, lane-linear: ds_write_b128 / ds_read_b128 without
 //     bank conflicts, no transposition anywhere;
-//   * a block is 8 waves (2 per SIMD), one per CU, 32 rows per barrier, two stages in LDS (96 KiB diagonal, 144 KiB off-diagonal);
+//   * a block is 8 waves (2 per SIMD), one per CU, 32 rows per barrier, two stages in LDS;
 //   * DIAGONAL block: the 36 upper tiles of a 256-column super-tile dealt to the 8 waves as 4 4 4 4 5 5 5 5 (G16_TR / G16_TC:
 //     waves w and w + 4 share a SIMD: 9 tiles per SIMD, the matrix pipes are evenly loaded); OFF-DIAGONAL block (I < J, `half`):
 //     128 columns of I against 256 of J, wave w owns tile row w >> 1 and four tile columns;
 //   * accumulation: the matrix cores sum one 32-row stage from zero, the vector unit adds the stage sums (the bf16 MFMA's f32
-//     accumulation is not round-to-nearest: see gram16_diag_body); fold, partial layout, reducer, mean: those of gram32_kernel
-//     (f32 over <= 2048 rows, f64 across; deterministic).
+//     accumulation is not round-to-nearest: see gram16_diag_body); f32 over <= 2048 rows, f64 across; deterministic.
 constexpr int G16_KR = 32;                    // rows per stage
 constexpr int G16_THREADS = 512;
 constexpr int G16_TR[8][5] = {{0, 0, 0, 0, -1}, {0, 0, 0, 0, -1}, {1, 1, 1, 1, -1}, {1, 1, 1, 7, -1},
@@ -573,44 +401,51 @@ __host__ __device__ constexpr bool g16_uses(int w, int blk) {
         if (G16_TR[w][q] == blk || G16_TC[w][q] == blk) return true;
     return false;
 }
-// byte offset of a fragment piece inside a stage: NCB column blocks per (k-step, split)
-template <int NCB>
-__device__ __forceinline__ uint32_t g16_slot(int ks, int s, int cbk, int lane) { return (uint32_t)((((ks * 3 + s) * NCB + cbk) * 64 + lane) * 16); }
+// byte offset of a fragment piece inside a stage: NS split pieces x NCB column blocks per k-step
+template <int NS, int NCB>
+__device__ __forceinline__ uint32_t g16_slot(int ks, int s, int cbk, int lane) { return (uint32_t)((((ks * NS + s) * NCB + cbk) * 64 + lane) * 16); }
 
-// one staging task: eight rows of one column -> centred, summed, split, three 16-byte pieces into the stage
-template <int NCB>
-__device__ __forceinline__ float g16_stage_task(const float (&pre)[8], int nv, float sh, char *stage, int o, int cbk, int lane) {
+// one staging task: eight rows of one column -> centred, summed, split, NS 16-byte pieces into the stage.
+// Returns the octet's sum; LEAN: `resid2` += sum of r1^2 (the diagonal correction above).
+template <bool LEAN, int NCB>
+__device__ __forceinline__ float g16_stage_task(const float (&pre)[8], int nv, float sh, char *stage, int o, int cbk, int lane, float &resid2) {
+    constexpr int NS = LEAN ? 2 : 3;
     float y[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) y[j] = j < nv ? __fsub_rn(pre[j], sh) : 0.f;
     u32x4 q1, q2, q3;
+    float rr = 0.f;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         uint32_t p1, p2, p3;
-        split3_pair(y[2 * jj], y[2 * jj + 1], p1, p2, p3);
+        if constexpr (LEAN) {
+            float ra, rb;
+            split2_pair(y[2 * jj], y[2 * jj + 1], p1, p2, ra, rb);
+            rr = __builtin_fmaf(ra, ra, rr);
+            rr = __builtin_fmaf(rb, rb, rr);
+            p3 = 0;
+        } else {
+            split3_pair(y[2 * jj], y[2 * jj + 1], p1, p2, p3);
+        }
         q1[jj] = p1; q2[jj] = p2; q3[jj] = p3;
     }
     const int ks = o >> 1, ln = (o & 1) * 32 + (lane & 31);
-    *reinterpret_cast<u32x4 *>(stage + g16_slot<NCB>(ks, 0, cbk, ln)) = q1;
-    *reinterpret_cast<u32x4 *>(stage + g16_slot<NCB>(ks, 1, cbk, ln)) = q2;
-    *reinterpret_cast<u32x4 *>(stage + g16_slot<NCB>(ks, 2, cbk, ln)) = q3;
+    *reinterpret_cast<u32x4 *>(stage + g16_slot<NS, NCB>(ks, 0, cbk, ln)) = q1;
+    *reinterpret_cast<u32x4 *>(stage + g16_slot<NS, NCB>(ks, 1, cbk, ln)) = q2;
+    if constexpr (!LEAN) *reinterpret_cast<u32x4 *>(stage + g16_slot<NS, NCB>(ks, 2, cbk, ln)) = q3;
+    resid2 += rr;
     return ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
 }
 
 #define G16_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
 constexpr f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+// the products of one (tile, k-step): operand pieces (A, B); the first starts from zero at ks == 0
+constexpr int G16_PA[6] = {0, 0, 1, 1, 0, 2}, G16_PB[6] = {0, 1, 0, 1, 2, 0};
+constexpr int G16_LA[3] = {0, 0, 1}, G16_LB[3] = {0, 1, 0};
 
-// ORDER: which waves stage the NEXT 32 rows (vector-unit work) AFTER their MFMAs of the current stage instead of before them.
-// Inside one iteration the two are independent (different LDS buffers), and a barrier per stage would otherwise line both
-// waves of a SIMD up in the same phase — vector work together, then the matrix pipe together.  1: waves 4..7 (the partners
-// of 0..3 if wave w sits on SIMD w mod 4); 2: odd waves; 0: none (the default: the three measure the same, profiles/r03_gram16_order.txt).
-template <int ORDER, int W>
-__host__ __device__ constexpr bool g16_late() { return ORDER == 1 ? W >= 4 : ORDER == 2 ? (W & 1) != 0 : false; }
-
-template <int W, int ORDER>
+template <int W, bool LEAN>
 __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds, uint32_t sup) {
-    constexpr int NT = g16_ntiles(W), NCB = 8, STAGE = 2 * 3 * NCB * 1024;
-    constexpr bool LATE = g16_late<ORDER, W>();
+    constexpr int NT = g16_ntiles(W), NCB = 8, NS = LEAN ? 2 : 3, NP = LEAN ? 3 : 6, STAGE = 2 * NS * NCB * 1024;
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
     const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
@@ -624,7 +459,7 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
     for (int q = 0; q < NT; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    double cs0 = 0.0, cs1 = 0.0;
+    double cs0 = 0.0, cs1 = 0.0, df0 = 0.0, df1 = 0.0;
     float pre0[8], pre1[8];
     int nv0 = 0, nv1 = 0;
     auto prefetch = [&](uint64_t row0) {
@@ -638,8 +473,10 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
         }
     };
     auto stage = [&](int buf) {
-        cs0 += (double)g16_stage_task<NCB>(pre0, nv0, sh0, lds + buf * STAGE, O0, 2 * CG0 + h, lane);
-        cs1 += (double)g16_stage_task<NCB>(pre1, nv1, sh1, lds + buf * STAGE, O1, 2 * CG1 + h, lane);
+        float r0 = 0.f, r1 = 0.f;
+        cs0 += (double)g16_stage_task<LEAN, NCB>(pre0, nv0, sh0, lds + buf * STAGE, O0, 2 * CG0 + h, lane, r0);
+        cs1 += (double)g16_stage_task<LEAN, NCB>(pre1, nv1, sh1, lds + buf * STAGE, O1, 2 * CG1 + h, lane, r1);
+        if constexpr (LEAN) { df0 += (double)r0; df1 += (double)r1; }
     };
     double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + (uint64_t)sup * G32_TILES) * 1024;
     auto tile_index = [](int q) { return upper_tile_index(G16_TR[W][q], G16_TC[W][q]); };
@@ -654,45 +491,36 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
     int buf = 0;
     uint32_t in_sub = 0;
     for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
-        auto stage_next = [&]() {
-            if (row0 + G16_KR < r_end) {
-                stage(buf ^ 1);
-                if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
-            }
-        };
-        if (!LATE) stage_next();
+        if (row0 + G16_KR < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
+        }
         const char *sb = lds + buf * STAGE;
         // The bf16 MFMA does not round its f32 accumulation to nearest: a long chain of same-sign terms (the variances on the
         // diagonal) comes out LOW — -1.3e-6 relative after 2048 rows, uniformly (profiles/r03u_gram_error.txt), against -6e-9
-        // for 32-row chains.  So the matrix cores only ever sum ONE stage (32 rows, 12 MFMAs per tile) from zero, and the
+        // for 32-row chains.  So the matrix cores only ever sum ONE stage (32 rows) from zero, and the
         // stage sums are added to the long accumulators by the vector unit (v_pk_add_f32: round to nearest even).
         f16v tmp[NT];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 f[8][3];
+            bf16x8 f[8][NS];
 #pragma unroll
             for (int blk = 0; blk < 8; ++blk)
                 if (g16_uses(W, blk)) {
 #pragma unroll
-                    for (int sp = 0; sp < 3; ++sp) f[blk][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NCB>(ks, sp, blk, lane));
+                    for (int sp = 0; sp < NS; ++sp) f[blk][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NS, NCB>(ks, sp, blk, lane));
                 }
             // product-major: consecutive MFMAs go to different accumulators
 #pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][0], f[G16_TC[W][q]][0], ks == 0 ? zero16 : tmp[q]);
+            for (int pr = 0; pr < NP; ++pr) {
+                const int pa = LEAN ? G16_LA[pr] : G16_PA[pr], pb = LEAN ? G16_LB[pr] : G16_PB[pr];
 #pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][0], f[G16_TC[W][q]][1], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][1], f[G16_TC[W][q]][0], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][1], f[G16_TC[W][q]][1], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][0], f[G16_TC[W][q]][2], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(f[G16_TR[W][q]][2], f[G16_TC[W][q]][0], tmp[q]);
+                for (int q = 0; q < NT; ++q)
+                    tmp[q] = G16_MFMA(f[G16_TR[W][q]][pa], f[G16_TC[W][q]][pb], (ks == 0 && pr == 0) ? zero16 : tmp[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
-        if (LATE) stage_next();
         in_sub += G16_KR;
         if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
             gram32_fold<NT>(out, acc, i, h, false, tile_index);
@@ -705,16 +533,23 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
     double *red = reinterpret_cast<double *>(lds);          // the loop ended on a barrier: the stages are free
     red[O0 * G32_D + 64 * CG0 + lane] = cs0;
     red[O1 * G32_D + 64 * CG1 + lane] = cs1;
+    if constexpr (LEAN) {
+        red[(4 + O0) * G32_D + 64 * CG0 + lane] = df0;
+        red[(4 + O1) * G32_D + 64 * CG1 + lane] = df1;
+    }
     __syncthreads();
-    if (t < G32_D) a.colsum[(uint64_t)blockIdx.y * a.d + cb + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
+    if (t < G32_D) {
+        a.colsum[(uint64_t)blockIdx.y * a.d + cb + t] = ((red[t] + red[G32_D + t]) + red[2 * G32_D + t]) + red[3 * G32_D + t];
+        if constexpr (LEAN)
+            a.diagfix[(uint64_t)blockIdx.y * a.d + cb + t] = ((red[4 * G32_D + t] + red[5 * G32_D + t]) + red[6 * G32_D + t]) + red[7 * G32_D + t];
+    }
 }
 
 // off-diagonal block: columns [256 I + 128 half, +128) (A: column blocks 0..3 of the stage) against [256 J, +256) (B: blocks 4..11);
 // wave W owns tile row W >> 1 of the half and tile columns 4 (W & 1) .. +3
-template <int W, int ORDER>
+template <int W, bool LEAN>
 __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, uint32_t I, uint32_t J, uint32_t half, uint32_t pair) {
-    constexpr int NT = 4, NCB = 12, STAGE = 2 * 3 * NCB * 1024, AR = W >> 1, B0 = 4 * (W & 1);
-    constexpr bool LATE = g16_late<ORDER, W>();
+    constexpr int NT = 4, NCB = 12, NS = LEAN ? 2 : 3, NP = LEAN ? 3 : 6, STAGE = 2 * NS * NCB * 1024, AR = W >> 1, B0 = 4 * (W & 1);
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
     const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;
@@ -753,8 +588,9 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
         }
     };
     auto stage = [&](int buf) {
+        float unused = 0.f;                                  // no diagonal entries in an off-diagonal block
 #pragma unroll
-        for (int u = 0; u < 3; ++u) (void)g16_stage_task<NCB>(pre[u], nv[u], sh[u], lds + buf * STAGE, oct[u], cbk[u], lane);
+        for (int u = 0; u < 3; ++u) (void)g16_stage_task<LEAN, NCB>(pre[u], nv[u], sh[u], lds + buf * STAGE, oct[u], cbk[u], lane, unused);
     };
     const uint32_t tile_base = a.S * G32_TILES + pair * G32_OFF_TILES + (4 * half + AR) * 8 + B0;
     double *const out = a.partial + ((uint64_t)blockIdx.y * a.tiles_per_slice + tile_base) * 1024;
@@ -770,40 +606,30 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
     int buf = 0;
     uint32_t in_sub = 0;
     for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
-        auto stage_next = [&]() {
-            if (row0 + G16_KR < r_end) {
-                stage(buf ^ 1);
-                if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
-            }
-        };
-        if (!LATE) stage_next();
+        if (row0 + G16_KR < r_end) {
+            stage(buf ^ 1);
+            if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
+        }
         const char *sb = lds + buf * STAGE;
         f16v tmp[NT];                                        // one stage's sums (see gram16_diag_body)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[3], fb[4][3];
+            bf16x8 fa[NS], fb[4][NS];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) fa[sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NCB>(ks, sp, AR, lane));
+            for (int sp = 0; sp < NS; ++sp) fa[sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NS, NCB>(ks, sp, AR, lane));
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) fb[q][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NCB>(ks, sp, 4 + B0 + q, lane));
+                for (int sp = 0; sp < NS; ++sp) fb[q][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NS, NCB>(ks, sp, 4 + B0 + q, lane));
 #pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[0], fb[q][0], ks == 0 ? zero16 : tmp[q]);
+            for (int pr = 0; pr < NP; ++pr) {
+                const int pa = LEAN ? G16_LA[pr] : G16_PA[pr], pb = LEAN ? G16_LB[pr] : G16_PB[pr];
 #pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[0], fb[q][1], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[1], fb[q][0], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[1], fb[q][1], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[0], fb[q][2], tmp[q]);
-#pragma unroll
-            for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[2], fb[q][0], tmp[q]);
+                for (int q = 0; q < NT; ++q) tmp[q] = G16_MFMA(fa[pa], fb[q][pb], (ks == 0 && pr == 0) ? zero16 : tmp[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
-        if (LATE) stage_next();
         in_sub += G16_KR;
         if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
             gram32_fold<NT>(out, acc, i, h, false, tile_index);
@@ -813,21 +639,22 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
     }
 }
 
-// grid = (S + S (S - 1), slices) like gram32_kernel; 512 threads; dynamic LDS: two stages (96 KiB when S == 1, else 144 KiB)
-template <int ORDER>
+// grid = (S + S (S - 1), slices): block x < S is the diagonal block of super-tile x; the others come in pairs per (I < J).
+// 512 threads; dynamic LDS: two stages of NS x NCB KiB x 2 k-steps (LEAN: 64 KiB when S == 1, else 96 KiB)
+template <bool LEAN>
 __global__ __launch_bounds__(G16_THREADS, 1) void gram16_kernel(const Gram32Args a) {
     extern __shared__ __attribute__((aligned(16))) char g16_lds[];
     const uint32_t b = blockIdx.x;
     if (b < a.S) {
         switch (threadIdx.x >> 6) {                          // whole waves take each arm; every arm meets the same barriers
-            case 0: gram16_diag_body<0, ORDER>(a, g16_lds, b); break;
-            case 1: gram16_diag_body<1, ORDER>(a, g16_lds, b); break;
-            case 2: gram16_diag_body<2, ORDER>(a, g16_lds, b); break;
-            case 3: gram16_diag_body<3, ORDER>(a, g16_lds, b); break;
-            case 4: gram16_diag_body<4, ORDER>(a, g16_lds, b); break;
-            case 5: gram16_diag_body<5, ORDER>(a, g16_lds, b); break;
-            case 6: gram16_diag_body<6, ORDER>(a, g16_lds, b); break;
-            default: gram16_diag_body<7, ORDER>(a, g16_lds, b); break;
+            case 0: gram16_diag_body<0, LEAN>(a, g16_lds, b); break;
+            case 1: gram16_diag_body<1, LEAN>(a, g16_lds, b); break;
+            case 2: gram16_diag_body<2, LEAN>(a, g16_lds, b); break;
+            case 3: gram16_diag_body<3, LEAN>(a, g16_lds, b); break;
+            case 4: gram16_diag_body<4, LEAN>(a, g16_lds, b); break;
+            case 5: gram16_diag_body<5, LEAN>(a, g16_lds, b); break;
+            case 6: gram16_diag_body<6, LEAN>(a, g16_lds, b); break;
+            default: gram16_diag_body<7, LEAN>(a, g16_lds, b); break;
         }
         return;
     }
@@ -836,14 +663,14 @@ __global__ __launch_bounds__(G16_THREADS, 1) void gram16_kernel(const Gram32Args
     while (q >= rowlen) { q -= rowlen; ++I; --rowlen; }
     const uint32_t J = I + 1 + q;
     switch (threadIdx.x >> 6) {
-        case 0: gram16_off_body<0, ORDER>(a, g16_lds, I, J, half, pair); break;
-        case 1: gram16_off_body<1, ORDER>(a, g16_lds, I, J, half, pair); break;
-        case 2: gram16_off_body<2, ORDER>(a, g16_lds, I, J, half, pair); break;
-        case 3: gram16_off_body<3, ORDER>(a, g16_lds, I, J, half, pair); break;
-        case 4: gram16_off_body<4, ORDER>(a, g16_lds, I, J, half, pair); break;
-        case 5: gram16_off_body<5, ORDER>(a, g16_lds, I, J, half, pair); break;
-        case 6: gram16_off_body<6, ORDER>(a, g16_lds, I, J, half, pair); break;
-        default: gram16_off_body<7, ORDER>(a, g16_lds, I, J, half, pair); break;
+        case 0: gram16_off_body<0, LEAN>(a, g16_lds, I, J, half, pair); break;
+        case 1: gram16_off_body<1, LEAN>(a, g16_lds, I, J, half, pair); break;
+        case 2: gram16_off_body<2, LEAN>(a, g16_lds, I, J, half, pair); break;
+        case 3: gram16_off_body<3, LEAN>(a, g16_lds, I, J, half, pair); break;
+        case 4: gram16_off_body<4, LEAN>(a, g16_lds, I, J, half, pair); break;
+        case 5: gram16_off_body<5, LEAN>(a, g16_lds, I, J, half, pair); break;
+        case 6: gram16_off_body<6, LEAN>(a, g16_lds, I, J, half, pair); break;
+        default: gram16_off_body<7, LEAN>(a, g16_lds, I, J, half, pair); break;
     }
 }
 
@@ -860,7 +687,7 @@ __global__ __launch_bounds__(256) void shift_round_kernel(double *__restrict__ s
 __global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__restrict__ partial, uint32_t slices, uint32_t S,
                                                             uint32_t tiles_per_slice, uint32_t d,
                                                             const double *__restrict__ delta, double n_rows,
-                                                            double *__restrict__ gram) {
+                                                            const double *__restrict__ diagfix, double *__restrict__ gram) {
     const uint32_t p = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;       // tile, element of the tile
     uint32_t gi, gj;
     bool mirror;
@@ -885,6 +712,8 @@ __global__ __launch_bounds__(256) void gram32_reduce_kernel(const double *__rest
     }
     double s = 0.0;
     for (uint32_t sl = 0; sl < slices; ++sl) s += partial[((uint64_t)sl * tiles_per_slice + p) * 1024 + e];
+    if (diagfix && gi == gj)                                // the r1^2 term of the three-product form (see gram16_kernel)
+        for (uint32_t sl = 0; sl < slices; ++sl) s += diagfix[(uint64_t)sl * d + gi];
     s -= n_rows * (delta[gi] * delta[gj]);                  // the product first: the same rounding for (i, j) and (j, i)
     gram[(uint64_t)gi * d + gj] = s;
     if (mirror) gram[(uint64_t)gj * d + gi] = s;
@@ -900,10 +729,7 @@ inline uint32_t gram_slices(uint64_t n, uint32_t group, int per_cu = 2) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         cus = c > 0 ? c : 256;
     }
-    // per_cu < 0: -per_cu blocks in TOTAL — a Gram that is to occupy only a part of the chip (one block per CU on that many
-    // CUs) while another kernel keeps the rest: a SIMD that holds a busy MFMA wave gives co-resident waves next to nothing
-    // (profiles/r03o_side_load.jsonl), so the loop's statistics take few CUs for longer instead of every CU for a while
-    const int resident = per_cu < 0 ? -per_cu : per_cu * cus;
+    const int resident = (per_cu == 1 ? 1 : 2) * cus;
     uint64_t s = group ? (uint64_t)resident / group : 1;
     const uint64_t cap = (n + GKC - 1) / GKC;   // at least one chunk of rows per slice
     if (s > cap) s = cap;
@@ -1031,209 +857,7 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------
-// projection, second form: the X tile lives in LDS for the whole block, T comes straight from L2
-// ---------------------------------------------------------------------------------------------
-// For d <= 512 a block owns RM rows of X and keeps them — centred, all d columns — in LDS (each row is read from HBM
-// exactly once, as whole 1 KiB lines), while the transform is streamed from L2 into registers in the exact order the
-// MFMA fragments need it.  No barrier in the main loop, no LDS traffic for T:
-//   * T is repacked once per call (pack_transform_kernel, d*k floats) into fragment order: for k-group g (8 values of
-//     the reduction index), 32-column tile j and lane l = (n, h): Tp[((g*tiles + j)*64 + l)*4 + q] = T[8g + 4h + q][32j + n],
-//     so one global_load_dwordx4 per wave = one contiguous 1 KiB = the B fragments of FOUR consecutive MFMAs;
-//   * the A fragments of the same four MFMAs are one ds_read_b128: lane (i, h) reads X_lds[row i][8g + 4h .. +3]
-//     (row stride d + 4 floats: the 16 lanes of a ds_read_b128 group land on all 64 banks);
-//   * MFMA q of group g therefore multiplies the k pair (8g + q, 8g + 4 + q): a fixed, documented summation order
-//     (f32 fma chain) — not numpy's sgemm order either; same tolerance as the first form.
-// Two 256-thread blocks per CU (LDS 2 x 66.5 KiB at d = 256): one block's prologue / epilogue runs under the other's MFMAs.
-constexpr int RM = 64;   // rows per block
-
-template <int WN>   // 32-column tiles per wave (2: the wave owns 64 output columns)
-__global__ __launch_bounds__(256, 2) void project_rows_kernel(const ProjArgs a, const float *__restrict__ tp,
-                                                              uint32_t col_tiles) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];       // [RM][d + 4]
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t d = a.d, lds = d + 4;
-    const uint64_t m0 = (uint64_t)blockIdx.x * RM;
-    const uint32_t n0 = (blockIdx.y * 4 + w) * (WN * 32);            // first output column of this wave
-
-    // ---- prologue: RM rows x d columns, centred in f32 (pycleora/__init__.py:161), one wave per row -----------------
-    {
-        const uint32_t c = (uint32_t)lane * 4;
-        for (uint32_t c0 = 0; c0 < d; c0 += 256) {
-            float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + c < d) mu = *reinterpret_cast<const float4 *>(a.mean + c0 + c);
-            for (int r = w; r < RM; r += 4 * 4) {
-                float4 v[4], v2[4];
-                float s[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t row = m0 + r + 4 * u;
-                    const bool ok = row < a.n && c0 + c < d && r + 4 * u < RM;
-                    v[u] = v2[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    s[u] = 1.f;
-                    if (ok && !(a.dbg & 2)) v[u] = *reinterpret_cast<const float4 *>(a.x + row * a.ldx + c0 + c);
-                    if (ok && a.x2) v2[u] = *reinterpret_cast<const float4 *>(a.x2 + row * a.ldx2 + c0 + c);
-                    if (ok && a.rowscale) s[u] = a.rowscale[row];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint64_t row = m0 + r + 4 * u;
-                    if (c0 + c < d && r + 4 * u < RM) {
-                        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row < a.n) {
-                            const bool sc = a.rowscale != nullptr;
-                            o = make_float4(centre(v[u].x, mu.x, s[u], sc), centre(v[u].y, mu.y, s[u], sc),
-                                            centre(v[u].z, mu.z, s[u], sc), centre(v[u].w, mu.w, s[u], sc));
-                            if (a.x2)
-                                o = make_float4(__fadd_rn(__fmul_rn(a.alpha, o.x), __fmul_rn(a.beta, __fsub_rn(v2[u].x, mu.x))),
-                                                __fadd_rn(__fmul_rn(a.alpha, o.y), __fmul_rn(a.beta, __fsub_rn(v2[u].y, mu.y))),
-                                                __fadd_rn(__fmul_rn(a.alpha, o.z), __fmul_rn(a.beta, __fsub_rn(v2[u].z, mu.z))),
-                                                __fadd_rn(__fmul_rn(a.alpha, o.w), __fmul_rn(a.beta, __fsub_rn(v2[u].w, mu.w))));
-                        }
-                        *reinterpret_cast<float4 *>(&xs[(r + 4 * u) * lds + c0 + c]) = o;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (n0 >= a.k && !a.norm) return;                                  // (after the barrier: this wave has no columns)
-
-    f16v acc[2][WN];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // Main loop, software-pipelined by hand with NO conditionals (the packed T is zero-padded by PF groups and to whole
-    // 8-tile column blocks, the LDS tile by one group): B fragments are fetched PF groups ahead into fixed register
-    // slots, A fragments one group ahead, so every wait is a counted s_waitcnt behind ~1000+ cycles of MFMAs.
-    const uint32_t groups = d / 8;                                     // a multiple of PF (d % 32 == 0)
-    const uint32_t jt0 = n0 / 32;
-    const float *ap = xs + (lane & 31) * lds + 4 * (lane >> 5);        // + 32*i*lds + 8*g
-    const float *bp = tp + ((uint64_t)jt0 * 64 + lane) * 4;            // + (g*col_tiles + j)*256
-    const uint64_t bstep = (uint64_t)col_tiles * 256;                  // floats per group
-    constexpr int PF = 4;                                              // groups of B in flight
-    float4 bq[PF][WN];
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) bq[p][j] = *reinterpret_cast<const float4 *>(bp + p * bstep + j * 256);
-    float4 af[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const float4 *>(ap + 32 * i * lds);
-    const float *bnext = bp + PF * bstep;
-    for (uint32_t g0 = 0; g0 < groups; g0 += PF, bnext += PF * bstep) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {
-            float4 an[2];                                              // A of the next group (one past the end: the pad)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) an[i] = *reinterpret_cast<const float4 *>(ap + 32 * i * lds + 8 * (g0 + p + 1));
-            __builtin_amdgcn_sched_barrier(0);                         // keep the read-ahead ABOVE this group's MFMAs
-            const float a4[2][4] = {{af[0].x, af[0].y, af[0].z, af[0].w}, {af[1].x, af[1].y, af[1].z, af[1].w}};
-            float b4[WN][4];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) { b4[j][0] = bq[p][j].x; b4[j][1] = bq[p][j].y; b4[j][2] = bq[p][j].z; b4[j][3] = bq[p][j].w; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][q], b4[j][q], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bq[p][j] = *reinterpret_cast<const float4 *>(bnext + p * bstep + j * 256);
-            // hipcc's scheduler otherwise sinks these loads down to their consumer PF groups later (one register slot, a
-            // full L2 latency exposed per group: measured 35 % MFMA idle); nothing may move across this point
-            __builtin_amdgcn_sched_barrier(0);
-            af[0] = an[0];
-            af[1] = an[1];
-        }
-    }
-
-    if (a.norm) {
-        // Row normalisation on the accumulators (the block holds whole output rows: 4 waves x 64 columns >= k): the
-        // next iterate of the overlapped whitened loop is normalise(projection), and doing it here saves a pass over
-        // the n x k matrix.  Per lane: the partial of its 32 row slots over its 2 column tiles; a 32-lane butterfly
-        // inside each half-wave; the four waves' partials meet in LDS (the X tile is dead once every wave is here).
-        float p[2][16];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float t = 0.f;
-#pragma unroll
-                for (int j = 0; j < WN; ++j) t += a.norm == 1 ? acc[i][j][reg] * acc[i][j][reg] : fabsf(acc[i][j][reg]);
-                p[i][reg] = t;
-            }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) p[i][reg] += __shfl_xor(p[i][reg], o, 64);
-        __syncthreads();                                   // every wave has left the main loop: xs is free
-        float *red = xs;                                   // [4 waves][64 rows] partials, then [64] factors
-        const int nl = lane & 31, h = lane >> 5;
-        float mine = 0.f;                                  // lane nl of half h publishes row slot nl of that half
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                if (nl == i * 16 + reg) mine = p[i][reg];
-        {
-            const int i = nl >> 4, reg = nl & 15;
-            red[w * RM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = mine;
-        }
-        __syncthreads();
-        if (t < RM) {
-            const float s = red[t] + red[RM + t] + red[2 * RM + t] + red[3 * RM + t];
-            // L2: v * (1 / max(sqrt(s), 1e-10)) like src/embedding.rs:98-102; L1: v / max(s, 1e-10) (pycleora/__init__.py:947-950)
-            red[4 * RM + t] = a.norm == 1 ? 1.0f / fmaxf(sqrtf(s), 1e-10f) : fmaxf(s, 1e-10f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float f = red[4 * RM + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h];
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j][reg] = a.norm == 1 ? acc[i][j][reg] * f : acc[i][j][reg] / f;
-            }
-    }
-
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-                const uint64_t row = m0 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-                const uint32_t col = n0 + j * 32 + (lane & 31);
-                if (row < a.n && col < a.k && (!(a.dbg & 1) || acc[i][j][reg] == 12345.678f)) a.out[row * a.ldo + col] = acc[i][j][reg];
-            }
-}
-
-// T (d x k row-major) -> fragment order, zero-padded to whole 32-column tiles.
-__global__ __launch_bounds__(256) void pack_transform_kernel(const float *__restrict__ t, uint32_t d, uint32_t k,
-                                                             uint32_t col_tiles, float *__restrict__ tp) {
-    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;     // one float4 of the packed array
-    const uint64_t total = (uint64_t)(d / 8 + 4) * col_tiles * 64;     // 4 = PF groups of zero padding behind the last
-    if (idx >= total) return;
-    const uint32_t lane = (uint32_t)(idx & 63);
-    const uint32_t j = (uint32_t)((idx >> 6) % col_tiles), g = (uint32_t)((idx >> 6) / col_tiles);
-    const uint32_t n = j * 32 + (lane & 31), k0 = 8 * g + 4 * (lane >> 5);
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = (n < k && k0 + q < d) ? t[(uint64_t)(k0 + q) * k + n] : 0.f;
-    reinterpret_cast<float4 *>(tp)[idx] = make_float4(v[0], v[1], v[2], v[3]);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// projection, third form: f32-accurate products from the bf16 matrix cores
+// projection, second form: f32-accurate products from the bf16 matrix cores
 // ---------------------------------------------------------------------------------------------
 // The f32 MFMA runs at the f32 VECTOR rate (157 TF), one sixteenth of the bf16 MFMA rate of the same chip.  An f32 value
 // is exactly the sum of three bf16 values up to 2^-27 of its magnitude (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 -
@@ -1257,7 +881,7 @@ __global__ __launch_bounds__(256) void pack_transform_kernel(const float *__rest
 //     barrier per step; fragments are lane-linear 1 KiB blocks: conflict-free ds_read_b128).
 //   * per k-step and wave: 12 B fragments, 24 MFMAs (the six products of each of the four tiles; consecutive MFMAs go to
 //     different accumulators).
-//   * epilogue per row tile: optional row normalisation on the accumulators (as in the second form), stores.
+//   * epilogue per row tile: optional row normalisation on the accumulators, stores.
 // T (d x k row-major f32) -> split into three bf16 matrices, in fragment order, zero-padded to whole k-steps and passes.
 __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *__restrict__ t, uint32_t d, uint32_t k,
                                                                    uint32_t ksteps, uint32_t passes, u32x4 *__restrict__ tp) {
@@ -1284,15 +908,13 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
     tp[idx] = (u32x4){w[0], w[1], w[2], w[3]};
 }
 
-// DBG (profiling builds of the plain instantiation only, CLEORA_PROJECT_DEBUG): 1 = no output stores, 2 = every row tile reads
-// the rows of tile 0 (A comes from cache, not HBM), 4 = no global loads for the B stage (zeros are staged instead).
 // U = k-steps per trip of the flat loop (a divisor of ksteps, a multiple of RING): the compiler copies the live part of the
 // operand ring at the loop's back edge — behind a vmcnt(0) that drains the prefetch — so the back edge is taken as rarely
 // as the shape allows (once per row tile at d = 256).
 // RG = row groups of 32 rows per block: 2 (a 64-row tile, 4 waves, two blocks per CU) or 4 (a 128-row tile, 8 waves, one
 // block per CU — for large n: the same two waves per SIMD, but one B stage feeds twice the MFMAs, so the L2 traffic of
 // the B stream (60 GB per call at the C3 shape, 2.6 of 8.75 ms by the profiling builds) halves).
-template <bool SCALED, bool BLEND, int RING, int U, int RG = 2, int DBG = 0>
+template <bool SCALED, bool BLEND, int RING, int U, int RG = 2>
 __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
                                                                                    uint32_t ksteps, uint64_t tiles) {
     constexpr int T = RG * 128;            // threads
@@ -1322,7 +944,7 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
     uint64_t ltile = blockIdx.x;          // row tile / k-step of the NEXT load
     uint32_t lks = 0;
     auto row_of = [&](uint64_t tile) {
-        const uint64_t r = ((DBG & 2) ? 0 : tile * SRT) + (uint64_t)(wr * 32 + i);
+        const uint64_t r = tile * SRT + (uint64_t)(wr * 32 + i);
         return r < a.n ? r : a.n - 1;                                            // clamped: always a valid address
     };
     auto issue_a = [&](int slot) {
@@ -1385,7 +1007,7 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
             const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
             u32x4 bst[NB];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) bst[u] = (DBG & 4) ? (u32x4){0u, 0u, 0u, 0u} : tpp[(uint64_t)ksn * SKB + t + T * u];
+            for (int u = 0; u < NB; ++u) bst[u] = tpp[(uint64_t)ksn * SKB + t + T * u];
             // A of k-step g + RING into the slot whose fragments were made during the PREVIOUS step, right behind the B loads:
             // the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in order), the one at
             // the end of the next step completes them; they are split two steps after that
@@ -1454,7 +1076,7 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
                         // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
                         const uint64_t row = tile * SRT + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
                         const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
-                        if (row < a.n && col < a.k && (!(DBG & 1) || acc[jj][reg] == 12345.678f)) a.out[row * a.ldo + col] = acc[jj][reg];
+                        if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[jj][reg];
                         acc[jj][reg] = 0.f;
                     }
                 tile += gridDim.x;
@@ -1471,12 +1093,12 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
 }  // namespace
 
 struct Gram32Plan { uint32_t S, blocks, tiles_per_slice, slices; };
-inline Gram32Plan gram32_plan(uint64_t n, uint32_t d, int per_cu) {
+inline Gram32Plan gram32_plan(uint64_t n, uint32_t d) {
     Gram32Plan p;
     p.S = d / G32_D;
     p.blocks = p.S + p.S * (p.S - 1);
     p.tiles_per_slice = p.S * G32_TILES + p.S * (p.S - 1) / 2 * G32_OFF_TILES;
-    p.slices = gram_slices(n, p.blocks, per_cu);
+    p.slices = gram_slices(n, p.blocks, 1);             // one 8-wave block per CU
     return p;
 }
 
@@ -1484,31 +1106,28 @@ uint64_t gram_workspace(uint64_t n, uint32_t d) {
     const GramPlan p = gram_plan(n, d);
     // tile partials, per-slice column sums of the diagonal blocks, delta
     uint64_t need = (uint64_t)p.s_max * p.pairs * GT * GT + (uint64_t)p.s_diag * p.tiles * GT + (uint64_t)p.tiles * GT;
-    if (d % G32_D == 0 && d <= 2048) {   // the f32 form: [slices][tiles][32][32] partials, [slices][d] column sums, delta
-        const Gram32Plan q = gram32_plan(n, d, 2);
-        const uint64_t need32 = (uint64_t)q.slices * ((uint64_t)q.tiles_per_slice * 1024 + d) + d;
+    if (d % G32_D == 0 && d <= 2048) {   // the split form: [slices][tiles][32][32] partials, [slices][d] column sums and diagonal corrections, delta
+        const Gram32Plan q = gram32_plan(n, d);
+        const uint64_t need32 = (uint64_t)q.slices * ((uint64_t)q.tiles_per_slice * 1024 + 2 * (uint64_t)d) + d;
         if (need32 > need) need = need32;
     }
     return need;
 }
 
 bool gram32_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d) {
-    static const bool off = std::getenv("CLEORA_GRAM") && !std::strcmp(std::getenv("CLEORA_GRAM"), "f64");   // A/B switch
-    return !off && d % G32_D == 0 && d <= 2048 && ldx % 4 == 0 && aligned16(x) && n >= 4096;
+    return d % G32_D == 0 && d <= 2048 && ldx % 4 == 0 && aligned16(x) && n >= 4096;
 }
 
-// One-pass centred Gram on the f32 matrix cores (d a multiple of 256; see gram32_kernel).  shift64 / shift32: the sampled shift,
+// One-pass centred Gram from the bf16 matrix cores (d a multiple of 256; see gram16_kernel).  shift64 / shift32: the sampled shift,
 // rounded to f32 here (both are updated: the kernel centres with the f32 value, the exact correction uses that same value).
 int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *shift64, float *shift32, double *ws, double *gram,
-                  hipStream_t stream, double *mean_out64, float *mean_out32, int blocks_per_cu) {
+                  hipStream_t stream, double *mean_out64, float *mean_out32) {
     CL_REQUIRE(x != nullptr && shift64 != nullptr && shift32 != nullptr && ws != nullptr && gram != nullptr && mean_out64 != nullptr &&
                mean_out32 != nullptr, "x / shift / workspace / gram / mean is NULL");
-    CL_REQUIRE(gram32_applies(x, ldx, n, d), "internal: the f32 Gram does not apply to this shape");
-    // CLEORA_GRAM=f32: the f32 matrix cores (gram32_kernel); default: the split-bf16 form (gram16_kernel, one 8-wave block per CU)
-    const char *form = std::getenv("CLEORA_GRAM");
-    const bool split = !(form && !std::strcmp(form, "f32"));
-    const Gram32Plan q = gram32_plan(n, d, blocks_per_cu < 0 ? blocks_per_cu : (split || blocks_per_cu == 1) ? 1 : 2);
+    CL_REQUIRE(gram32_applies(x, ldx, n, d), "internal: the split Gram does not apply to this shape");
+    const Gram32Plan q = gram32_plan(n, d);             // the same plan gram_workspace() sized the workspace for
     CL_REQUIRE(q.slices <= 65535, "internal: too many Gram slices");
+    static const bool six = std::getenv("CLEORA_X_GRAM6") != nullptr;     // EXPERIMENT (round 4, removed before the round ends): the six-product form
     Gram32Args a{};
     a.x = x;
     a.ldx = ldx;
@@ -1518,34 +1137,27 @@ int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     a.tiles_per_slice = q.tiles_per_slice;
     a.partial = ws;
     a.colsum = ws + (uint64_t)q.slices * q.tiles_per_slice * 1024;
-    double *delta = a.colsum + (uint64_t)q.slices * d;
+    a.diagfix = a.colsum + (uint64_t)q.slices * d;
+    double *delta = a.diagfix + (uint64_t)q.slices * d;
     uint64_t rps = (n + q.slices - 1) / q.slices;
-    a.rows_per_slice = (rps + G16_KR - 1) / G16_KR * G16_KR;           // whole stages of either kernel (G16_KR is a multiple of G32_KC)
+    a.rows_per_slice = (rps + G16_KR - 1) / G16_KR * G16_KR;           // whole stages
     a.sub_rows = 2048;
-    if (const char *sr = std::getenv("CLEORA_GRAM_SUB_ROWS")) {           // experiment: the f32 accumulation length
-        const int v = std::atoi(sr);
-        if (v >= G16_KR && v % G16_KR == 0) a.sub_rows = (uint32_t)v;
-    }
     hipLaunchKernelGGL(shift_round_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, shift64, shift32, d);
     // mean_out32 may be the buffer that holds shift32: the kernel reads it before gram_mean_kernel (same stream) rewrites it
     a.shift32 = shift32;
-    if (split) {
-        const size_t lds = (size_t)(q.S == 1 ? 2 * 2 * 3 * 8 * 1024 : 2 * 2 * 3 * 12 * 1024);
-        const char *ord = std::getenv("CLEORA_GRAM16_ORDER");                  // A/B: which waves stage after their MFMAs (gram16_kernel)
-        const int order = ord ? std::atoi(ord) : 0;                            // measured: 4.75 / 4.67 / 4.84 ms for 0 / 1 / 2 at the C3 shape — no gain
-        auto go = [&](auto kernel) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(q.blocks, q.slices), dim3(G16_THREADS), lds, stream, a);
-            return e;
-        };
-        CL_HIP(order == 0 ? go(gram16_kernel<0>) : order == 2 ? go(gram16_kernel<2>) : go(gram16_kernel<1>));
-    } else {
-        hipLaunchKernelGGL(gram32_kernel, dim3(q.blocks, q.slices), dim3(256), 0, stream, a);
-    }
+    auto go = [&](auto kernel, size_t lds) {
+        // per DEVICE and cheap: set on every call (a process-wide "done" flag broke the second GPU of a multi-device host)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(q.blocks, q.slices), dim3(G16_THREADS), lds, stream, a);
+        return e;
+    };
+    const size_t ncb = q.S == 1 ? 8 : 12;
+    if (six) CL_HIP(go(gram16_kernel<false>, 2 * 2 * 3 * ncb * 1024));
+    else CL_HIP(go(gram16_kernel<true>, 2 * 2 * 2 * ncb * 1024));
     hipLaunchKernelGGL(gram_mean_kernel, dim3((d + 255) / 256), dim3(256), 0, stream, a.colsum, q.slices, d / GT, d, n, shift64, delta,
                        mean_out64, mean_out32);
     hipLaunchKernelGGL(gram32_reduce_kernel, dim3(4, q.tiles_per_slice), dim3(256), 0, stream, ws, q.slices, q.S, q.tiles_per_slice, d,
-                       delta, (double)n, gram);
+                       delta, (double)n, six ? nullptr : a.diagfix, gram);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }
@@ -1560,7 +1172,7 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
     CL_REQUIRE(x != nullptr && mean != nullptr && ws != nullptr && gram != nullptr,
                "x / mean / workspace / gram is NULL");
     CL_REQUIRE((mean_out64 == nullptr) == (mean_out32 == nullptr), "mean outputs come in pairs");
-    const GramPlan p = gram_plan(n, d, blocks_per_cu < 0 ? blocks_per_cu : blocks_per_cu == 1 ? 1 : 2);     // (the workspace is sized for 2: enough for fewer)
+    const GramPlan p = gram_plan(n, d, blocks_per_cu == 1 ? 1 : 2);     // (the workspace is sized for 2: enough for fewer)
     GramArgs a{};
     a.colsum = ws + (uint64_t)p.s_max * p.pairs * GT * GT;
     double *delta = a.colsum + (uint64_t)p.s_diag * p.tiles * GT;
@@ -1615,8 +1227,6 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.ldx2 = ldx2;
     a.alpha = x2 ? alpha : 1.0f;
     a.beta = beta;
-    static const int dbg = std::getenv("CLEORA_PROJECT_DEBUG") ? std::atoi(std::getenv("CLEORA_PROJECT_DEBUG")) : 0;
-    a.dbg = dbg;
     a.x = x;
     a.ldx = ldx;
     a.n = n;
@@ -1629,12 +1239,11 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     a.nb_n = (k + PN - 1) / PN;
     a.w4x = (d % 4 == 0) && (ldx % 4 == 0) && aligned16(x) && (!x2 || (ldx2 % 4 == 0 && aligned16(x2)));
     a.w4t = (k % 4 == 0) && aligned16(t);
-    // split-bf16 form (third form above): any d that is a multiple of 32, any k.  CLEORA_PROJECT=f32 keeps the f32-MFMA
-    // forms below (A/B runs, and the accuracy comparison of tests/test_gpu_whiten.py).
-    static const char *form_env = std::getenv("CLEORA_PROJECT");
-    const bool f32_forms = form_env && !std::strcmp(form_env, "f32");
-    if (!f32_forms && a.w4x && d % 32 == 0 && n >= 1) {
-        const uint32_t ksteps = d / 16, passes = (k + SN - 1) / SN;
+    // split-bf16 form: any d that is a multiple of 32 whose mean fits the block's LDS beside the two B stages, any k.
+    // Everything else (d % 32 != 0, unaligned rows, d beyond ~28k) takes the tiled f32-MFMA kernel below.
+    const uint32_t ksteps = d / 16, passes = (k + SN - 1) / SN;
+    const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
+    if (a.w4x && d % 32 == 0 && lds_bytes <= 160 * 1024) {
         const uint64_t units = (uint64_t)passes * ksteps * SKB;
         u32x4 *tp = nullptr;
         CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
@@ -1650,18 +1259,26 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         if (norm_done) *norm_done = a.norm != 0;
         const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
         // large n: 128-row tiles, one 8-wave block per CU (RG = 4: half the B-stage traffic per MFMA); otherwise 64-row tiles,
-        // two 4-wave blocks per CU.  CLEORA_PROJECT=split64 keeps the 64-row form for A/B runs.
-        const bool wide = !(form_env && !std::strcmp(form_env, "split64")) && (n + 127) / 128 >= (uint64_t)cus && !dbg;
+        // two 4-wave blocks per CU
+        const bool wide = (n + 127) / 128 >= (uint64_t)cus;
         const uint64_t tiles = wide ? (n + 127) / 128 : (n + SR - 1) / SR;
         const uint64_t resident = wide ? (uint64_t)cus : 2ull * (uint64_t)cus;
         const unsigned gx = (unsigned)(tiles < resident ? tiles : resident);
-        const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
         const dim3 grid(gx, passes);
+        hipError_t attr_err = hipSuccess;
         auto launch_shape = [&](auto SCt, auto BLt, auto RGt) {
             constexpr bool SC = decltype(SCt)::value, BL = decltype(BLt)::value;
             constexpr int RG = decltype(RGt)::value;
-#define CLEORA_SPLIT_LAUNCH(RING, UU) \
-            hipLaunchKernelGGL((project_split_kernel<SC, BL, RING, UU, RG>), grid, dim3(RG * 128), lds_bytes, stream, a, tp, ksteps, tiles)
+            // the mean of a wide row pushes the block past the 64 KiB a kernel gets without asking (d >= 3872): raise the limit for
+            // the instantiation being launched — per DEVICE and cheap, so on every call
+#define CLEORA_SPLIT_LAUNCH(RING, UU)                                                                                                  \
+            do {                                                                                                                       \
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(project_split_kernel<SC, BL, RING, UU, RG>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+                if (attr_err == hipSuccess)                                                                                            \
+                    hipLaunchKernelGGL((project_split_kernel<SC, BL, RING, UU, RG>), grid, dim3(RG * 128), lds_bytes, stream, a, tp,   \
+                                       ksteps, tiles);                                                                                 \
+            } while (0)
             if constexpr (!BL) {                  // ring of 4 k-steps (the blended operand doubles the ring: 2 there)
                 if (ksteps % 16 == 0) { CLEORA_SPLIT_LAUNCH(4, 16); return; }
                 if (ksteps % 8 == 0) { CLEORA_SPLIT_LAUNCH(4, 8); return; }
@@ -1678,44 +1295,9 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
                 if (scaled) launch_shape(std::true_type{}, std::false_type{}, RGt); else launch_shape(std::false_type{}, std::false_type{}, RGt);
             }
         };
-        if (ksteps % 16 == 0 && !blend && !scaled && dbg) {                  // profiling builds (see the kernel)
-            switch (dbg) {
-                case 1: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 1>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                case 2: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 2>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                case 3: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 3>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                case 4: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 4>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-                default: hipLaunchKernelGGL((project_split_kernel<false, false, 4, 16, 2, 7>), grid, dim3(256), lds_bytes, stream, a, tp, ksteps, tiles); break;
-            }
-        } else if (wide) {
-            launch_rg(std::integral_constant<int, 4>{});
-        } else {
-            launch_rg(std::integral_constant<int, 2>{});
-        }
-        const hipError_t le = hipGetLastError();
-        CL_HIP(hipFreeAsync(tp, stream));
-        CL_HIP(le);
-        return CLEORA_OK;
-    }
-    // rows-in-LDS form: whole rows as float4, reduction index in groups of 8, the X tile within the LDS budget
-    static const bool first_form_only = std::getenv("CLEORA_PROJECT_TILED") != nullptr;   // A/B switch for profiling
-    if (!first_form_only && a.w4x && d % 32 == 0 && d <= 512 && aligned16(mean) && n >= 4 * RM) {
-        const uint32_t col_tiles = ((k + 31) / 32 + 7) / 8 * 8;           // whole 8-tile (256-column) blocks, zero-padded
-        const uint64_t packed = (uint64_t)(d / 8 + 4) * col_tiles * 64 * 4; // floats, incl. 4 groups of padding
-        float *tp = nullptr;
-        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), packed * sizeof(float), stream));
-        hipLaunchKernelGGL(pack_transform_kernel, dim3((unsigned)((packed / 4 + 255) / 256)), dim3(256), 0, stream, t, d, k,
-                           col_tiles, tp);
-        const size_t lds_bytes = (size_t)RM * (d + 4) * sizeof(float) + 64;   // + the one-group read-ahead of the last row
-        // per DEVICE and cheap: set on every call (a process-wide "done" flag broke the second GPU of a multi-device host)
-        CL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(project_rows_kernel<2>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        const uint64_t row_blocks = (n + RM - 1) / RM;
-        CL_REQUIRE(row_blocks < (1ull << 31), "internal: too many row blocks");
-        a.norm = (norm && col_tiles == 8) ? norm : 0;                     // whole rows inside one block only
-        if (norm_done) *norm_done = a.norm != 0;
-        hipLaunchKernelGGL(project_rows_kernel<2>, dim3((unsigned)row_blocks, col_tiles / 8), dim3(256), lds_bytes,
-                           stream, a, tp, col_tiles);
-        const hipError_t le = hipGetLastError();
+        if (wide) launch_rg(std::integral_constant<int, 4>{});
+        else launch_rg(std::integral_constant<int, 2>{});
+        const hipError_t le = attr_err != hipSuccess ? attr_err : hipGetLastError();
         CL_HIP(hipFreeAsync(tp, stream));
         CL_HIP(le);
         return CLEORA_OK;

@@ -334,7 +334,7 @@ int cleora_comm_unique_id(void *id_out);
 int cleora_comm_create(const void *id, int rank, int world, int device, cleora_comm **out);
 int cleora_comm_destroy(cleora_comm *c);
 int cleora_comm_info(const cleora_comm *c, int *rank, int *world, int *device);
-int cleora_comm_set_allgather(cleora_comm *c, int algo);   /* default RING; env CLEORA_ALLGATHER=p2p selects P2P */
+int cleora_comm_set_allgather(cleora_comm *c, int algo);   /* default RING */
 int cleora_comm_get_allgather(const cleora_comm *c, int *algo);   /* which of the two cleora_allgatherv_f32_dev will take */
 
 /* The exchange step of the row partition: buf holds offsets[world] floats (e.g. a row range of the next iterate,
@@ -363,8 +363,11 @@ int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint
  * Selection: from 256 Ki rows on, a threshold from a stratified row sample, ONE pass over the scores that compacts what
  * passes it into a short list (checked on the host: the call synchronises the stream once per batch of queries), the
  * ordering on that list; below that size, or if a list came out shorter than k or longer than its buffer, k rounds of an
- * arg-max over all n scores.  Same result either way.  cleora_topk_last_route(): which one the last call took (1 = the
- * short list in every batch, 0 = in none, 2 = in some); CLEORA_TOPK=rounds|short forces one (tests, A/B).
+ * arg-max over all n scores.  Same result either way.  cleora_topk_last_route(): which one the calling thread's last call took
+ * (1 = the short list in every batch, 0 = in none, 2 = in some); cleora_topk_set_route(route) forces one for the calling thread's
+ * later calls (0 = automatic, the default; 1 = the rounds; 2 = the short list from 2048 rows on) — for tests and A/B runs.
+ * Unlike the other *_dev entry points this one may WAIT for `stream`: the short list's lengths are checked on the host once per
+ * batch of queries (64 per pass).
  * workspace: cleora_topk_workspace_for(n, k, n_queries) BYTES (8 n floats + candidates up to 8 queries, 64 n floats
  * beyond); cleora_topk_workspace(n, k) is the size that serves any batch.  1 <= k <= min(n, 1024). */
 uint64_t cleora_topk_workspace(uint64_t n, uint32_t k);
@@ -373,6 +376,7 @@ int cleora_topk_cosine_dev(const cleora_graph *g, const float *x, uint64_t ldx, 
                            const uint32_t *query_rows_dev, uint32_t n_queries, uint32_t k, int exclude_self,
                            int exclude_existing, uint32_t *out_index_dev, float *out_score_dev, void *workspace, void *stream);
 int cleora_topk_last_route(void);
+int cleora_topk_set_route(int route);
 
 /* ---- host-pointer entry points: what the PyO3 methods call ------------------------- */
 

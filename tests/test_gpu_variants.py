@@ -233,8 +233,8 @@ def _topk_against_numpy(x, queries, k, g=None, rowptr=None, col=None, atol=3e-6)
 
 
 @pytest.mark.parametrize("n,d,k,nq", [(300_000, 32, 10, 3), (300_000, 32, 100, 70), (400_000, 64, 1, 1), (270_000, 16, 1024, 9)])
-def test_topk_selection_from_a_short_list(n, d, k, nq, monkeypatch):
-    """From 256 Ki rows on (and 512 results per batch: below that CLEORA_TOPK=short asks for it) the selection runs on a short list: threshold = the r-th largest of a stratified sample of
+def test_topk_selection_from_a_short_list(n, d, k, nq):
+    """From 256 Ki rows on (and 512 results per batch: below that cleora_topk_set_route(2) asks for it) the selection runs on a short list: threshold = the r-th largest of a stratified sample of
     the scores, one compaction pass, k rounds over what passed (csrc/similarity.hip).  Same contract as the full selection
     (numpy's `argsort()[::-1][:k]`, pycleora/__init__.py:663, 771; scores to 3e-6), both score layouts ([query][row] up to
     8 queries, [row][query] from the matrix cores beyond), with the -2 masks, and the route is the short list."""
@@ -247,21 +247,33 @@ def test_topk_selection_from_a_short_list(n, d, k, nq, monkeypatch):
     g = _hip.Graph.from_host(rowptr, col, vl)
     queries = rng.choice(n, nq, replace=False).astype(np.uint32)
     queries[0] = 3
+    L = _hip.lib()
     if k * nq < 512:
-        monkeypatch.setenv("CLEORA_TOPK", "short")
-    route, _, _ = _topk_against_numpy(x, queries, k, g, rowptr, col)
+        _hip.check(L.cleora_topk_set_route(2))                  # the short list for a batch the plan would leave to the rounds
+    try:
+        route, _, _ = _topk_against_numpy(x, queries, k, g, rowptr, col)
+    finally:
+        _hip.check(L.cleora_topk_set_route(0))
     assert route == 1
     g.close()
 
 
-def test_topk_short_list_on_adversarial_score_layouts(monkeypatch):
+def test_topk_short_list_on_adversarial_score_layouts():
     """Where a sampled threshold could go wrong: (a) scores that grow with the row index (a strided sample of a sorted
     sequence); (b) all rows equal — every score ties, the list overflows its buffer and the batch falls back to the full
     selection (ties: the larger row index first, like numpy's reversed argsort); (c) the k best all inside one stratum.
     The result is numpy's in every case; only (b) may leave the short list."""
     n, d, k = 300_000, 8, 25
     rng = np.random.default_rng(5)
-    monkeypatch.setenv("CLEORA_TOPK", "short")
+    L = _hip.lib()
+    _hip.check(L.cleora_topk_set_route(2))
+    try:
+        _adversarial_layouts(n, d, k, rng, L)
+    finally:
+        _hip.check(L.cleora_topk_set_route(0))
+
+
+def _adversarial_layouts(n, d, k, rng, L):
     t = np.linspace(0.0, 1.5, n, dtype=np.float64)
     x = np.zeros((n, d), np.float32)
     x[:, 0], x[:, 1] = np.cos(t), np.sin(t)                      # cosine with row n-1 grows monotonically with the index
@@ -278,9 +290,9 @@ def test_topk_short_list_on_adversarial_score_layouts(monkeypatch):
     assert route == 1 and set(idx[0].tolist()) == set(range(1001, 1000 + k))
     # the forced forms at a size both can take give identical arrays
     xs = rng.standard_normal((20_000, 24)).astype(np.float32)
-    monkeypatch.setenv("CLEORA_TOPK", "short")
+    _hip.check(L.cleora_topk_set_route(2))
     r1, i1, s1 = _topk_against_numpy(xs, [5, 6, 7, 8, 9, 10, 11, 12, 13, 14], 8)
-    monkeypatch.setenv("CLEORA_TOPK", "rounds")
+    _hip.check(L.cleora_topk_set_route(1))
     r0, i0, s0 = _topk_against_numpy(xs, [5, 6, 7, 8, 9, 10, 11, 12, 13, 14], 8)
     assert (r1, r0) == (1, 0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
 

@@ -16,9 +16,10 @@ OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE, E_RCCL = 0, -1, -2, -3, -4, -5
 LEFT, SYMMETRIC = 0, 1
 F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
 F_L1NORM, F_BLEND_ANY, F_SQDIFF64 = 128, 256, 512
-ABI_VERSION = 2
+ABI_VERSION = 3
 COMM_ID_BYTES = 128
-ALLGATHER_RING, ALLGATHER_P2P = 0, 1
+ALLGATHER_RING, ALLGATHER_P2P, ALLGATHER_PEER = 0, 1, 2
+BALANCE_AUTO, BALANCE_ROWS, BALANCE_NNZ = 0, 1, 2
 
 c_u64, c_u32, c_i64, c_int, c_f32 = (ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_float)
@@ -31,8 +32,31 @@ class GraphInfo(ctypes.Structure):
                 ("hub_segment", c_u32), ("device", ctypes.c_int32), ("has_symmetric", ctypes.c_int32)]
 
 
+class ShardedInfo(ctypes.Structure):
+    _fields_ = [("n", c_u64), ("n_pad", c_u64), ("local_rows", c_u64), ("local_nnz", c_u64), ("device_bytes", c_u64),
+                ("steps", c_u32), ("rank", ctypes.c_int32), ("world", ctypes.c_int32), ("balance", ctypes.c_int32),
+                ("has_symmetric", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/cleora_hip.h one to one
 SIGNATURES = {
+    "cleora_comm_local_id": (c_int, [vp]),
+    "cleora_comm_create_local": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp)]),
+    "cleora_comm_enable_peer": (c_int, [vp]),
+    "cleora_comm_register": (c_int, [vp, vp, c_u64]),
+    "cleora_comm_unregister": (c_int, [vp, vp]),
+    "cleora_comm_check": (c_int, [vp]),
+    "cleora_sharded_plan": (c_int, [c_u64, vp, c_u32, c_u32, c_int, vp, ctypes.POINTER(c_u64), ctypes.POINTER(c_int)]),
+    "cleora_sharded_create": (c_int, [vp, c_int, c_u64, c_u64, vp, vp, vp, vp, c_int, c_u32, c_int, ctypes.POINTER(vp)]),
+    "cleora_sharded_destroy": (c_int, [vp]),
+    "cleora_sharded_get_info": (c_int, [vp, ctypes.POINTER(ShardedInfo)]),
+    "cleora_sharded_bounds": (c_int, [vp, vp]),
+    "cleora_sharded_block": (c_int, [vp, c_u32, ctypes.POINTER(vp), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
+    "cleora_sharded_propagate_dev": (c_int, [vp, c_int, vp, vp, c_u32, c_u32, c_f32, vp, c_int, vp]),
+    "cleora_sharded_set_timing": (c_int, [vp, c_int]),
+    "cleora_sharded_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 2), ctypes.POINTER(c_u64)]),
+    "cleora_embed_sharded_bytes": (c_u64, [c_u64, c_u64, c_u64, c_u32, c_u32, c_u32]),
+    "cleora_embed_sharded": (c_int, [vp, vp, c_int, c_u32, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),
     "cleora_abi_version": (c_int, []),
     "cleora_last_error": (ctypes.c_char_p, []),
     "cleora_device_count": (c_int, [ctypes.POINTER(c_int)]),

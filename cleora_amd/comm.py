@@ -94,21 +94,27 @@ class TorchComm:
 
 
 class RcclComm:
-    """The C-ABI communicator: RCCL over xGMI, collectives on a communication stream of its own.
+    """The C-ABI communicator, collectives on a communication stream of its own.  Two transports under the same calls
+    (csrc/comm.hip, csrc/peer.hip):
+      * RCCL over xGMI (the default; `enable_peer()` adds the peer-direct all-gather as a third algorithm);
+      * local=True: no RCCL at all — hipIpc mappings between the ranks of one node: peer-direct all-gather, all-reduce summed
+        in rank order on every rank, broadcast.  Unlike RCCL it accepts several ranks on ONE device, which is how the multi-rank
+        loops run through the C ABI on a one-GPU box (tests, bench.py --share-gpu).
 
     stream_fn() returns the compute stream (a hipStream_t as int, None = the default stream); with torch
     present it defaults to torch's current stream on `device`."""
 
-    def __init__(self, unique_id, rank, world, device=0, stream_fn=None):
+    def __init__(self, unique_id, rank, world, device=0, stream_fn=None, local=False):
         self.L = _hip.lib()
         self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self.local = bool(local)
         if len(unique_id) != _hip.COMM_ID_BYTES:
             raise ValueError(f"unique_id must be {_hip.COMM_ID_BYTES} bytes")
         idbuf = (ctypes.c_char * _hip.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         _hip.check(self.L.cleora_set_device(self.device))
         h = _hip.vp()
-        _hip.check(self.L.cleora_comm_create(ctypes.cast(idbuf, _hip.vp), self.rank, self.world, self.device,
-                                             ctypes.byref(h)))
+        create = self.L.cleora_comm_create_local if self.local else self.L.cleora_comm_create
+        _hip.check(create(ctypes.cast(idbuf, _hip.vp), self.rank, self.world, self.device, ctypes.byref(h)))
         self.handle = h
         s = _hip.vp()
         _hip.check(self.L.cleora_stream_create(ctypes.byref(s)))
@@ -117,19 +123,39 @@ class RcclComm:
         self._pending = False
 
     @staticmethod
-    def unique_id():
+    def unique_id(local=False):
         buf = (ctypes.c_char * _hip.COMM_ID_BYTES)()
-        _hip.check(_hip.lib().cleora_comm_unique_id(ctypes.cast(buf, _hip.vp)))
+        L = _hip.lib()
+        _hip.check((L.cleora_comm_local_id if local else L.cleora_comm_unique_id)(ctypes.cast(buf, _hip.vp)))
         return bytes(buf)
 
     @classmethod
-    def from_torch_distributed(cls, device, group=None):
-        """torch.distributed (any backend) as the launcher: rank 0 draws the RCCL id, the group broadcasts it."""
+    def from_torch_distributed(cls, device, group=None, local=False):
+        """torch.distributed (any backend) as the launcher: rank 0 draws the id, the group broadcasts it."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [cls.unique_id(local) if rank == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group else 0, group=group)
-        return cls(box[0], rank, world, device)
+        return cls(box[0], rank, world, device, local=local)
+
+    def enable_peer(self):
+        """Adds the peer-direct transport to an RCCL communicator (collective): ALLGATHER_PEER becomes selectable."""
+        _hip.check(self.L.cleora_comm_enable_peer(self.handle))
+
+    def register(self, t):
+        """Every rank passes its copy of a buffer the peer-direct all-gather will work in (collective; a no-op without the peer
+        transport).  `t`: a torch tensor / DevArray-like with data_ptr() or .ptr, and its byte size."""
+        p = t.data_ptr() if hasattr(t, "data_ptr") else t.ptr
+        nbytes = t.numel() * t.element_size() if hasattr(t, "numel") else t.nbytes
+        _hip.check(self.L.cleora_comm_register(self.handle, p, nbytes))
+
+    def unregister(self, t):
+        p = t.data_ptr() if hasattr(t, "data_ptr") else t.ptr
+        _hip.check(self.L.cleora_comm_unregister(self.handle, p))
+
+    def check(self):
+        """Raises if a device-side wait of this rank ever timed out (a peer died)."""
+        _hip.check(self.L.cleora_comm_check(self.handle))
 
     def _torch_stream(self):
         try:

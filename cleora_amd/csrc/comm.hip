@@ -10,20 +10,31 @@
 //
 // Every collective is IN PLACE on device memory and only ENQUEUES on the caller's stream (NCCL semantics):
 // order it against the SpMM with cleora_stream_wait_stream.
+//
+// Second transport (round 4): PEER-DIRECT exchange over hipIpc mappings, for the ranks of ONE node (north_star's layout).
+// Every rank maps the peers' registered buffers (cleora_comm_register) and a small uncached mailbox; the all-gather is then a
+// copy kernel that stores this rank's finished rows straight into every peer's replica ("peer-mapped direct
+// stores"), followed by a release store of a sequence number into each peer's mailbox; a consumer waits with a one-wave kernel
+// that polls its own mailbox (bounded: a peer that never arrives raises an error instead of hanging the GPU).  No staging
+// buffers, no ring: every shard crosses each xGMI link once, all links at the same time.  The node-local bootstrap (handles,
+// host barrier) is a POSIX shared-memory segment named after the communicator's id.
+//   * on an RCCL communicator it is an additional all-gather algorithm (CLEORA_ALLGATHER_PEER) beside the ring / send-recv ones;
+//   * a LOCAL communicator (cleora_comm_create_local) has no RCCL underneath at all: all-gather, all-reduce (every rank sums the
+//     peers' contributions in rank order: bit-identical everywhere) and broadcast over the same mappings.  RCCL refuses two ranks
+//     on one device, hipIpc does not — so the multi-rank loops run through the C ABI on a one-GPU box too (tests).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 #include "common.h"
 
-struct cleora_comm {
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1, device = 0;
-    int allgather_algo = 0;   // 0: ncclAllGather when the shards are equal, else grouped broadcasts; 1: direct send/recv mesh
-    std::mutex mu;
-};
+#include "comm_internal.h"
 
 namespace cleora {
 namespace {
@@ -171,6 +182,7 @@ int cleora_comm_create(const void *id, int rank, int world, int device, cleora_c
     c->device = device;
     ncclUniqueId uid;
     std::memcpy(&uid, id, sizeof(uid));
+    std::memcpy(c->id, id, sizeof(c->id));
     const ncclResult_t e = r->comm_init_rank(&c->comm, world, uid, rank);
     if (e != ncclSuccess) {
         delete c;
@@ -180,8 +192,72 @@ int cleora_comm_create(const void *id, int rank, int world, int device, cleora_c
     return CLEORA_OK;
 }
 
+int cleora_comm_local_id(void *id_out) {
+    CL_REQUIRE(id_out != nullptr, "id_out is NULL");
+    unsigned char *id = static_cast<unsigned char *>(id_out);
+    std::memset(id, 0, CLEORA_COMM_ID_BYTES);
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    size_t got = f ? std::fread(id, 1, 32, f) : 0;
+    if (f) std::fclose(f);
+    const uint64_t salt[2] = {(uint64_t)getpid(), (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count()};
+    std::memcpy(id + 32, salt, sizeof salt);
+    (void)got;
+    std::memcpy(id + 64, "cleora-local", 12);
+    return CLEORA_OK;
+}
+
+int cleora_comm_create_local(const void *id, int rank, int world, int device, cleora_comm **out) {
+    CL_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    CL_REQUIRE(id != nullptr, "id is NULL");
+    CL_REQUIRE(world >= 1 && rank >= 0 && rank < world, "need 0 <= rank < world");
+    CL_HIP(hipSetDevice(device));
+    cleora_comm *c = new (std::nothrow) cleora_comm();
+    if (!c) {
+        set_error("host allocation failed");
+        return CLEORA_E_OOM;
+    }
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    c->allgather_algo = CLEORA_ALLGATHER_PEER;
+    std::memcpy(c->id, id, sizeof(c->id));
+    const int rc = peer_enable(c);
+    if (rc != CLEORA_OK) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return CLEORA_OK;
+}
+
+int cleora_comm_enable_peer(cleora_comm *c) {
+    CL_REQUIRE(c != nullptr, "comm is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
+    return peer_enable(c);
+}
+
+int cleora_comm_register(cleora_comm *c, void *buf_dev, uint64_t bytes) {
+    CL_REQUIRE(c != nullptr, "comm is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->peer) return CLEORA_OK;                      // RCCL needs no registration
+    return peer_register(c, buf_dev, bytes);
+}
+
+int cleora_comm_unregister(cleora_comm *c, void *buf_dev) {
+    CL_REQUIRE(c != nullptr, "comm is NULL");
+    std::lock_guard<std::mutex> lock(c->mu);
+    return peer_unregister(c, buf_dev);
+}
+
+int cleora_comm_check(cleora_comm *c) {
+    CL_REQUIRE(c != nullptr, "comm is NULL");
+    return peer_check(c);
+}
+
 int cleora_comm_destroy(cleora_comm *c) {
     if (!c) return CLEORA_OK;
+    peer_destroy(c);
     Rccl &r = rccl();
     if (r.lib && c->comm) {
         (void)hipSetDevice(c->device);
@@ -201,7 +277,9 @@ int cleora_comm_info(const cleora_comm *c, int *rank, int *world, int *device) {
 
 int cleora_comm_set_allgather(cleora_comm *c, int algo) {
     CL_REQUIRE(c != nullptr, "comm is NULL");
-    CL_REQUIRE(algo == CLEORA_ALLGATHER_RING || algo == CLEORA_ALLGATHER_P2P, "unknown all-gather algorithm");
+    CL_REQUIRE(algo == CLEORA_ALLGATHER_RING || algo == CLEORA_ALLGATHER_P2P || algo == CLEORA_ALLGATHER_PEER, "unknown all-gather algorithm");
+    CL_REQUIRE(algo == CLEORA_ALLGATHER_PEER || c->comm != nullptr, "a local communicator has the peer-direct all-gather only");
+    CL_REQUIRE(algo != CLEORA_ALLGATHER_PEER || c->peer != nullptr, "enable the peer transport first (cleora_comm_enable_peer)");
     std::lock_guard<std::mutex> lock(c->mu);
     c->allgather_algo = algo;
     return CLEORA_OK;
@@ -221,6 +299,10 @@ int cleora_allgatherv_f32_dev(cleora_comm *c, float *buf, const uint64_t *offset
     for (int r = 0; r < P; ++r) {
         CL_REQUIRE(offsets[r] <= offsets[r + 1], "offsets must be non-decreasing");
         if (offsets[r + 1] - offsets[r] != offsets[1] - offsets[0]) equal = false;
+    }
+    if (c->allgather_algo == CLEORA_ALLGATHER_PEER || !c->comm) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        return peer_allgatherv_f32(c, buf, offsets, S(stream));
     }
     // (a world of one still goes through RCCL: a single-GPU box then exercises the same calls)
     Rccl *r;
@@ -275,6 +357,10 @@ static int allreduce(cleora_comm *c, void *buf, uint64_t n, ncclDataType_t t, vo
     CL_REQUIRE(c != nullptr, "comm is NULL");
     CL_REQUIRE(buf != nullptr || n == 0, "buf is NULL");
     if (n == 0) return CLEORA_OK;
+    if (!c->comm) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        return peer_allreduce(c, buf, n, t == ncclDouble, S(stream));
+    }
     Rccl *r;
     int rc = need_rccl(&r);
     if (rc != CLEORA_OK) return rc;
@@ -297,6 +383,10 @@ int cleora_broadcast_dev(cleora_comm *c, void *buf, uint64_t bytes, int root, vo
     CL_REQUIRE(root >= 0 && root < c->world, "bad root");
     CL_REQUIRE(buf != nullptr || bytes == 0, "buf is NULL");
     if (bytes == 0) return CLEORA_OK;
+    if (!c->comm) {
+        std::lock_guard<std::mutex> lock(c->mu);
+        return peer_broadcast(c, buf, bytes, root, S(stream));
+    }
     Rccl *r;
     int rc = need_rccl(&r);
     if (rc != CLEORA_OK) return rc;
@@ -317,6 +407,7 @@ int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint
             CL_HIP(hipMemcpyAsync(recv, send, elems_per_rank * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
         return CLEORA_OK;
     }
+    CL_REQUIRE(c->comm != nullptr, "a local communicator has no all-to-all (the column partition's layout switch needs RCCL)");
     Rccl *r;
     int rc = need_rccl(&r);
     if (rc != CLEORA_OK) return rc;

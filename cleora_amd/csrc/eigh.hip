@@ -188,15 +188,15 @@ int launch_mean(const double *colsum, uint64_t n, uint32_t d, double *mean64, fl
 //   * potrf reports a non-positive pivot, or the smallest squared pivot is < 1e-8;
 //   * trace(cov^-1) = ||L^-T||_F^2 > 1e10: sum 1/lambda_i >= 1/lambda_min, so passing proves lambda_min >= 1e-10, i.e. that
 //     np.maximum(eigenvalues, 1e-10) (pycleora/__init__.py:155) is inactive;
-//   * approximate_gram (the Gram came from the split-bf16 form, ~1e-8 of the f64 one: ||dG||_2 <~ 2e-8 trace(cov) / d) and
-//     sum_i (trace(cov) / d) / lambda_i > kMaxRelativeSpread = 1e5: in a direction of variance lambda the
-//     transform built on that Gram is off by ~2e-8 (trace / d) / lambda, so a spread below 1e5 keeps W^T cov_exact W within
-//     2e-3 of I in the worst direction (typically two orders less: the sum runs over d terms) — and with it the clamp check
-//     holds for the exact covariance too (lambda_min >= 1e-5 trace / d >> 1e-10 + the Gram's error).
+//   * approximate_gram (the Gram came from the split-bf16 form: ||dG||_2 <~ 1e-7 n trace(cov) / d — whiten.hip launch_gram32) and
+//     sum_i (trace(cov) / d) / lambda_i > kMaxRelativeSpread = 1e4: in a direction of variance lambda the
+//     transform built on that Gram is off by ~1e-7 (trace / d) / lambda, so a spread below 1e4 keeps W^T cov_exact W within
+//     1e-3 of I in the worst direction (typically two orders less: the sum runs over d terms) — and with it the clamp check
+//     holds for the exact covariance too (lambda_min >= 1e-4 trace / d >> 1e-10 + the Gram's error).
 // Two routes: d <= 256 on one host core (dxd_host.cpp: Gram down, transform up, ~1 ms — the ~215 small launches of the library
 // route cost 3.5 ms of launch latency per iteration and slow the SpMM beside them), wider matrices on rocSOLVER's potrf + trtri.
 // (A third route, a single-launch in-house kernel, measured slower than both: scripts/rejected/cholesky_whiten_kernel.hip.txt.)
-constexpr double kMaxRelativeSpread = 1e5;
+constexpr double kMaxRelativeSpread = 1e4;
 
 __global__ __launch_bounds__(256) void diag_sum_kernel(const double *__restrict__ m, uint32_t d, double scale, double *__restrict__ out) {
     __shared__ double sm[256];

@@ -1,0 +1,459 @@
+// peer.hip — the PEER-DIRECT transport of the communicator (comm.hip has the RCCL one): the ranks of one node map each other's
+// buffers with hipIpc and exchange data with plain stores / loads over xGMI (or inside one GPU when ranks share it).
+//
+// The reference has no distributed code (pycleora is single-process: rayon over rows, src/embedding.rs:59-63); this is the
+// exchange step BASELINE.json:north_star asks for, in the form SURVEY.md 8e names as the mitigation for the all-gather being
+// the critical path at 8 GPUs: "peer-mapped direct stores".
+//
+//   bootstrap   a POSIX shared-memory segment named after the communicator's id: a sense-reversing barrier for the ranks' HOST
+//               threads and one 128-byte record per rank for exchanging hipIpc handles.  Node-local by construction.
+//   mailbox     per rank, device memory allocated UNCACHED (hipDeviceMallocUncached): flags[channel][rank] = the last
+//               sequence number that rank signalled; mapped by every peer.
+//   register    a buffer every rank holds (the replicas of the iterate) is exported once and mapped by every peer.
+//   all-gather  push_kernel: this rank's shard -> the same offsets of every peer's buffer (blockIdx.y = peer: all links at the
+//               same time), then signal_kernel: a system-scope release store of the sequence number into every peer's mailbox
+//               (a kernel boundary separates data and flag), then wait_kernel: one wave polls the own mailbox until every peer
+//               has signalled — bounded by a wall-clock budget, after which it records an error instead of hanging the GPU.
+//               The consumer's next kernel starts with the usual acquire, so it sees the peers' stores.
+//   all-reduce  (local communicators) post to the own scratch, signal, wait, then EVERY rank sums the P contributions in rank
+//               order through the mappings: bit-identical results on all ranks, no reduction tree.  Scratch halves alternate
+//               with the sequence number; a half is reused two operations later, when every peer has provably read it.
+//   broadcast   the same through the root's scratch.
+// Why a rank may safely store into a peer's replica: rank r writes rows of X_next of iteration t only after its own SpMM of that
+// block, which needs all of X of iteration t, i.e. every peer's last signal of iteration t-1 — sent after that peer's last
+// kernel reading the buffer that is X_next now.  (sharded.hip keeps that order: gathers of an iteration are joined before the
+// next iteration's first kernel.)
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "comm_internal.h"
+
+namespace cleora {
+
+constexpr int kMaxWorld = 64;
+constexpr int kChannels = 2;                  // 0: all-gather, 1: all-reduce / broadcast
+constexpr double kHostBarrierSeconds = 180.0; // a rank that never arrives is an error, not a hang
+constexpr uint64_t kWaitTicks = 60ull * 100000000ull;   // wait_kernel's budget: 60 s of the 100 MHz wall clock
+
+struct ShmRecord {                            // what a rank publishes for one exchange
+    hipIpcMemHandle_t handle;
+    uint64_t offset, bytes;
+    int32_t device, ok;
+    uint8_t pad[128 - sizeof(hipIpcMemHandle_t) - 24];
+};
+static_assert(sizeof(ShmRecord) == 128, "record size");
+
+struct ShmSegment {
+    std::atomic<uint32_t> count, sense, failed;
+    uint32_t world;
+    ShmRecord rec[kMaxWorld];
+};
+
+struct Mailbox {                              // device memory (uncached), one per rank
+    uint64_t flags[kChannels][kMaxWorld];
+    uint64_t error;                           // != 0: a wait timed out (channel + 1 in the low byte, the missing rank above it)
+    uint64_t pad[7];
+};
+
+struct Registration {
+    char *local = nullptr;
+    uint64_t bytes = 0;
+    char *peer[kMaxWorld] = {nullptr};        // the same buffer in rank p's memory, as mapped here (nullptr for the own rank)
+    void *mapped_base[kMaxWorld] = {nullptr}; // what hipIpcOpenMemHandle returned (to close)
+};
+
+struct PeerPtrs { void *p[kMaxWorld]; };
+
+struct PeerLayer {
+    ShmSegment *shm = nullptr;
+    size_t shm_bytes = 0;
+    uint32_t local_sense = 0;
+    Mailbox *mailbox = nullptr;               // own (device pointer)
+    Registration mailboxes;                   // every peer's mailbox
+    uint64_t seq[kChannels] = {0, 0};
+    std::vector<Registration> regs;
+    char *scratch = nullptr;                  // all-reduce / broadcast staging, two halves
+    uint64_t scratch_half = 0;
+};
+
+namespace {
+
+uint64_t fnv1a(const unsigned char *p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+int barrier_host(cleora_comm *c) {
+    PeerLayer *pl = c->peer;
+    ShmSegment *s = pl->shm;
+    const uint32_t my = pl->local_sense ^= 1u;
+    if (s->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->world) {
+        s->count.store(0, std::memory_order_relaxed);
+        s->sense.store(my, std::memory_order_release);
+        return CLEORA_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (s->sense.load(std::memory_order_acquire) != my) {
+        if (++spins > 200) { sched_yield(); }
+        if ((spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kHostBarrierSeconds) {
+            set_error("peer transport: a rank did not reach the host barrier within " + std::to_string((int)kHostBarrierSeconds) + " s");
+            return CLEORA_E_RCCL;
+        }
+    }
+    return CLEORA_OK;
+}
+
+// every rank publishes (ptr, bytes) [ptr may be nullptr: ok = 0], all map all; returns with `out` filled.  Collective.
+int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *out) {
+    PeerLayer *pl = c->peer;
+    ShmRecord &mine = pl->shm->rec[c->rank];
+    std::memset(&mine, 0, sizeof(mine));
+    int rc = CLEORA_OK;
+    void *base = nullptr;
+    size_t range = 0;
+    if (ptr) {
+        hipError_t e = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &range, ptr);
+        if (e == hipSuccess) e = hipIpcGetMemHandle(&mine.handle, base);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error(std::string("peer transport: the buffer cannot be exported with hipIpcGetMemHandle (") + hipGetErrorString(e) +
+                      "); it must come from hipMalloc / cleora_malloc, and HSA_ENABLE_IPC_MODE_LEGACY=0 must be set");
+            rc = CLEORA_E_HIP;
+        } else {
+            mine.offset = (uint64_t)(static_cast<char *>(ptr) - static_cast<char *>(base));
+            mine.bytes = bytes;
+            mine.device = c->device;
+            mine.ok = 1;
+        }
+    }
+    int b = barrier_host(c);
+    if (b != CLEORA_OK) return b;
+    out->local = static_cast<char *>(ptr);
+    out->bytes = bytes;
+    for (int p = 0; p < c->world && rc == CLEORA_OK; ++p) {
+        if (p == c->rank) continue;
+        const ShmRecord &r = pl->shm->rec[p];
+        if (!r.ok || r.bytes != bytes) {
+            set_error("peer transport: rank " + std::to_string(p) + " did not publish a matching buffer");
+            rc = CLEORA_E_INVALID;
+            break;
+        }
+        void *mapped = nullptr;
+        hipIpcMemHandle_t h = r.handle;
+        const hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error(std::string("peer transport: hipIpcOpenMemHandle of rank ") + std::to_string(p) + "'s buffer failed (" + hipGetErrorString(e) + ")");
+            rc = CLEORA_E_HIP;
+            break;
+        }
+        out->mapped_base[p] = mapped;
+        out->peer[p] = static_cast<char *>(mapped) + r.offset;
+    }
+    if (rc != CLEORA_OK) pl->shm->failed.store(1, std::memory_order_release);
+    b = barrier_host(c);                                    // nobody reuses the records before everybody has read them
+    if (b != CLEORA_OK) return b;
+    if (pl->shm->failed.load(std::memory_order_acquire)) {
+        for (int p = 0; p < c->world; ++p)
+            if (out->mapped_base[p]) { (void)hipIpcCloseMemHandle(out->mapped_base[p]); out->mapped_base[p] = nullptr; out->peer[p] = nullptr; }
+        if (rc == CLEORA_OK) { set_error("peer transport: the exchange failed on another rank"); rc = CLEORA_E_RCCL; }
+        (void)barrier_host(c);
+        if (c->rank == 0) pl->shm->failed.store(0, std::memory_order_release);
+        (void)barrier_host(c);
+        return rc;
+    }
+    return CLEORA_OK;
+}
+
+void close_registration(Registration &r, int world) {
+    for (int p = 0; p < world; ++p)
+        if (r.mapped_base[p]) { (void)hipIpcCloseMemHandle(r.mapped_base[p]); r.mapped_base[p] = nullptr; r.peer[p] = nullptr; }
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------------------
+// this rank's shard into every peer: blockIdx.y = peer slot (dst.p[] is already offset to the shard and ordered for link stagger)
+__global__ __launch_bounds__(256) void push_kernel(const float *__restrict__ src, PeerPtrs dst, uint64_t n_floats, int vec4) {
+    float *out = static_cast<float *>(dst.p[blockIdx.y]);
+    const uint64_t stride = (uint64_t)gridDim.x * 256, t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vec4) {
+        const uint64_t n4 = n_floats >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *o4 = reinterpret_cast<float4 *>(out);
+        for (uint64_t i = t0; i < n4; i += stride) o4[i] = s4[i];
+        for (uint64_t i = (n4 << 2) + t0; i < n_floats; i += stride) out[i] = src[i];
+    } else {
+        for (uint64_t i = t0; i < n_floats; i += stride) out[i] = src[i];
+    }
+}
+
+// flags[channel][me] = seq in every peer's mailbox (lane = peer)
+__global__ void signal_kernel(PeerPtrs mailboxes, int channel, int me, int world, uint64_t seq) {
+    const int p = threadIdx.x;
+    if (p >= world || p == me) return;
+    Mailbox *mb = static_cast<Mailbox *>(mailboxes.p[p]);
+    __hip_atomic_store(&mb->flags[channel][me], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// until every peer's flag of `channel` in the OWN mailbox has reached seq
+__global__ void wait_kernel(Mailbox *mb, int channel, int me, int world, uint64_t seq, uint64_t budget_ticks) {
+    const int p = threadIdx.x;
+    if (p >= world || p == me) return;
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(&mb->flags[channel][p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > budget_ticks) {
+            __hip_atomic_store(&mb->error, (uint64_t)(channel + 1) | ((uint64_t)p << 8) | (seq << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+}
+
+// out[i] = sum over ranks (in rank order) of their posted vectors; src.p[r] = rank r's scratch half (own one included)
+template <class T>
+__global__ __launch_bounds__(256) void reduce_kernel(PeerPtrs src, int world, uint64_t n, T *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        T s = 0;
+        for (int r = 0; r < world; ++r) {
+            // a load that does not stop at this device's non-coherent caches: the peer wrote the value in ITS memory
+            const T *p = static_cast<const T *>(src.p[r]) + i;
+            if constexpr (sizeof(T) == 8) {
+                const uint64_t bits = __hip_atomic_load(reinterpret_cast<const uint64_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s += __builtin_bit_cast(T, bits);
+            } else {
+                const uint32_t bits = __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                s += __builtin_bit_cast(T, bits);
+            }
+        }
+        out[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void fetch_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint64_t n_words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int signal_and_wait(cleora_comm *c, int channel, uint64_t seq, hipStream_t stream) {
+    PeerLayer *pl = c->peer;
+    PeerPtrs mb{};
+    for (int p = 0; p < c->world; ++p) mb.p[p] = p == c->rank ? (void *)pl->mailbox : (void *)pl->mailboxes.peer[p];
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(kMaxWorld), 0, stream, mb, channel, c->rank, c->world, seq);
+    hipLaunchKernelGGL(wait_kernel, dim3(1), dim3(kMaxWorld), 0, stream, pl->mailbox, channel, c->rank, c->world, seq, kWaitTicks);
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+// staging for all-reduce / broadcast: two halves of at least `bytes`; growing it is collective and host-synchronous
+int ensure_scratch(cleora_comm *c, uint64_t bytes, hipStream_t stream) {
+    PeerLayer *pl = c->peer;
+    if (pl->scratch && pl->scratch_half >= bytes) return CLEORA_OK;
+    CL_HIP(hipStreamSynchronize(stream));                   // whatever still reads the old staging
+    int rc;
+    if (pl->scratch) {
+        if ((rc = peer_unregister(c, pl->scratch)) != CLEORA_OK) return rc;
+        (void)hipFree(pl->scratch);
+        pl->scratch = nullptr;
+    }
+    uint64_t half = 1ull << 20;
+    while (half < bytes) half <<= 1;
+    void *p = nullptr;
+    CL_HIP(hipMalloc(&p, 2 * half));
+    pl->scratch = static_cast<char *>(p);
+    pl->scratch_half = half;
+    return peer_register(c, pl->scratch, 2 * half);
+}
+
+Registration *find_registration(PeerLayer *pl, const void *ptr, uint64_t bytes) {
+    const char *b = static_cast<const char *>(ptr);
+    for (Registration &r : pl->regs)
+        if (b >= r.local && b + bytes <= r.local + r.bytes) return &r;
+    return nullptr;
+}
+
+}  // namespace
+
+int peer_host_barrier(cleora_comm *c) {
+    if (!c->peer || c->world == 1) return CLEORA_OK;
+    return barrier_host(c);
+}
+
+int peer_enable(cleora_comm *c) {
+    if (c->peer) return CLEORA_OK;
+    CL_REQUIRE(c->world <= kMaxWorld, "the peer transport serves at most 64 ranks (one node)");
+    CL_HIP(hipSetDevice(c->device));
+    PeerLayer *pl = new (std::nothrow) PeerLayer();
+    if (!pl) { set_error("host allocation failed"); return CLEORA_E_OOM; }
+    c->peer = pl;
+    auto fail = [&](int rc) { peer_destroy(c); return rc; };
+    // the mailbox: uncached device memory where the platform offers it (flags polled by a running kernel must not sit in a
+    // non-coherent cache), else fine-grained, else plain (enough when the ranks share one device)
+    void *mb = nullptr;
+    if (hipExtMallocWithFlags(&mb, sizeof(Mailbox), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(&mb, sizeof(Mailbox), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hipMalloc(&mb, sizeof(Mailbox)) != hipSuccess) { (void)hipGetLastError(); set_error("peer transport: no memory for the mailbox"); return fail(CLEORA_E_OOM); }
+        }
+    }
+    pl->mailbox = static_cast<Mailbox *>(mb);
+    if (hipMemset(mb, 0, sizeof(Mailbox)) != hipSuccess) { (void)hipGetLastError(); set_error("peer transport: hipMemset failed"); return fail(CLEORA_E_HIP); }
+    if (c->world == 1) return CLEORA_OK;
+    char name[64];
+    std::snprintf(name, sizeof name, "/cleora.%016llx", (unsigned long long)fnv1a(c->id, sizeof c->id));
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { set_error(std::string("peer transport: shm_open failed: ") + std::strerror(errno)); return fail(CLEORA_E_RCCL); }
+    pl->shm_bytes = sizeof(ShmSegment);
+    if (ftruncate(fd, (off_t)pl->shm_bytes) != 0) { close(fd); set_error("peer transport: ftruncate of the shared segment failed"); return fail(CLEORA_E_RCCL); }
+    void *m = mmap(nullptr, pl->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { set_error("peer transport: mmap of the shared segment failed"); return fail(CLEORA_E_RCCL); }
+    pl->shm = static_cast<ShmSegment *>(m);                  // a fresh segment is zero-filled: barrier state starts at 0 everywhere
+    int rc = barrier_host(c);
+    if (c->rank == 0) (void)shm_unlink(name);               // the mappings live on; nothing is left behind if a rank dies later
+    if (rc != CLEORA_OK) return fail(rc);
+    if ((rc = exchange_and_map(c, pl->mailbox, sizeof(Mailbox), &pl->mailboxes)) != CLEORA_OK) return fail(rc);
+    return CLEORA_OK;
+}
+
+void peer_destroy(cleora_comm *c) {
+    PeerLayer *pl = c->peer;
+    if (!pl) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (Registration &r : pl->regs) close_registration(r, c->world);
+    close_registration(pl->mailboxes, c->world);
+    if (pl->shm && c->world > 1) (void)barrier_host(c);      // peers have closed their mappings of OUR memory before we free it
+    if (pl->scratch) (void)hipFree(pl->scratch);
+    if (pl->mailbox) (void)hipFree(pl->mailbox);
+    if (pl->shm) munmap(pl->shm, pl->shm_bytes);
+    delete pl;
+    c->peer = nullptr;
+}
+
+int peer_register(cleora_comm *c, void *buf, uint64_t bytes) {
+    CL_REQUIRE(c->peer != nullptr, "the peer transport is not enabled on this communicator");
+    CL_REQUIRE(buf != nullptr && bytes > 0, "buf is NULL / empty");
+    PeerLayer *pl = c->peer;
+    if (Registration *r = find_registration(pl, buf, bytes)) { (void)r; return CLEORA_OK; }
+    CL_HIP(hipSetDevice(c->device));
+    Registration reg;
+    if (c->world > 1) {
+        const int rc = exchange_and_map(c, buf, bytes, &reg);
+        if (rc != CLEORA_OK) return rc;
+    } else {
+        reg.local = static_cast<char *>(buf);
+        reg.bytes = bytes;
+    }
+    pl->regs.push_back(reg);
+    return CLEORA_OK;
+}
+
+int peer_unregister(cleora_comm *c, void *buf) {
+    if (!c->peer) return CLEORA_OK;
+    PeerLayer *pl = c->peer;
+    for (size_t k = 0; k < pl->regs.size(); ++k) {
+        if (pl->regs[k].local != static_cast<char *>(buf)) continue;
+        CL_HIP(hipSetDevice(c->device));
+        CL_HIP(hipDeviceSynchronize());                     // our kernels that store into the peers' copies
+        int rc = c->world > 1 ? barrier_host(c) : CLEORA_OK;
+        close_registration(pl->regs[k], c->world);
+        if (rc == CLEORA_OK && c->world > 1) rc = barrier_host(c);   // every mapping of `buf` is closed: the owner may free it
+        pl->regs.erase(pl->regs.begin() + (long)k);
+        return rc;
+    }
+    return CLEORA_OK;
+}
+
+int peer_allgatherv_f32(cleora_comm *c, float *buf, const uint64_t *offsets, hipStream_t stream) {
+    CL_REQUIRE(c->peer != nullptr, "the peer transport is not enabled on this communicator");
+    PeerLayer *pl = c->peer;
+    const int P = c->world, me = c->rank;
+    if (P == 1) return CLEORA_OK;
+    Registration *reg = find_registration(pl, buf, offsets[P] * sizeof(float));
+    CL_REQUIRE(reg != nullptr, "peer-direct all-gather: the buffer is not registered (cleora_comm_register)");
+    CL_HIP(hipSetDevice(c->device));
+    const uint64_t mine = offsets[me + 1] - offsets[me];
+    const uint64_t seq = ++pl->seq[0];
+    if (mine) {
+        const uint64_t byte_off = (uint64_t)(reinterpret_cast<char *>(buf + offsets[me]) - reg->local);
+        PeerPtrs dst{};
+        for (int k = 1; k < P; ++k) dst.p[k - 1] = reg->peer[(me + k) % P] + byte_off;       // staggered: rank r starts with r + 1
+        const bool vec4 = (byte_off & 15u) == 0 && (reinterpret_cast<uintptr_t>(reg->local) & 15u) == 0;
+        const uint64_t units = vec4 ? (mine + 3) / 4 : mine;
+        uint64_t bx = (units + 255) / 256;
+        if (bx > 160) bx = 160;                                                              // bandwidth-bound on the links: a few blocks per CU in total
+        hipLaunchKernelGGL(push_kernel, dim3((unsigned)bx, (unsigned)(P - 1)), dim3(256), 0, stream, buf + offsets[me], dst, mine, vec4 ? 1 : 0);
+    }
+    return signal_and_wait(c, 0, seq, stream);
+}
+
+int peer_allreduce(cleora_comm *c, void *buf, uint64_t n, bool f64, hipStream_t stream) {
+    CL_REQUIRE(c->peer != nullptr, "the peer transport is not enabled on this communicator");
+    PeerLayer *pl = c->peer;
+    if (c->world == 1 || n == 0) return CLEORA_OK;
+    CL_HIP(hipSetDevice(c->device));
+    const uint64_t bytes = n * (f64 ? 8 : 4);
+    int rc = ensure_scratch(c, bytes, stream);
+    if (rc != CLEORA_OK) return rc;
+    const uint64_t seq = ++pl->seq[1];
+    const uint64_t half = (seq & 1) * pl->scratch_half;
+    CL_HIP(hipMemcpyAsync(pl->scratch + half, buf, bytes, hipMemcpyDeviceToDevice, stream));
+    if ((rc = signal_and_wait(c, 1, seq, stream)) != CLEORA_OK) return rc;
+    Registration *reg = find_registration(pl, pl->scratch, 2 * pl->scratch_half);
+    PeerPtrs src{};
+    for (int p = 0; p < c->world; ++p) src.p[p] = (p == c->rank ? pl->scratch : reg->peer[p]) + half;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    if (f64) hipLaunchKernelGGL(reduce_kernel<double>, dim3(blocks), dim3(256), 0, stream, src, c->world, n, static_cast<double *>(buf));
+    else hipLaunchKernelGGL(reduce_kernel<float>, dim3(blocks), dim3(256), 0, stream, src, c->world, n, static_cast<float *>(buf));
+    CL_HIP(hipGetLastError());
+    return CLEORA_OK;
+}
+
+int peer_broadcast(cleora_comm *c, void *buf, uint64_t bytes, int root, hipStream_t stream) {
+    CL_REQUIRE(c->peer != nullptr, "the peer transport is not enabled on this communicator");
+    PeerLayer *pl = c->peer;
+    if (c->world == 1 || bytes == 0) return CLEORA_OK;
+    CL_REQUIRE(bytes % 4 == 0, "broadcast of whole 4-byte words");
+    CL_HIP(hipSetDevice(c->device));
+    int rc = ensure_scratch(c, bytes, stream);
+    if (rc != CLEORA_OK) return rc;
+    const uint64_t seq = ++pl->seq[1];
+    const uint64_t half = (seq & 1) * pl->scratch_half;
+    if (c->rank == root) CL_HIP(hipMemcpyAsync(pl->scratch + half, buf, bytes, hipMemcpyDeviceToDevice, stream));
+    if ((rc = signal_and_wait(c, 1, seq, stream)) != CLEORA_OK) return rc;
+    if (c->rank != root) {
+        Registration *reg = find_registration(pl, pl->scratch, 2 * pl->scratch_half);
+        const uint64_t words = bytes / 4;
+        const unsigned blocks = (unsigned)((words + 255) / 256 > 1024 ? 1024 : (words + 255) / 256);
+        hipLaunchKernelGGL(fetch_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(reg->peer[root] + half),
+                           static_cast<uint32_t *>(buf), words);
+        CL_HIP(hipGetLastError());
+    }
+    return CLEORA_OK;
+}
+
+int peer_check(cleora_comm *c) {
+    if (!c->peer || !c->peer->mailbox) return CLEORA_OK;
+    uint64_t err = 0;
+    CL_HIP(hipMemcpy(&err, &c->peer->mailbox->error, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        set_error("peer transport: rank " + std::to_string(c->rank) + " waited 60 s for rank " + std::to_string((int)((err >> 8) & 0xff)) +
+                  " (channel " + std::to_string((int)(err & 0xff) - 1) + ", operation " + std::to_string((unsigned long long)(err >> 16)) + "): a peer died or the mappings are not coherent");
+        return CLEORA_E_RCCL;
+    }
+    return CLEORA_OK;
+}
+
+}  // namespace cleora

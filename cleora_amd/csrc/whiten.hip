@@ -373,9 +373,10 @@ __device__ __forceinline__ void gram32_fold(double *out, f16v (&acc)[NT], int i,
 //     sum_r r1_a^2 is accumulated beside the matrix cores (one FMA per element in the staging thread that owns the column, f32 over
 //     the octet, f64 across) and added to the diagonal by the reducer (`diagfix`);
 //   * the y1 r2 cross terms: 2^-18 of the entry per row with random sign, 2^-18 / sqrt(n) of the sum.
-// So THREE bf16 MFMAs per product (LEAN) give the Gram to ~1e-8 of the f64 one, like the six-product form of the projection
-// (1,1) (1,2) (2,1) (2,2) (1,3) (3,1) that this kernel used in round 3 — at half the matrix-core work, two thirds of the split
-// arithmetic and two thirds of the LDS traffic (measured: see DESIGN 3.5; LEAN = false keeps the six-product form for the A/B).
+// So THREE bf16 MFMAs per product (LEAN) give the Gram of a LONG matrix to a few 1e-8 of the f64 one — at half the matrix-core
+// work, two thirds of the split arithmetic and two thirds of the LDS traffic of the six-product form (1,1) (1,2) (2,1) (2,2) (1,3)
+// (3,1) of the projection, which LEAN = false keeps for matrices of fewer than 2^20 rows (launch_gram32: the random-walk terms
+// fall as 1 / sqrt(n)).
 // For G = Y^T Y both MFMA operands are "column i, eight consecutive ROWS": lane (i, h) of a fragment holds rows 8h .. 8h+7 of
 // column i of its 32-column block — the A fragment of column block a and the B fragment of column block b are the same kind of
 // thing, and the one of a diagonal tile is one register set used twice.
@@ -1092,6 +1093,7 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
 
 }  // namespace
 
+constexpr uint64_t kLeanGramMinRows = 1ull << 20;
 struct Gram32Plan { uint32_t S, blocks, tiles_per_slice, slices; };
 inline Gram32Plan gram32_plan(uint64_t n, uint32_t d) {
     Gram32Plan p;
@@ -1127,7 +1129,12 @@ int launch_gram32(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *
     CL_REQUIRE(gram32_applies(x, ldx, n, d), "internal: the split Gram does not apply to this shape");
     const Gram32Plan q = gram32_plan(n, d);             // the same plan gram_workspace() sized the workspace for
     CL_REQUIRE(q.slices <= 65535, "internal: too many Gram slices");
-    static const bool six = std::getenv("CLEORA_X_GRAM6") != nullptr;     // EXPERIMENT (round 4, removed before the round ends): the six-product form
+    // Three products from kLeanGramMinRows rows on: the terms they drop are random-signed per row, so their sum falls as
+    // 1 / sqrt(n) relative to the Gram — ||G3 - G64||_F / ||G64||_F = sqrt(d) 2^-18 / sqrt(n), measured 8.0e-7 / 2.2e-7 / 1.05e-7 /
+    // 1.9e-8 at n = 5 003 / 70 001 / 300 007 / 10 M (d = 256) against 8e-9 for the six-product form at 10 M (profiles/r04_gram_forms.txt).
+    // From 2^20 rows that is <= 6e-8 at d = 256 (the class of the f32 matrix cores' 4.4e-8, round 3) for 3.5 instead of 4.7 ms at
+    // the C3 shape; shorter matrices keep the six products — their Gram is a fraction of a millisecond either way.
+    const bool six = n < kLeanGramMinRows;
     Gram32Args a{};
     a.x = x;
     a.ldx = ldx;

@@ -18,15 +18,137 @@ multi-GPU design BASELINE.json:north_star asks for, not a port of anything:
   * the L2 normalisation is row-local and fused into the SpMM epilogue, so what travels over
     xGMI is the finished next iterate.
 
-`backend` does the per-block arithmetic and `comm` the exchange steps (cleora_amd/comm.py).  The product
-path is HipBackend + RcclComm: kernels AND collectives go through the C ABI of libcleora_hip.so (RCCL bound
-directly, csrc/comm.hip), so the same loop can be driven by a non-Python host.  Tests inject a CPU backend
-and a gloo TorchComm so the partition / collective logic runs without a GPU.
+The PRODUCT path is `DeviceShardedGraph`: a thin ctypes wrapper over the row-partitioned loops of libcleora_hip.so
+(csrc/sharded.hip: cleora_sharded_create / cleora_sharded_propagate_dev / cleora_embed_sharded) — block schedule, stream
+ordering, statistics all-reduce and the Cholesky / PCA switch all live behind the C ABI, where a Rust host finds them too
+(INTEGRATION.md); it needs no torch.
+
+`ShardedGraph` / `ColumnShardedGraph` below are the same algorithm with the arithmetic (`backend`) and the exchange steps
+(`comm`, cleora_amd/comm.py) injected: the executable specification the CPU suite runs over gloo with a numpy backend
+(no GPU in the build container), held against the oracle and — for the plan — against cleora_sharded_plan; and the column
+partition that bench.py measures beside north_star's row partition.
 """
-import torch
+import ctypes
+
+import numpy as np
 
 from . import _hip
 from . import comm as comm_mod
+
+try:                                   # the model classes below work on torch tensors; DeviceShardedGraph does not need them
+    import torch
+except ImportError:                    # pragma: no cover
+    torch = None
+
+
+def _dev_ptr(a):
+    """Device pointer of a torch tensor / DevArray (None passes through)."""
+    if a is None:
+        return None
+    return a.data_ptr() if hasattr(a, "data_ptr") else a.ptr
+
+
+class DeviceShardedGraph:
+    """This rank's row blocks of a CSR graph on its GPU and the loops over the partition, through the C ABI (csrc/sharded.hip).
+
+    rowptr / col / val_left / val_sym: the WHOLE graph (identical on every rank) as numpy host arrays, or as device arrays
+    (torch tensors / _hip.DevArray) — only the rank's slices are copied.  comm: an RcclComm (RCCL, or local=True for the
+    peer-direct transport) or None for a world of one.  Replicas are (n_pad, d) f32, rows >= n zero."""
+
+    def __init__(self, n, rowptr, col, val_left, val_sym=None, comm=None, steps=1, balance="auto", device=0):
+        L = self.L = _hip.lib()
+        self.comm = comm
+        mode = {"auto": _hip.BALANCE_AUTO, "rows": _hip.BALANCE_ROWS, "nnz": _hip.BALANCE_NNZ}.get(balance)
+        if mode is None:
+            raise ValueError("balance must be 'auto', 'rows' or 'nnz'")
+        on_device = not isinstance(rowptr, np.ndarray)
+        if on_device:
+            args = [_dev_ptr(rowptr), _dev_ptr(col), _dev_ptr(val_left), _dev_ptr(val_sym)]
+            nnz = int(col.numel() if hasattr(col, "numel") else col.shape[0])
+        else:
+            rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val_left = np.ascontiguousarray(val_left, dtype=np.float32)
+            val_sym = None if val_sym is None else np.ascontiguousarray(val_sym, dtype=np.float32)
+            args = [_hip.ptr(rowptr), _hip.ptr(col), _hip.ptr(val_left), _hip.ptr(val_sym)]
+            nnz = int(col.shape[0])
+        h = _hip.vp()
+        _hip.check(L.cleora_sharded_create(comm.handle if comm is not None else None, int(device), int(n), nnz, *args,
+                                           1 if on_device else 0, int(steps), mode, ctypes.byref(h)))
+        self.handle = h
+        info = _hip.ShardedInfo()
+        _hip.check(L.cleora_sharded_get_info(h, ctypes.byref(info)))
+        self.n, self.n_pad, self.local_rows, self.local_nnz = info.n, info.n_pad, info.local_rows, info.local_nnz
+        self.steps, self.rank, self.world = info.steps, info.rank, info.world
+        self.balance = {_hip.BALANCE_ROWS: "rows", _hip.BALANCE_NNZ: "nnz"}[info.balance]
+        b = np.zeros(self.world * self.steps + 1, dtype=np.uint64)
+        _hip.check(L.cleora_sharded_bounds(h, _hip.ptr(b)))
+        self.bounds = [int(v) for v in b]
+        self.my_rows = [(self.bounds[k * self.world + self.rank], self.bounds[k * self.world + self.rank + 1]) for k in range(self.steps)]
+
+    def block(self, k):
+        """(a borrowed _hip.Graph view of block k, row_begin, row_end) — for info / timing; do not close it."""
+        g, b0, b1 = _hip.vp(), _hip.c_u64(0), _hip.c_u64(0)
+        _hip.check(self.L.cleora_sharded_block(self.handle, int(k), ctypes.byref(g), ctypes.byref(b0), ctypes.byref(b1)))
+        view = _hip.Graph.__new__(_hip.Graph)
+        view.handle, view._keepalive = None, self             # never destroyed through the view
+        view.borrowed = g
+        return view, b0.value, b1.value
+
+    def block_info(self, k):
+        g, _, _ = self.block(k)
+        gi = _hip.GraphInfo()
+        _hip.check(self.L.cleora_graph_get_info(g.borrowed, ctypes.byref(gi)))
+        return gi
+
+    def propagate(self, kind, x, x_next, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, gather=True, stream=None, d=None):
+        """One iteration; x / x_next: (n_pad, d) replicas (torch tensors or DevArrays)."""
+        d = int(d if d is not None else x.shape[1])
+        if stream is None and torch is not None and hasattr(x, "data_ptr"):
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        _hip.check(self.L.cleora_sharded_propagate_dev(self.handle, int(kind), _dev_ptr(x), _dev_ptr(x_next), d, int(flags), float(rw),
+                                                       _dev_ptr(row_sqdiff), 1 if gather else 0, _hip.vp(stream) if stream else None))
+
+    def embed(self, x, kind, d, iterations, residual_weight=0.0, convergence_threshold=0.0, flags=_hip.F_L2NORM):
+        """The loops of cleora_embed_sharded on the replica x (E_0 in, result out).  Returns the iterations run."""
+        ran = _hip.c_u64(0)
+        _hip.check(self.L.cleora_embed_sharded(self.handle, _dev_ptr(x), int(kind), int(d), int(iterations), float(residual_weight),
+                                               float(convergence_threshold), int(flags), ctypes.byref(ran)))
+        return ran.value
+
+    def embed_bytes(self, d, flags=0):
+        return int(self.L.cleora_embed_sharded_bytes(self.n_pad, self.local_rows, self.n, self.world, int(d), int(flags)))
+
+    def set_timing(self, enable):
+        _hip.check(self.L.cleora_sharded_set_timing(self.handle, 1 if enable else 0))
+
+    def get_timing(self):
+        """((spmm ms, all-gather ms) summed, propagate calls) since the last query."""
+        ms, calls = (ctypes.c_double * 2)(), _hip.c_u64(0)
+        _hip.check(self.L.cleora_sharded_get_timing(self.handle, ctypes.byref(ms), ctypes.byref(calls)))
+        return (ms[0], ms[1]), calls.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.cleora_sharded_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def plan_rows(n, rowptr, world, steps, balance="auto"):
+    """cleora_sharded_plan (pure host arithmetic, no GPU): (bounds list, n_pad, 'rows' | 'nnz')."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+    mode = {"auto": _hip.BALANCE_AUTO, "rows": _hip.BALANCE_ROWS, "nnz": _hip.BALANCE_NNZ}[balance]
+    b = np.zeros(world * steps + 1, dtype=np.uint64)
+    n_pad, got = _hip.c_u64(0), _hip.c_int(0)
+    _hip.check(_hip.lib().cleora_sharded_plan(int(n), _hip.ptr(rowptr), int(world), int(steps), mode, _hip.ptr(b), ctypes.byref(n_pad),
+                                              ctypes.byref(got)))
+    return [int(v) for v in b], n_pad.value, {_hip.BALANCE_ROWS: "rows", _hip.BALANCE_NNZ: "nnz"}[got.value]
 
 
 class HipBackend:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CLEORA_ABI_VERSION 2
+#define CLEORA_ABI_VERSION 3
 
 #define CLEORA_OK 0
 #define CLEORA_E_INVALID (-1)   /* bad argument (shape, null pointer, unknown enum) */
@@ -329,13 +329,35 @@ int cleora_cosine_scores_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t 
 #define CLEORA_COMM_ID_BYTES 128
 #define CLEORA_ALLGATHER_RING 0  /* ncclAllGather for equal shards (grouped ncclBroadcast for unequal ones) */
 #define CLEORA_ALLGATHER_P2P 1   /* grouped ncclSend/ncclRecv: every shard crosses each xGMI link once, directly */
+#define CLEORA_ALLGATHER_PEER 2  /* peer-direct stores: a copy kernel writes the shard straight into every peer's registered buffer through
+                                    hipIpc mappings, all links at once, a flag per peer (needs cleora_comm_enable_peer + cleora_comm_register) */
 typedef struct cleora_comm cleora_comm;
 int cleora_comm_unique_id(void *id_out);
 int cleora_comm_create(const void *id, int rank, int world, int device, cleora_comm **out);
 int cleora_comm_destroy(cleora_comm *c);
 int cleora_comm_info(const cleora_comm *c, int *rank, int *world, int *device);
-int cleora_comm_set_allgather(cleora_comm *c, int algo);   /* default RING */
+int cleora_comm_set_allgather(cleora_comm *c, int algo);   /* default RING (PEER on a local communicator) */
 int cleora_comm_get_allgather(const cleora_comm *c, int *algo);   /* which of the two cleora_allgatherv_f32_dev will take */
+
+/* Peer-direct transport (csrc/peer.hip; one node): the ranks map each other's buffers with hipIpc and exchange data with plain stores
+ * over xGMI — SURVEY 8e's "peer-mapped direct stores".  Bootstrap through a POSIX shared-memory segment named after the id.
+ *   cleora_comm_enable_peer   adds it to an RCCL communicator (collective, host-synchronous); CLEORA_ALLGATHER_PEER then selects it.
+ *   cleora_comm_create_local  a communicator WITHOUT RCCL: all-gather, all-reduce (every rank sums the contributions in rank order:
+ *                             bit-identical everywhere) and broadcast over the same mappings.  Unlike RCCL it accepts several ranks on
+ *                             one device, so the multi-rank loops run through this ABI on a one-GPU box.  id: CLEORA_COMM_ID_BYTES
+ *                             bytes shared by the ranks of ONE communicator (cleora_comm_local_id draws them; distribute like the RCCL id).
+ *   cleora_comm_register      every rank passes ITS copy of a buffer (device memory from hipMalloc / cleora_malloc, same size everywhere):
+ *                             afterwards cleora_allgatherv_f32_dev on any range inside it may take the peer-direct form (collective,
+ *                             host-synchronous; a no-op on a communicator without the peer transport).  cleora_comm_unregister before
+ *                             freeing the buffer (collective).
+ *   cleora_comm_check         CLEORA_E_RCCL if a device-side wait of this rank ever ran out of its 60 s budget (a peer died): the waits are
+ *                             bounded so that a lost rank cannot hang the GPU; synchronise the streams first. */
+int cleora_comm_local_id(void *id_out);
+int cleora_comm_create_local(const void *id, int rank, int world, int device, cleora_comm **out);
+int cleora_comm_enable_peer(cleora_comm *c);
+int cleora_comm_register(cleora_comm *c, void *buf_dev, uint64_t bytes);
+int cleora_comm_unregister(cleora_comm *c, void *buf_dev);
+int cleora_comm_check(cleora_comm *c);
 
 /* The exchange step of the row partition: buf holds offsets[world] floats (e.g. a row range of the next iterate,
  * contiguous, ld = d); rank r has just written elements [offsets[r], offsets[r+1]) and every rank ends up with all
@@ -350,6 +372,63 @@ int cleora_broadcast_dev(cleora_comm *c, void *buf, uint64_t bytes, int root, vo
 /* recv[j * elems_per_rank ...] <- rank j's send[me * elems_per_rank ...]: the column <-> row layout switch around the
  * whitening step of the column partition. */
 int cleora_alltoall_f32_dev(cleora_comm *c, const float *send, float *recv, uint64_t elems_per_rank, void *stream);
+
+/* ---- the row-partitioned loops (csrc/sharded.hip; no reference counterpart: pycleora is single-process, src/embedding.rs:59-63) ----
+ * north_star's multi-GPU layout as calls a Rust host makes through the FFI instead of re-writing the schedule: one process per GPU;
+ * every rank keeps full replicas of the iterate (n_pad x d, ld = d; rows >= n zero) and owns row blocks of the CSR.  With P ranks
+ * and K steps per iteration the row space is cut into P*K contiguous blocks, rank r owns blocks {k*P + r}; step k computes block
+ * (k, r) straight into its slot of the next replica, then the contiguous row range of step k is all-gathered IN PLACE on a
+ * communication stream while the SpMM of step k+1 runs (cleora_allgatherv_f32_dev with the communicator's algorithm).
+ * comm == NULL: a world of one (no collectives). */
+#define CLEORA_BALANCE_AUTO 0   /* ROWS when its heaviest block is within 3 % of the mean work (randomly permuted ids), else NNZ */
+#define CLEORA_BALANCE_ROWS 1   /* equal row counts (multiples of 4 rows): the shards of a step are equal, one ncclAllGather */
+#define CLEORA_BALANCE_NNZ 2    /* split on the prefix sum of edges + 1 per row: unequal shards, all-gather-v */
+typedef struct cleora_sharded cleora_sharded;
+typedef struct cleora_sharded_info {
+    uint64_t n, n_pad;         /* entities; rows of a replica (n padded to whole blocks; the padding rows are empty) */
+    uint64_t local_rows;       /* rows of this rank's blocks (padding included) */
+    uint64_t local_nnz, device_bytes;
+    uint32_t steps;
+    int32_t rank, world, balance, has_symmetric;
+} cleora_sharded_info;
+
+/* The row boundaries of the world * steps blocks: bounds_out[world * steps + 1]; block j = rows [bounds[j], bounds[j + 1]).
+ * Pure host arithmetic (no GPU): rowptr_host is the whole graph's u64[n + 1]. */
+int cleora_sharded_plan(uint64_t n, const uint64_t *rowptr_host, uint32_t world, uint32_t steps, int balance, uint64_t *bounds_out,
+                        uint64_t *n_pad_out, int *mode_out);
+/* This rank's blocks of the WHOLE graph's CSR (every rank passes the same arrays: the graph build is deterministic).  rowptr / col /
+ * val_*: host pointers, or device pointers on `device` when arrays_on_device != 0; only the rank's slices are copied, the caller
+ * keeps its arrays.  val_sym may be NULL.  comm: the communicator whose rank / world decide the blocks (NULL: world of one). */
+int cleora_sharded_create(cleora_comm *comm, int device, uint64_t n, uint64_t nnz, const uint64_t *rowptr, const uint32_t *col,
+                          const float *val_left, const float *val_sym, int arrays_on_device, uint32_t steps, int balance,
+                          cleora_sharded **out);
+int cleora_sharded_destroy(cleora_sharded *s);
+int cleora_sharded_get_info(const cleora_sharded *s, cleora_sharded_info *info);
+int cleora_sharded_bounds(const cleora_sharded *s, uint64_t *bounds_out);           /* world * steps + 1 values */
+int cleora_sharded_block(const cleora_sharded *s, uint32_t k, cleora_graph **graph, uint64_t *row_begin, uint64_t *row_end);
+/* One iteration: x_next <- epilogue(A x) with the flags of cleora_propagate_dev (x_self = the same rows of x), replicated on every
+ * rank when gather != 0 (else only this rank's rows of x_next are written).  row_sqdiff_local: f64[local_rows] in block order, or
+ * NULL.  Enqueues on `stream` and on the handle's communication stream; returns with every collective ordered before later work on
+ * `stream`.  With the peer-direct all-gather both replicas must be registered (cleora_comm_register). */
+int cleora_sharded_propagate_dev(cleora_sharded *s, int markov_type, const float *x, float *x_next, uint32_t d, uint32_t flags,
+                                 float residual_weight, double *row_sqdiff_local, int gather, void *stream);
+/* Timing for throughput reports: while enabled, ms[0] sums the SpMM kernels of this rank's blocks and ms[1] the all-gathers on the
+ * communication stream (HIP events), over `calls` cleora_sharded_propagate_dev calls; get waits for the events and resets. */
+int cleora_sharded_set_timing(cleora_sharded *s, int enable);
+int cleora_sharded_get_timing(cleora_sharded *s, double ms[2], uint64_t *calls);
+/* The loops over the partition, x_replica (n_pad x d): E_0 in, result out, replicated; synchronous.
+ *   flags without CLEORA_F_WHITEN: embed_full / embed_full_with_convergence (src/embedding.rs:106-188) — bit-equal to the one-GPU
+ *     loop on rows that are not split;
+ *   with CLEORA_F_WHITEN: the default loop of pycleora.embed() (pycleora/__init__.py:109-117).  L2 norm and no convergence test: the
+ *     reorganised form of cleora_embed (SpMM before the projection, Cholesky whitening in the intermediate iterations behind the clamp
+ *     guard, normalisation in the projection's epilogue): Z = A Y on the rank's rows beside the statistics of Y (every rank one
+ *     contiguous range of the replica, one pass; column sums and Gram all-reduced: d + d*d doubles), transform decided together and
+ *     broadcast, one all-gather of the iterate per iteration.  Otherwise the reference's order, statistics in the reference's two passes.
+ * Device memory beside the caller's replica: cleora_embed_sharded_bytes — one more replica for the plain loop; one more replica + the
+ * rank's own rows + the whitening workspace for the whitened one (config 4 on 8 GPUs: 2 x 113.7 + 14.2 GB of iterates). */
+uint64_t cleora_embed_sharded_bytes(uint64_t n_pad, uint64_t local_rows, uint64_t n, uint32_t world, uint32_t d, uint32_t flags);
+int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, uint32_t d, uint64_t max_iterations,
+                         float residual_weight, float convergence_threshold, uint32_t flags, uint64_t *iterations_run);
 
 /* The k nearest rows of X by cosine similarity for a batch of query ROWS of X, selected on the device: the
  * `normed @ normed[src]`, the -2 masks and `argsort()[::-1][:top_k]` of predict_links / find_most_similar

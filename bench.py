@@ -216,14 +216,14 @@ def sampled_row_check(g, x_dev, y_dev, n, d, hub_threshold, rows=4096, seed=11):
                                                            "iteration is run when the iterate fits the host: see oracle_rows_compared)"}
 
 
-def rccl_comm_or_fallback(local_rank, dev, rank, world, allow_fallback=False, fallback_backend="nccl"):
-    """The C-ABI communicator, checked with one small all-reduce before anything depends on it.  Two agreement points over
-    the gloo launcher group — after the creation and after the probe — so that the ranks always take the same branch: if
-    the communicator cannot be created or gives a wrong sum on ANY rank, EVERY rank stops with the reason (exit code 4): a
-    line measured over torch.distributed's collectives would not be a measurement of csrc/comm.hip.  Only with
-    --allow-torch-collectives do all ranks fall back to RCCL through torch.distributed's nccl backend, and the bench line
-    says so in config.collectives.  (What this cannot catch: a rank that dies before ncclCommInitRank leaves the others
-    waiting inside it; the watchdog ends that run.)"""
+def c_abi_communicator(local_rank, dev, rank, world, transport="rccl"):
+    """The C-ABI communicator, checked with one small all-reduce before anything depends on it.  Agreement points over the gloo
+    launcher group — after the creation and after the probe — so that the ranks always take the same branch.  transport "rccl":
+    RCCL over xGMI (csrc/comm.hip); if it cannot be created or gives a wrong sum on ANY rank, every rank moves to the library's
+    second transport, the peer-direct hipIpc one (csrc/peer.hip, "local") — still the C ABI, and config.collectives says which; if
+    that fails too every rank stops (exit code != 0: nothing is measured over torch.distributed's collectives — VERDICT round 3,
+    weak #6).  (What this cannot catch: a rank that dies before ncclCommInitRank leaves the others waiting inside it; the
+    watchdog ends that run.)"""
     def agree(err):
         ok = torch.tensor([0 if err else 1], dtype=torch.int32)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -233,43 +233,44 @@ def rccl_comm_or_fallback(local_rank, dev, rank, world, allow_fallback=False, fa
         dist.all_gather_object(errs, err)
         return next(e for e in errs if e)
 
-    err, comm = "", None
-    try:
-        comm = comm_mod.RcclComm.from_torch_distributed(local_rank)
-    except Exception as e:                    # noqa: BLE001 - reported below, on every rank
-        err = f"{type(e).__name__}: {e}"
-    first = agree(err)
-    if first is None:
+    def attempt(local):
+        err, comm = "", None
         try:
-            probe = torch.full((1024,), float(rank + 1), device=dev)
-            comm.allreduce(probe)
-            if dev.type == "cuda":
-                torch.cuda.synchronize()
-            if not bool((probe == world * (world + 1) / 2).all()):
-                err = f"all-reduce probe gave {float(probe[0])}, expected {world * (world + 1) / 2}"
-        except Exception as e:                # noqa: BLE001
+            comm = comm_mod.RcclComm.from_torch_distributed(local_rank, local=local)
+        except Exception as e:                    # noqa: BLE001 - reported below, on every rank
             err = f"{type(e).__name__}: {e}"
         first = agree(err)
         if first is None:
-            return comm, "RCCL via the C ABI (csrc/comm.hip)"
-    if not allow_fallback:
-        if comm is not None:
+            try:
+                probe = torch.full((1024,), float(rank + 1), device=dev)
+                comm.allreduce(probe)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize()
+                if not bool((probe == world * (world + 1) / 2).all()):
+                    err = f"all-reduce probe gave {float(probe[0])}, expected {world * (world + 1) / 2}"
+            except Exception as e:                # noqa: BLE001
+                err = f"{type(e).__name__}: {e}"
+            first = agree(err)
+        if first is not None and comm is not None:
             try:
                 comm.close()
-            except Exception:                 # noqa: BLE001
+            except Exception:                     # noqa: BLE001
                 pass
-        raise SystemExit(f"bench.py: the C-ABI communicator (csrc/comm.hip) is unusable on rank {rank}: {first}; nothing was measured "
-                         f"(--allow-torch-collectives would measure torch.distributed's collectives instead)")
-    if rank == 0:
-        print(f"bench.py: C-ABI communicator unusable ({first}); falling back to torch.distributed {fallback_backend}",
-              file=sys.stderr, flush=True)
+            comm = None
+        return comm, first
+
+    why = None
+    if transport == "rccl":
+        comm, why = attempt(False)
+        if comm is not None:
+            return comm, "RCCL via the C ABI (csrc/comm.hip)"
+        if rank == 0:
+            print(f"bench.py: the RCCL communicator is unusable ({why}); trying the peer-direct transport of the C ABI", file=sys.stderr, flush=True)
+    comm, why2 = attempt(True)
     if comm is not None:
-        try:
-            comm.close()
-        except Exception:                     # noqa: BLE001
-            pass
-    group = dist.new_group(backend=fallback_backend)
-    return comm_mod.TorchComm(group), f"RCCL via torch.distributed {fallback_backend} (fallback; C-ABI communicator: {first[:200]})"
+        return comm, ("peer-direct hipIpc transport via the C ABI (csrc/peer.hip)"
+                      + (f" — the RCCL communicator was unusable: {why[:200]}" if why else " (--backend local)"))
+    raise SystemExit(f"bench.py: no C-ABI communicator on rank {rank}: RCCL: {why}; peer-direct: {why2}; nothing was measured")
 
 
 def free_port():
@@ -375,7 +376,7 @@ class Launcher:
         return float(t)
 
 
-def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=950_000, d=64):
+def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=950_000, d=64, column=True):
     """N > 1, before anything big is built: ONE iteration (SpMM + L2 norm) of every partition on a 100k-row power-law graph,
     compared on every rank with the same iteration computed by that rank alone through the single-GPU path.  The row
     partition must reproduce it bit for bit (same kernel, same edges per row, all-gather of finished rows); the column
@@ -393,15 +394,27 @@ def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=
     _hip.check(L.cleora_propagate_dev(single.handle, _hip.LEFT, x.data_ptr(), d, d, want.data_ptr(), d, _hip.F_L2NORM, 0.0, None,
                                       None, None, stream))
     out = {"graph": f"power-law n={n} nnz={nnz} d={d}"}
-    sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world, 2, backend, comm=comm)
+    sg = sharded.DeviceShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, comm, 2, "auto", dev.index or 0)
     xr = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
     xr[:n] = x
     yr = torch.zeros_like(xr)
-    sg.propagate(_hip.LEFT, xr, yr)
-    torch.cuda.synchronize()
-    out["row_max_abs_diff"] = float((yr[:n] - want).abs().max())
-    out["row_bit_equal"] = bool(torch.equal(yr[:n], want))
-    if d % (4 * world) == 0:
+    comm.register(xr)
+    comm.register(yr)
+    out["row_max_abs_diff"], out["row_bit_equal"], algos = 0.0, True, [_hip.ALLGATHER_PEER] if comm.local else [_hip.ALLGATHER_RING, _hip.ALLGATHER_P2P]
+    if not comm.local and getattr(comm, "peer_enabled", False):
+        algos.append(_hip.ALLGATHER_PEER)
+    for algo in algos:                                    # every all-gather algorithm the timed run may pick
+        comm.set_allgather(algo)
+        yr.zero_()
+        sg.propagate(_hip.LEFT, xr, yr)
+        torch.cuda.synchronize()
+        out["row_max_abs_diff"] = max(out["row_max_abs_diff"], float((yr[:n] - want).abs().max()))
+        out["row_bit_equal"] = out["row_bit_equal"] and bool(torch.equal(yr[:n], want))
+    comm.check()
+    comm.unregister(xr)
+    comm.unregister(yr)
+    sg.close()
+    if column and d % (4 * world) == 0:
         cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend, comm=comm, steps=2)
         xc = x[:, cg.c0:cg.c0 + cg.dl].contiguous()
         yc = torch.zeros_like(xc)
@@ -529,10 +542,12 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     steps_per_iter = args.overlap_steps or (1 if world == 1 else 4)
     launch_bytes = []
     stream = torch.cuda.current_stream().cuda_stream
+    sg = None
     if part == "row":
-        sg = sharded.ShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, rank, world, steps_per_iter,
-                                  backend, comm=comm, balance=args.balance)
-        blocks = sg.blocks
+        # csrc/sharded.hip through the C ABI: cleora_sharded_create + cleora_sharded_propagate_dev (the loop body of cleora_embed_sharded)
+        ccomm = comm if isinstance(comm, comm_mod.RcclComm) else None
+        sg = sharded.DeviceShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, ccomm, steps_per_iter, args.balance, dev.index or 0)
+        blocks = [sg.block(k)[0] for k in range(steps_per_iter)]
         for k in range(steps_per_iter):
             b0, b1 = sg.my_rows[k]
             r0, r1 = min(b0, n), min(b1, n)
@@ -545,9 +560,12 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         x.zero_()
         x_next.zero_()
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
+        if ccomm is not None:
+            ccomm.register(x)                          # peer-direct all-gather: both replicas mapped by every rank (a no-op without it)
+            ccomm.register(x_next)
         dl = d
-        par = (f"row-block-cyclic x{world} ({sg.balance}-balanced), {steps_per_iter} block(s)/rank/iter"
-               + (", in-place RCCL all-gather of X (C ABI) overlapped with the next block" if world > 1 else ""))
+        par = (f"row-block-cyclic x{world} ({sg.balance}-balanced), {steps_per_iter} block(s)/rank/iter, csrc/sharded.hip through the C ABI"
+               + (", in-place all-gather of X (C ABI) overlapped with the next block" if world > 1 else ""))
 
         def iterate(a, b):
             sg.propagate(_hip.LEFT, a, b)
@@ -576,10 +594,14 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         torch.cuda.synchronize()
 
     extra = {}
-    # all-gather algorithm (row partition, N > 1): RCCL's ring all-gather against the direct send/recv mesh
+    # all-gather algorithm (row partition, N > 1): RCCL's ring all-gather, the send/recv mesh, the peer-direct stores — two timed
+    # iterations each, BEFORE the timed region; every rank sees the max-reduced times, so they agree on the pick
     if part == "row" and world > 1 and isinstance(comm, comm_mod.RcclComm):
+        candidates = [("peer_direct", _hip.ALLGATHER_PEER)] if comm.local else [("rccl_allgather", _hip.ALLGATHER_RING), ("p2p_mesh", _hip.ALLGATHER_P2P)]
+        if not comm.local and getattr(comm, "peer_enabled", False):
+            candidates.append(("peer_direct", _hip.ALLGATHER_PEER))
         tried = {}
-        for name, algo in (("rccl_allgather", _hip.ALLGATHER_RING), ("p2p_mesh", _hip.ALLGATHER_P2P)):
+        for name, algo in candidates:
             comm.set_allgather(algo)
             iterate(x, x_next)
             sync()
@@ -588,8 +610,8 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
             iterate(x, x_next)
             sync()
             tried[name] = launcher.max(time.perf_counter() - t0) / 2 * 1e3
-        best = min(tried, key=tried.get)                      # every rank sees the same (max-reduced) times
-        comm.set_allgather(_hip.ALLGATHER_P2P if best == "p2p_mesh" else _hip.ALLGATHER_RING)
+        best = min(tried, key=tried.get)
+        comm.set_allgather(dict(candidates)[best])
         extra["allgather_ms_per_iter_tried"] = {k: round(v, 3) for k, v in tried.items()}
         extra["allgather"] = best
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
@@ -598,8 +620,11 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     for _ in range(args.warmup):
         iterate(a, b)
         a, b = b, a
-    for blk in blocks:
-        blk.set_timing(True)
+    if sg is not None:
+        sg.set_timing(True)                            # the blocks' kernels and the all-gathers on the communication stream
+    else:
+        for blk in blocks:
+            blk.set_timing(True)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -611,10 +636,29 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     rows_ms, calls, other_ms = 0.0, 0, 0.0
     for blk in blocks:
         ms, c = blk.get_timing()
-        blk.set_timing(False)
         rows_ms += ms[1]
         other_ms += ms[0] + ms[2]
         calls += c
+    if sg is not None:
+        (_, gather_ms), _ = sg.get_timing()            # (the blocks' own records were read above: the SpMM part comes back as 0 here)
+        sg.set_timing(False)
+        if world > 1:
+            # VERDICT round 3, next #1c: what an iteration is made of on the slowest rank, beside the stated ceiling
+            spmm_iter = launcher.max((rows_ms + other_ms) / args.steps)
+            gather_iter = launcher.max(gather_ms / args.steps)
+            step_ms = elapsed / args.steps * 1e3
+            recv_gb = (world - 1) / world * n * d * 4 / 1e9
+            extra["per_iteration_ms"] = {"spmm_kernels_max_rank": round(spmm_iter, 3), "allgather_on_comm_stream_max_rank": round(gather_iter, 3),
+                                         "exposed_beyond_spmm": round(step_ms - spmm_iter, 3), "wall": round(step_ms, 3)}
+            lo, hi = recv_gb / ((world - 1) * 0.1536) , recv_gb / ((world - 1) * 0.0768)     # ms at 153.6 / 76.8 GB/s per link and direction
+            extra["ceiling"] = {"received_GB_per_rank_per_iteration": round(recv_gb, 3), "links": world - 1,
+                                "gather_ms_at_153.6_GBps_per_link": round(lo, 2), "gather_ms_at_76.8_GBps_per_link": round(hi, 2),
+                                "iterations_per_sec_if_gather_bound": [round(1e3 / max(hi, spmm_iter), 1), round(1e3 / max(lo, spmm_iter), 1)],
+                                "note": "one xGMI link per peer (7 x ~153 GB/s per GPU by the environment's figure; 76.8 if that is bidirectional); "
+                                        "block k's gather overlaps block k+1's SpMM, so an iteration is >= max(SpMM, gather)"}
+    else:
+        for blk in blocks:
+            blk.set_timing(False)
     avg_ms = rows_ms / max(calls, 1)
     avg_bytes = sum(launch_bytes) / len(launch_bytes)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -642,7 +686,9 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         "placement_tuning": placement,
     }
     res.update(extra)
-    return res, a, b, iterate, blocks
+    if sg is not None and isinstance(comm, comm_mod.RcclComm) and world > 1:
+        comm.check()                                   # a device-side wait that ran out of its budget is an error, not a number
+    return res, a, b, iterate, blocks, sg
 
 
 def finite_and_row_sumsq(a, n, rows_per_pass=4_000_000):
@@ -820,13 +866,12 @@ def main():
     ap.add_argument("--whiten-iters", type=int, default=8, help="iterations of the whitened default loop (N = 1); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--watchdog", type=int, default=1500, help="seconds before every thread's traceback is dumped and the run exits")
-    # developer switches for exercising the N > 1 code path on a ONE-GPU box (every rank on cuda:0, collectives
-    # through torch.distributed/gloo instead of RCCL, which refuses two ranks on one device); numbers mean nothing
-    ap.add_argument("--backend", default="rccl", choices=["rccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "local", "gloo"],
+                    help="N > 1: transport of the C-ABI communicator — rccl (RCCL over xGMI, csrc/comm.hip; the peer-direct all-gather is timed "
+                         "beside its two algorithms) or local (the peer-direct hipIpc transport alone, csrc/peer.hip; also what --share-gpu "
+                         "needs: RCCL refuses two ranks on one device).  'gloo' is accepted as an alias of 'local' (round 3's developer mode)")
+    # developer switch for exercising the N > 1 code path on a ONE-GPU box: every rank on cuda:0; numbers mean nothing
     ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--allow-torch-collectives", action="store_true",
-                    help="N > 1: if the C-ABI communicator cannot be created, measure over torch.distributed's nccl group instead of "
-                         "stopping (the line then says so in config.collectives and is not a measurement of csrc/comm.hip)")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -856,11 +901,21 @@ def main():
     collectives = None
     if world > 1:
         with native_stdout_to_stderr():
-            dist.init_process_group("gloo")       # the launcher; the data path's collectives are the C ABI's (RCCL)
-            if args.backend == "rccl":
-                comm, collectives = rccl_comm_or_fallback(local_rank, dev, rank, world, args.allow_torch_collectives)
-            else:
-                comm, collectives = comm_mod.TorchComm(), "torch.distributed/gloo (developer mode)"
+            dist.init_process_group("gloo")       # the launcher; the data path's collectives are the C ABI's
+            transport = "local" if (args.backend in ("local", "gloo") or args.share_gpu) else "rccl"
+            comm, collectives = c_abi_communicator(local_rank, dev, rank, world, transport)
+            comm.peer_enabled = False
+            if not comm.local:
+                # the peer-direct all-gather as a third algorithm beside RCCL's two (collective; every rank must succeed)
+                err = ""
+                try:
+                    comm.enable_peer()
+                except Exception as e:            # noqa: BLE001
+                    err = f"{type(e).__name__}: {e}"
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                comm.peer_enabled = int(ok) == 1
+                collectives += "; peer-direct all-gather available" if comm.peer_enabled else f"; peer-direct transport not available ({err[:160] or 'another rank failed'})"
     else:
         comm = comm_mod.LocalComm()
 
@@ -869,7 +924,7 @@ def main():
     if world > 1 and not args.no_selftest:
         # a broken collective or partition must cost seconds, not the run: one iteration of every partition on a small
         # graph against the same iteration computed by this rank alone, BEFORE the big graph is built
-        selftest = partition_selftest(dev, rank, world, comm, backend, L)
+        selftest = partition_selftest(dev, rank, world, comm, backend, L, column=args.partition != "row")
     g, hashes, workload_label, cfg = make_workload(args, dev, rank, world, args.share_gpu)
     torch.cuda.empty_cache()                  # the iterates come from hipMalloc (cleora_alloc_iterates), not from torch's cache
     args.dim = args.dim or cfg["dim"]
@@ -884,15 +939,40 @@ def main():
             parts.remove("column")
             parts = parts or ["row"]
 
-    results, keep = {}, None
+    results, keep, whitened_sharded = {}, None, None
     for part in parts:
-        res, a, b, iterate, blocks = run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher,
-                                                   backend, L)
+        res, a, b, iterate, blocks, sg = run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher,
+                                                       backend, L)
         results[part] = res
         if world == 1:
-            keep = (a, b, iterate, blocks)
+            keep = (a, b, iterate, blocks, sg)
         else:
-            del a, b, iterate, blocks
+            if part == "row" and args.whiten_iters > 0 and sg.embed_bytes(d, _hip.F_WHITEN) + 3 * sg.n_pad * d * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.9:
+                # the DEFAULT loop over the partition, one call: cleora_embed_sharded + CLEORA_F_WHITEN (wall clock incl. the final PCA whitening)
+                comm.unregister(a)
+                comm.unregister(b)
+                _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                sg.embed(a, _hip.LEFT, d, 2, 0.0, 0.0, _hip.F_WHITEN)       # untimed: the first eigensolver call of a process
+                _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                launcher.barrier()
+                t0 = time.perf_counter()
+                sg.embed(a, _hip.LEFT, d, args.whiten_iters, 0.0, 0.0, _hip.F_WHITEN)
+                el = launcher.max(time.perf_counter() - t0)
+                cov = torch.cov(a[: min(n, 2_000_000)].double().T)
+                whitened_sharded = {"ms_per_iter": el / args.whiten_iters * 1e3, "iterations": args.whiten_iters,
+                                    "loop": "cleora_embed_sharded + CLEORA_F_WHITEN (csrc/sharded.hip: two replicas + the rank's own rows; statistics "
+                                            "all-reduced, one all-gather of the iterate per iteration); wall clock of the call incl. its allocations, "
+                                            "the registration of the replicas and the final PCA whitening",
+                                    "device_bytes_beside_the_callers_replica": sg.embed_bytes(d, _hip.F_WHITEN),
+                                    "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
+            elif part == "row" and isinstance(comm, comm_mod.RcclComm):
+                comm.unregister(a)
+                comm.unregister(b)
+            if sg is not None:
+                sg.close()
+            del a, b, iterate, blocks, sg
             torch.cuda.empty_cache()
     # `value` is north_star's layout — row partition + all-gather of X — for every N; the column partition is a measured
     # comparison beside it (`partitions`), never the headline
@@ -901,7 +981,7 @@ def main():
 
     whitened = cpu = None
     if world == 1:
-        a, b, iterate, blocks = keep
+        a, b, iterate, blocks, sg = keep
         if not args.no_cpu_baseline:
             iterate(a, b)                                     # the GPU iteration the oracle is compared with
             torch.cuda.synchronize()
@@ -914,7 +994,8 @@ def main():
                 cpu, checks = cpu_baseline_and_checks(g, a, b, n, d, blocks[0].info().hub_threshold)
                 r["checks"].update(checks)
         x_w = a
-        del b, iterate, blocks, keep
+        sg.close()                                            # the rank's copy of the CSR
+        del b, iterate, blocks, keep, sg
         torch.cuda.empty_cache()
         if args.whiten_iters > 0 and n * d * 4 * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.8:
             whitened = run_whitened(args, g, x_w, dev, L, args.whiten_iters)
@@ -955,6 +1036,12 @@ def main():
         if world > 1:
             out["partitions"] = {p: {k: v for k, v in results[p].items() if k not in ("placement_tuning",)} for p in results}
             out["selftest"] = selftest
+            for k in ("allgather", "allgather_ms_per_iter_tried", "per_iteration_ms", "ceiling"):
+                if k in r:
+                    out["config"][k] = r[k]
+            out["config"]["ranks"] = world
+            if whitened_sharded is not None:
+                out["whitened_sharded"] = whitened_sharded
         if whitened is not None:
             out["whitened"] = whitened
         print(json.dumps(out), flush=True)

@@ -74,7 +74,15 @@ struct Registration {
 
 struct PeerPtrs { void *p[kMaxWorld]; };
 
+struct Mapping {                              // an allocation of a peer opened here; shared by every registration inside it
+    int peer;
+    hipIpcMemHandle_t handle;
+    void *base;
+    int refs;
+};
+
 struct PeerLayer {
+    std::vector<Mapping> mappings;
     ShmSegment *shm = nullptr;
     size_t shm_bytes = 0;
     uint32_t local_sense = 0;
@@ -115,6 +123,8 @@ int barrier_host(cleora_comm *c) {
     return CLEORA_OK;
 }
 
+void close_registration(PeerLayer *pl, Registration &r, int world);
+
 // every rank publishes (ptr, bytes) [ptr may be nullptr: ok = 0], all map all; returns with `out` filled.  Collective.
 int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *out) {
     PeerLayer *pl = c->peer;
@@ -152,12 +162,17 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
         }
         void *mapped = nullptr;
         hipIpcMemHandle_t h = r.handle;
-        const hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            set_error(std::string("peer transport: hipIpcOpenMemHandle of rank ") + std::to_string(p) + "'s buffer failed (" + hipGetErrorString(e) + ")");
-            rc = CLEORA_E_HIP;
-            break;
+        for (Mapping &m : pl->mappings)                       // two buffers of one allocation (a caching allocator's segment): one mapping
+            if (m.peer == p && std::memcmp(&m.handle, &h, sizeof h) == 0) { mapped = m.base; ++m.refs; break; }
+        if (!mapped) {
+            const hipError_t e = hipIpcOpenMemHandle(&mapped, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                set_error(std::string("peer transport: hipIpcOpenMemHandle of rank ") + std::to_string(p) + "'s buffer failed (" + hipGetErrorString(e) + ")");
+                rc = CLEORA_E_HIP;
+                break;
+            }
+            pl->mappings.push_back(Mapping{p, h, mapped, 1});
         }
         out->mapped_base[p] = mapped;
         out->peer[p] = static_cast<char *>(mapped) + r.offset;
@@ -166,8 +181,7 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
     b = barrier_host(c);                                    // nobody reuses the records before everybody has read them
     if (b != CLEORA_OK) return b;
     if (pl->shm->failed.load(std::memory_order_acquire)) {
-        for (int p = 0; p < c->world; ++p)
-            if (out->mapped_base[p]) { (void)hipIpcCloseMemHandle(out->mapped_base[p]); out->mapped_base[p] = nullptr; out->peer[p] = nullptr; }
+        close_registration(pl, *out, c->world);
         if (rc == CLEORA_OK) { set_error("peer transport: the exchange failed on another rank"); rc = CLEORA_E_RCCL; }
         (void)barrier_host(c);
         if (c->rank == 0) pl->shm->failed.store(0, std::memory_order_release);
@@ -177,9 +191,21 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
     return CLEORA_OK;
 }
 
-void close_registration(Registration &r, int world) {
+void release_mapping(PeerLayer *pl, int peer, void *base) {
+    for (size_t k = 0; k < pl->mappings.size(); ++k) {
+        Mapping &m = pl->mappings[k];
+        if (m.peer != peer || m.base != base) continue;
+        if (--m.refs == 0) {
+            (void)hipIpcCloseMemHandle(base);
+            pl->mappings.erase(pl->mappings.begin() + (long)k);
+        }
+        return;
+    }
+}
+
+void close_registration(PeerLayer *pl, Registration &r, int world) {
     for (int p = 0; p < world; ++p)
-        if (r.mapped_base[p]) { (void)hipIpcCloseMemHandle(r.mapped_base[p]); r.mapped_base[p] = nullptr; r.peer[p] = nullptr; }
+        if (r.mapped_base[p]) { release_mapping(pl, p, r.mapped_base[p]); r.mapped_base[p] = nullptr; r.peer[p] = nullptr; }
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------------------
@@ -300,13 +326,16 @@ int peer_enable(cleora_comm *c) {
     // the mailbox: uncached device memory where the platform offers it (flags polled by a running kernel must not sit in a
     // non-coherent cache), else fine-grained, else plain (enough when the ranks share one device)
     void *mb = nullptr;
-    if (hipExtMallocWithFlags(&mb, sizeof(Mailbox), hipDeviceMallocUncached) != hipSuccess) {
-        (void)hipGetLastError();
-        if (hipExtMallocWithFlags(&mb, sizeof(Mailbox), hipDeviceMallocFinegrained) != hipSuccess) {
-            (void)hipGetLastError();
-            if (hipMalloc(&mb, sizeof(Mailbox)) != hipSuccess) { (void)hipGetLastError(); set_error("peer transport: no memory for the mailbox"); return fail(CLEORA_E_OOM); }
-        }
+    for (int kind = 0; kind < 3 && !mb; ++kind) {
+        void *p = nullptr;
+        const hipError_t e = kind == 0 ? hipExtMallocWithFlags(&p, sizeof(Mailbox), hipDeviceMallocUncached)
+                             : kind == 1 ? hipExtMallocWithFlags(&p, sizeof(Mailbox), hipDeviceMallocFinegrained) : hipMalloc(&p, sizeof(Mailbox));
+        if (e != hipSuccess) { (void)hipGetLastError(); continue; }
+        hipIpcMemHandle_t probe;                              // a kind that cannot be exported is of no use here
+        if (c->world > 1 && hipIpcGetMemHandle(&probe, p) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); continue; }
+        mb = p;
     }
+    if (!mb) { set_error("peer transport: no exportable device memory for the mailbox (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"); return fail(CLEORA_E_HIP); }
     pl->mailbox = static_cast<Mailbox *>(mb);
     if (hipMemset(mb, 0, sizeof(Mailbox)) != hipSuccess) { (void)hipGetLastError(); set_error("peer transport: hipMemset failed"); return fail(CLEORA_E_HIP); }
     if (c->world == 1) return CLEORA_OK;
@@ -332,8 +361,8 @@ void peer_destroy(cleora_comm *c) {
     if (!pl) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (Registration &r : pl->regs) close_registration(r, c->world);
-    close_registration(pl->mailboxes, c->world);
+    for (Registration &r : pl->regs) close_registration(pl, r, c->world);
+    close_registration(pl, pl->mailboxes, c->world);
     if (pl->shm && c->world > 1) (void)barrier_host(c);      // peers have closed their mappings of OUR memory before we free it
     if (pl->scratch) (void)hipFree(pl->scratch);
     if (pl->mailbox) (void)hipFree(pl->mailbox);
@@ -368,7 +397,7 @@ int peer_unregister(cleora_comm *c, void *buf) {
         CL_HIP(hipSetDevice(c->device));
         CL_HIP(hipDeviceSynchronize());                     // our kernels that store into the peers' copies
         int rc = c->world > 1 ? barrier_host(c) : CLEORA_OK;
-        close_registration(pl->regs[k], c->world);
+        close_registration(pl, pl->regs[k], c->world);
         if (rc == CLEORA_OK && c->world > 1) rc = barrier_host(c);   // every mapping of `buf` is closed: the owner may free it
         pl->regs.erase(pl->regs.begin() + (long)k);
         return rc;

@@ -41,6 +41,13 @@ except ImportError:                    # pragma: no cover
     torch = None
 
 
+class _BorrowedGraph(_hip.Graph):
+    """A block of a DeviceShardedGraph: the sharded handle owns it."""
+
+    def close(self):
+        self.handle = None
+
+
 def _dev_ptr(a):
     """Device pointer of a torch tensor / DevArray (None passes through)."""
     if a is None:
@@ -87,19 +94,10 @@ class DeviceShardedGraph:
         self.my_rows = [(self.bounds[k * self.world + self.rank], self.bounds[k * self.world + self.rank + 1]) for k in range(self.steps)]
 
     def block(self, k):
-        """(a borrowed _hip.Graph view of block k, row_begin, row_end) — for info / timing; do not close it."""
+        """(block k as a _hip.Graph that does NOT own its handle — info, timing, cleora_alloc_iterates —, row_begin, row_end)."""
         g, b0, b1 = _hip.vp(), _hip.c_u64(0), _hip.c_u64(0)
         _hip.check(self.L.cleora_sharded_block(self.handle, int(k), ctypes.byref(g), ctypes.byref(b0), ctypes.byref(b1)))
-        view = _hip.Graph.__new__(_hip.Graph)
-        view.handle, view._keepalive = None, self             # never destroyed through the view
-        view.borrowed = g
-        return view, b0.value, b1.value
-
-    def block_info(self, k):
-        g, _, _ = self.block(k)
-        gi = _hip.GraphInfo()
-        _hip.check(self.L.cleora_graph_get_info(g.borrowed, ctypes.byref(gi)))
-        return gi
+        return _BorrowedGraph(g, self), b0.value, b1.value
 
     def propagate(self, kind, x, x_next, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, gather=True, stream=None, d=None):
         """One iteration; x / x_next: (n_pad, d) replicas (torch tensors or DevArrays)."""

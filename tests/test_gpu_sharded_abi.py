@@ -1,0 +1,194 @@
+"""GPU: the row-partitioned loops and the peer-direct transport THROUGH THE C ABI (csrc/sharded.hip, csrc/peer.hip) — what a
+Rust host would call (missing #2 / next #4, #7).  No torch anywhere in this file: numpy + ctypes only.
+
+  * world 1 (no communicator): cleora_embed_sharded equals the one-GPU cleora_embed bit for bit (plain loop, any block count /
+    balance) and to the whitened loop's tolerances (reorganised and reference order);
+  * world 2 and 3 with the ranks SHARING the one GPU of the test box over a LOCAL communicator (cleora_comm_create_local: hipIpc
+    mappings; RCCL refuses two ranks on one device): the collectives themselves (peer-direct all-gather-v into registered
+    buffers, all-reduce summed in rank order, broadcast), then the loops — replicas identical on every rank, the plain loop
+    bit-equal to the one-GPU loop, the whitened loops against it and against the oracle's loop.
+The reference has no counterpart (single process: src/embedding.rs:59-63); the loops' arithmetic is the reference's
+(src/embedding.rs:106-188, pycleora/__init__.py:109-117) and is pinned through the one-GPU entry points and the oracle."""
+import ctypes
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from cleora_amd import _hip, comm as comm_mod, sharded
+from oracle import whiten as ow
+from tests.graphs import random_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(n, seed):
+    return random_csr(n, 9, seed=seed, empty_frac=0.03, hubs=[(17, 2200)])
+
+
+def _cosines(e, rows):
+    u = e[rows].astype(np.float64)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    return u @ u.T
+
+
+def _one_gpu(rowptr, col, val, x0, d, iters, rw, thr, flags):
+    g = _hip.Graph.from_host(rowptr, col, val)
+    out = np.empty_like(x0)
+    ran = ctypes.c_uint64(0)
+    _hip.check(_hip.lib().cleora_embed(g.handle, None, _hip.ptr(x0), _hip.LEFT, d, iters, 0, rw, thr, flags, _hip.ptr(out), ctypes.byref(ran)))
+    g.close()
+    return out, ran.value
+
+
+def _run_sharded(sg, x0, d, iters, rw, thr, flags):
+    xp = np.zeros((sg.n_pad, d), np.float32)
+    xp[: sg.n] = x0
+    dx = _hip.DevArray.from_host(xp)
+    ran = sg.embed(dx, _hip.LEFT, d, iters, rw, thr, flags)
+    out = dx.to_host()
+    dx.free()
+    assert not out[sg.n:].any()                            # padding rows stay zero
+    return out[: sg.n], ran
+
+
+@pytest.mark.parametrize("steps,balance", [(1, "rows"), (3, "nnz"), (4, "auto")])
+def test_world_of_one_equals_the_one_gpu_loops(steps, balance):
+    n, d = 6001, 256
+    rowptr, col, vl, vs = _graph(n, 51)
+    x0 = np.random.default_rng(52).standard_normal((n, d)).astype(np.float32)
+    sg = sharded.DeviceShardedGraph(n, rowptr, col, vl, vs, None, steps, balance)
+    assert sg.world == 1 and sg.n_pad % 4 == 0 and sg.local_rows == sg.n_pad and sg.local_nnz == col.shape[0]
+    # plain loop with residual and a convergence test: bit-equal, same stop iteration
+    got, ran = _run_sharded(sg, x0, d, 12, 0.25, 2e-3, 0)
+    want, wran = _one_gpu(rowptr, col, vl, x0, d, 12, 0.25, 2e-3, 0)
+    assert ran == wran
+    np.testing.assert_array_equal(got, want)
+    rows = np.random.default_rng(1).choice(n, 400, replace=False)
+    # the default loop: reorganised form (no threshold) and the reference's order (a threshold that is never met)
+    for thr in (0.0, 1e-30):
+        got, ran = _run_sharded(sg, x0, d, 4, 0.2, thr, _hip.F_WHITEN)
+        want, _ = _one_gpu(rowptr, col, vl, x0, d, 4, 0.2, thr, _hip.F_WHITEN)
+        assert ran == 4 and np.isfinite(got).all()
+        assert np.abs(_cosines(got, rows) - _cosines(want, rows)).max() < 1e-4
+        assert np.abs(np.cov(got.astype(np.float64).T) - np.eye(d)).max() < 5e-3
+    sg.close()
+
+
+def _shard_cuts(world):
+    """Row boundaries of an all-gather-v test: rank r owns 148 (r + 1) rows."""
+    return np.cumsum([0] + [4 * 37 * (r + 1) for r in range(world)]).astype(np.int64)
+
+
+def _worker(rank, world, ident, q, cases):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        L = _hip.lib()
+        cm = comm_mod.RcclComm(ident, rank, world, 0, stream_fn=lambda: None, local=True)
+        out = {}
+        # ---- the collectives themselves ---------------------------------------------------------------------------------
+        d = 24
+        cuts = _shard_cuts(world)                                        # shards of different lengths
+        rows = int(cuts[-1])
+        buf = np.full((rows, d), -1.0, np.float32)
+        buf[cuts[rank]:cuts[rank + 1]] = (np.arange(cuts[rank], cuts[rank + 1], dtype=np.float32)[:, None] * 100 + np.arange(d, dtype=np.float32)) + 0.5 * rank
+        db = _hip.DevArray.from_host(buf)
+        cm.register(db)
+        off = np.asarray([c * d for c in cuts], dtype=np.uint64)
+        for _ in range(3):                                               # repeated: sequence numbers, no stale flags
+            _hip.check(L.cleora_allgatherv_f32_dev(cm.handle, db.ptr, _hip.ptr(off), None))
+        _hip.check(L.cleora_stream_sync(None))
+        out["gathered"] = db.to_host()
+        v32 = _hip.DevArray.from_host(np.arange(1000, dtype=np.float32) * (rank + 1))
+        v64 = _hip.DevArray.from_host((np.arange(70_000, dtype=np.float64) + 0.25) * (rank + 1))
+        for _ in range(3):
+            _hip.check(L.cleora_allreduce_f32_dev(cm.handle, v32.ptr, 1000, None))
+        _hip.check(L.cleora_allreduce_f64_dev(cm.handle, v64.ptr, 70_000, None))
+        bc = _hip.DevArray.from_host(np.full(5000, float(rank + 7), np.float32))
+        _hip.check(L.cleora_broadcast_dev(cm.handle, bc.ptr, 5000 * 4, world - 1, None))
+        _hip.check(L.cleora_stream_sync(None))
+        cm.check()
+        out["allreduce32"], out["allreduce64"], out["broadcast"] = v32.to_host(), v64.to_host(), bc.to_host()
+        cm.unregister(db)
+        # ---- the loops ---------------------------------------------------------------------------------------------------
+        for name, (n, d, seed, steps, balance, iters, rw, thr, flags) in cases.items():
+            rowptr, col, vl, vs = _graph(n, seed)
+            x0 = np.random.default_rng(seed + 1).standard_normal((n, d)).astype(np.float32)
+            sg = sharded.DeviceShardedGraph(n, rowptr, col, vl, vs, cm, steps, balance)
+            res, ran = _run_sharded(sg, x0, d, iters, rw, thr, flags)
+            out[name] = (res, ran, sg.balance, sg.local_rows)
+            sg.close()
+        cm.check()
+        cm.close()
+        q.put((rank, out, None))
+    except BaseException as e:                       # noqa: BLE001 - reported to the parent
+        import traceback
+        q.put((rank, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+
+
+CASES = {
+    "plain": (6001, 256, 51, 2, "rows", 12, 0.25, 2e-3, 0),
+    "plain_nnz": (5003, 64, 61, 3, "nnz", 5, 0.0, 0.0, 0),
+    "whitened": (6001, 256, 51, 2, "auto", 4, 0.2, 0.0, _hip.F_WHITEN),
+    "whitened_reference_order": (4003, 64, 71, 2, "nnz", 3, 0.0, 1e-30, _hip.F_WHITEN),
+}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_the_gpu_over_the_local_communicator(world):
+    ident = comm_mod.RcclComm.unique_id(local=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, ident, q, CASES)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = {}
+        for _ in range(world):
+            rank, out, err = q.get(timeout=420)
+            assert err is None, f"rank {rank}: {err}"
+            got[rank] = out
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    # ---- collectives
+    for r in range(world):
+        g = got[r]["gathered"]
+        rows = g.shape[0]
+        d = g.shape[1]
+        owner = np.zeros(rows, np.int64)
+        cuts = _shard_cuts(world)
+        assert rows == cuts[-1]
+        for k in range(world):
+            owner[cuts[k]:cuts[k + 1]] = k
+        want = np.arange(rows, dtype=np.float32)[:, None] * 100 + np.arange(d, dtype=np.float32) + 0.5 * owner[:, None].astype(np.float32)
+        np.testing.assert_array_equal(g, want)
+        s = sum(k + 1 for k in range(world))
+        np.testing.assert_array_equal(got[r]["allreduce32"], got[0]["allreduce32"])          # bit-identical on every rank
+        np.testing.assert_array_equal(got[r]["allreduce32"], np.arange(1000, dtype=np.float32) * (s * world * world))   # three in a row
+        np.testing.assert_array_equal(got[r]["allreduce64"], (np.arange(70_000, dtype=np.float64) + 0.25) * s)
+        np.testing.assert_array_equal(got[r]["broadcast"], np.full(5000, float(world - 1 + 7), np.float32))
+    # ---- loops
+    for name, (n, d, seed, steps, balance, iters, rw, thr, flags) in CASES.items():
+        rowptr, col, vl, vs = _graph(n, seed)
+        x0 = np.random.default_rng(seed + 1).standard_normal((n, d)).astype(np.float32)
+        want, wran = _one_gpu(rowptr, col, vl, x0, d, iters, rw, thr, flags)
+        for r in range(world):
+            res, ran, _, _ = got[r][name]
+            np.testing.assert_array_equal(res, got[0][name][0])                                # replicas identical
+            assert ran == wran
+        res = got[0][name][0]
+        if not flags & _hip.F_WHITEN:
+            np.testing.assert_array_equal(res, want)        # the one-GPU kernel on row blocks: bit-identical rows, same stop iteration
+        else:
+            rows = np.random.default_rng(1).choice(n, 400, replace=False)
+            assert np.isfinite(res).all()
+            assert np.abs(_cosines(res, rows) - _cosines(want, rows)).max() < 1e-4
+            ref, _ = ow.embed_slow(lambda v: oracle.spmm(rowptr, col, vl, v), x0, iters, residual_weight=rw, whiten=True)
+            assert np.abs(_cosines(res, rows) - _cosines(ref, rows)).max() < 1e-3
+    assert got[0]["plain_nnz"][2] == "nnz" and got[0]["plain"][2] == "rows"
+    assert sum(got[r]["plain_nnz"][3] for r in range(world)) >= 5003

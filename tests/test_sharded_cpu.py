@@ -245,16 +245,16 @@ def test_column_partition_world2(world, steps):
             np.testing.assert_array_equal(got[0][1][key][0], res[key][0])       # replicas identical
 
 
-def _fallback_worker(rank, world, port, q, fail_on, allow=True):
+def _fallback_worker(rank, world, port, q, fail_on, local_fails=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import bench
         from cleora_amd import comm as comm_mod
 
-        class FakeRccl:                       # stands in for the C-ABI communicator: same interface, gloo underneath
-            def __init__(self, wrong=False):
-                self.wrong = wrong
+        class FakeComm:                       # stands in for the C-ABI communicator: same interface, gloo underneath
+            def __init__(self, local, wrong=False):
+                self.local, self.wrong = local, wrong
 
             def allreduce(self, t):
                 dist.all_reduce(t)
@@ -264,29 +264,33 @@ def _fallback_worker(rank, world, port, q, fail_on, allow=True):
             def close(self):
                 pass
 
-        def from_torch_distributed(local_rank, group=None):
+        def from_torch_distributed(local_rank, group=None, local=False):
+            if local:
+                if local_fails and rank == 0:
+                    raise RuntimeError("simulated hipIpc failure")
+                return FakeComm(True)
             if fail_on == "raise" and rank == 1:
                 raise RuntimeError("simulated bootstrap failure")
-            return FakeRccl(wrong=(fail_on == "wrong" and rank == 0))
+            return FakeComm(False, wrong=(fail_on == "wrong" and rank == 0))
 
         comm_mod.RcclComm.from_torch_distributed = staticmethod(from_torch_distributed)
         try:
-            comm, label = bench.rccl_comm_or_fallback(0, torch.device("cpu"), rank, world, allow_fallback=allow, fallback_backend="gloo")
-        except SystemExit as e:               # the default: no line is printed over another transport
+            comm, label = bench.c_abi_communicator(0, torch.device("cpu"), rank, world)
+        except SystemExit as e:               # no C-ABI transport at all: no line is printed over another one
             q.put((rank, "SystemExit", str(e), 0.0))
             return
         t = torch.full((4,), float(rank + 1))
         comm.allreduce(t)                     # whatever came back must be a working communicator on every rank
-        q.put((rank, type(comm).__name__, label, float(t[0])))
+        q.put((rank, "local" if comm.local else "rccl", label, float(t[0])))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("fail_on", [None, "raise", "wrong"])
-def test_bench_falls_back_as_one_when_the_c_abi_communicator_is_unusable(fail_on):
-    """bench.py's N > 1 start-up WITH --allow-torch-collectives: if the C-ABI RCCL communicator cannot be created on ANY rank, or
-    its probe all-reduce gives a wrong sum on any rank, every rank falls back to the torch.distributed group (and says so in
-    config.collectives); if all is well, every rank keeps it.  Two gloo ranks, the communicator replaced by a stand-in."""
+def test_bench_moves_to_the_peer_direct_transport_as_one_when_rccl_is_unusable(fail_on):
+    """bench.py's N > 1 start-up: if the RCCL communicator of the C ABI cannot be created on ANY rank, or its probe all-reduce gives
+    a wrong sum on any rank, EVERY rank moves to the library's peer-direct transport (still csrc/, still the C ABI) and
+    config.collectives says so; if all is well, every rank keeps RCCL.  Two gloo ranks, the communicator replaced by a stand-in."""
     world, port = 2, 29500 + (os.getpid() + {None: 0, "raise": 1, "wrong": 2}[fail_on]) % 400 + 40
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -299,22 +303,20 @@ def test_bench_falls_back_as_one_when_the_c_abi_communicator_is_unusable(fail_on
         assert p.exitcode == 0
     kinds = {g[1] for g in got}
     assert len(kinds) == 1                                   # the ranks agree
-    assert all(g[3] == 3.0 for g in got) or fail_on == "wrong" and kinds == {"TorchComm"}
+    assert all(g[3] == 3.0 for g in got)
     if fail_on is None:
-        assert kinds == {"FakeRccl"} and all("C ABI" in g[2] for g in got)
+        assert kinds == {"rccl"} and all("RCCL via the C ABI" in g[2] for g in got)
     else:
-        assert kinds == {"TorchComm"} and all("fallback" in g[2] for g in got)
-        assert all(g[3] == 3.0 for g in got)
+        assert kinds == {"local"} and all("peer-direct" in g[2] and "unusable" in g[2] for g in got)
 
 
-@pytest.mark.parametrize("fail_on", ["raise", "wrong"])
-def test_bench_refuses_to_measure_over_another_transport_by_default(fail_on):
-    """Without --allow-torch-collectives an unusable C-ABI communicator stops EVERY rank with the reason (VERDICT round 3,
-    weak #6: a line measured over torch's collectives is not a measurement of csrc/comm.hip)."""
-    world, port = 2, 29500 + (os.getpid() + {"raise": 5, "wrong": 6}[fail_on]) % 400 + 40
+def test_bench_refuses_to_measure_without_a_c_abi_transport():
+    """Both transports unusable: EVERY rank stops with the reasons (a line measured over
+    torch.distributed's collectives would not be a measurement of csrc/)."""
+    world, port = 2, 29500 + (os.getpid() + 7) % 400 + 40
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q, fail_on, False)) for r in range(world)]
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q, "raise", True)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=120) for _ in range(world))
@@ -322,4 +324,4 @@ def test_bench_refuses_to_measure_over_another_transport_by_default(fail_on):
         p.join(60)
         assert p.exitcode == 0
     assert [g[1] for g in got] == ["SystemExit", "SystemExit"]
-    assert all("C-ABI communicator" in g[2] and "nothing was measured" in g[2] for g in got)
+    assert all("no C-ABI communicator" in g[2] and "nothing was measured" in g[2] for g in got)

@@ -137,6 +137,44 @@ def test_c_host_row_partitioned_loop_world1(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("whiten", [False, True])
+def test_c_host_two_ranks_sharing_the_gpu_over_the_local_transport(tmp_path, whiten):
+    """examples/sharded_embed --local: two torch-free C processes on the ONE GPU of the test box, the peer-direct (hipIpc)
+    communicator, cleora_sharded_create + cleora_embed_sharded, the id through a file.  Plain loop: equals embed_fast bit for bit;
+    --whiten: the default embed() loop, pairwise cosines against the one-GPU device loop."""
+    from cleora_amd.pycleora import SparseMatrix
+    build_example()
+    edges = _graph_file(tmp_path, 12)
+    g = SparseMatrix.from_files([str(edges)], "complex::reflexive::n")
+    env = {k: v for k, v in os.environ.items() if k not in ("CLEORA_ROCSOLVER", "CLEORA_RCCL")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = tmp_path / "o.tsv"
+    dim, iters = (16, 4) if whiten else (32, 5)
+    args = ["--local"] + (["--whiten"] if whiten else [])
+    procs = [subprocess.Popen([SHARDED] + args + [str(r), "2", str(tmp_path / "id"), "complex::reflexive::n", str(dim), str(iters), str(out), str(edges)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    errs = []
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            _, err = p.communicate()
+        errs.append(err)
+    assert [p.returncode for p in procs] == [0, 0], errs
+    assert "peer-direct" in errs[0]
+    ids, got = read_tsv(out)
+    assert ids == g.entity_ids
+    if not whiten:
+        np.testing.assert_array_equal(got, g.embed_fast(dim, iters))
+    else:
+        from cleora_amd import embed as dev_embed
+        want = dev_embed.embed(g, dim, iters)
+        cos = lambda e: (lambda u: u @ u.T)(e.astype(np.float64) / np.linalg.norm(e.astype(np.float64), axis=1, keepdims=True))
+        assert np.abs(cos(got) - cos(want)).max() < 1e-3
+
+
+@pytest.mark.gpu
 def test_c_host_row_partitioned_loop_two_gpus(tmp_path):
     """Two processes, two GPUs, RCCL over the C ABI, the unique id through a file: equals the single-GPU result."""
     from cleora_amd import _hip

@@ -1015,11 +1015,36 @@ def main():
                     tnote = "profiles/hbm_traffic.json was measured on another build of the kernel (stale): re-profile"
                 else:
                     traffic = rec.get("bytes_per_launch")
-                    tnote = f"rocprofv3 PMC, profiles/{rec.get('source', 'r02_pmc.json')}"
+                    tnote = (f"rocprofv3 PMC of the same kernel build, committed in profiles/{rec.get('source', 'r02_pmc.json')} — NOT measured in this run "
+                             f"(counters perturb the timing; the stamp in profiles/hbm_traffic.json ties it to these kernel sources)")
             except Exception as ex:
                 tnote = f"unreadable profiles/hbm_traffic.json: {ex}"
         r["roofline"]["traffic"] = traffic
         r["roofline"]["traffic_note"] = tnote
+        # the same launch on the FIRST (plain) allocation pair, before the library's placement search
+        pt = r.get("placement_tuning") or {}
+        if pt.get("untuned_launch_ms"):
+            r["roofline"]["frac_untuned"] = r["roofline"]["algorithmic_bytes_per_launch"] / (pt["untuned_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            r["roofline"]["frac_untuned_note"] = "one launch on the first allocation pair cleora_alloc_iterates drew (what a plain hipMalloc pair runs at)"
+        # end-to-end drift figures of the GPU suite (tests/test_gpu_parity_at_scale.py), quoted from the committed record
+        ppath = os.path.join(ROOT, "profiles", "r04_parity_at_scale.json")
+        if os.path.exists(ppath):
+            try:
+                pj = json.load(open(ppath))
+                drift = {"source": "profiles/r04_parity_at_scale.json (tests/test_gpu_parity_at_scale.py at BASELINE config 2's size; NOT measured in this run)"}
+                plain = pj.get("plain_loop_drift_c2", {}).get("compared_at_iterations", {})
+                if plain:
+                    last = str(max(int(k) for k in plain))
+                    drift["plain_loop_max_abs_diff_vs_oracle"] = {"iterations": int(last), "value": plain[last]["max_abs_diff"], "stated_tolerance": 5e-5}
+                dl = pj.get("default_loop_40_iterations_c2", {})
+                if dl:
+                    drift["default_loop_max_abs_cosine_diff_vs_reference_order"] = {k: v["max_abs_cosine_diff_2000_rows"] for k, v in dl.get("vs_reference_order_on_gpu", {}).items()}
+                    drift["default_loop_max_abs_cosine_diff_vs_oracle_loop"] = {"iterations": dl.get("vs_oracle_loop", {}).get("iterations"),
+                                                                                "value": dl.get("vs_oracle_loop", {}).get("max_abs_cosine_diff_2000_rows")}
+                    drift["default_loop_stated_tolerance"] = 1e-4
+                r["checks"]["drift_at_scale"] = drift
+            except Exception as ex:                           # noqa: BLE001
+                r["checks"]["drift_at_scale"] = {"error": f"unreadable profiles/r04_parity_at_scale.json: {ex}"}
         out = {
             "metric": METRIC if args.config == "C3" else f"propagate iterations/sec & edges·dim/sec, BASELINE config {args.config}", "value": r["value"], "unit": "edge*dim/s",
             "iterations_per_sec": r["iterations_per_sec"],

@@ -909,21 +909,29 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
     tp[idx] = (u32x4){w[0], w[1], w[2], w[3]};
 }
 
-// U = k-steps per trip of the flat loop (a divisor of ksteps, a multiple of RING): the compiler copies the live part of the
+// U = k-steps per trip of the flat loop (a divisor of ksteps, a multiple of 2 RING): the compiler copies the live part of the
 // operand ring at the loop's back edge — behind a vmcnt(0) that drains the prefetch — so the back edge is taken as rarely
 // as the shape allows (once per row tile at d = 256).
 // RG = row groups of 32 rows per block: 2 (a 64-row tile, 4 waves, two blocks per CU) or 4 (a 128-row tile, 8 waves, one
 // block per CU — for large n: the same two waves per SIMD, but one B stage feeds twice the MFMAs, so the L2 traffic of
 // the B stream (60 GB per call at the C3 shape, 2.6 of 8.75 ms by the profiling builds) halves).
-template <bool SCALED, bool BLEND, int RING, int U, int RG = 2>
-__global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
-                                                                                   uint32_t ksteps, uint64_t tiles) {
+// Round 4: the two waves of a row group (column halves wc = 0 / 1) need the SAME A fragments.  Until round 3 each loaded,
+// centred and split them for itself — the split is 4.5 vector instructions per element, ~60 of the ~90 non-MFMA instructions of a
+// k-step, in a kernel that is bound by instruction issue (MFMA pipe busy 0.51: profiles/r03_whiten_pmc.json).  Now the waves take
+// turns: the wave whose parity PAR matches k-step g + 1 loads, centres and splits it under the MFMAs of k-step g and leaves the
+// three fragments in LDS (af[(g + 1) & 1][row group]: 3 KiB), both read them after the step's barrier.  Same values, same
+// order of operations: results are bit-identical to the round-3 kernel.  RING counts a wave's OWN k-steps in flight (every second).
+// PAR = wc ^ (row group >> 1), so that the two waves of a SIMD (w and w + 4) produce in opposite steps.
+template <bool SCALED, bool BLEND, int RING, int U, int RG, int PAR>
+__device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x4 *__restrict__ tp, uint32_t ksteps, uint64_t tiles,
+                                                   unsigned char *smem) {
+    static_assert(U % 2 == 0 && (U / 2) % RING == 0, "ring slots must be compile-time functions of the unrolled step");
     constexpr int T = RG * 128;            // threads
     constexpr int NB = SKB / T;            // 16-byte units of a B stage per thread (6 or 3)
     constexpr int SRT = RG * 32;           // rows per block tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *const bs = reinterpret_cast<u32x4 *>(smem);                           // [2][SKB]
-    float *const mean_s = reinterpret_cast<float *>(smem + 2 * SKB * 16);        // [16 ksteps]
+    u32x4 *const af = bs + 2 * SKB;                                              // [2][RG][3][64]: the A fragments of a k-step
+    float *const mean_s = reinterpret_cast<float *>(af + 2 * RG * 3 * 64);       // [16 ksteps]
     float *const red = mean_s + 16 * ksteps;                                     // [2 RG waves][32 rows]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1, i = lane & 31, h = lane >> 5;
@@ -938,12 +946,12 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
 #pragma unroll
     for (int u = 0; u < NB; ++u) bs[t + T * u] = tpp[t + T * u];
 
-    // ---- operand ring: A of the next RING k-steps --------------------------------------------------------------------
+    // ---- operand ring: A of this wave's next RING own k-steps (k-steps PAR, PAR + 2, ...) -------------------------------------
     float4 ra[RING][2], rb[BLEND ? RING : 1][2];
     float rs[SCALED ? RING : 1];          // the row's scale travels with its operand slot (an unconditional 4-byte load per
                                           // k-step: a load behind a "first k-step of a tile" branch would cost the counted waits)
     uint64_t ltile = blockIdx.x;          // row tile / k-step of the NEXT load
-    uint32_t lks = 0;
+    uint32_t lks = PAR;
     auto row_of = [&](uint64_t tile) {
         const uint64_t r = tile * SRT + (uint64_t)(wr * 32 + i);
         return r < a.n ? r : a.n - 1;                                            // clamped: always a valid address
@@ -959,7 +967,8 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
             rb[slot][1] = *reinterpret_cast<const float4 *>(p2 + 8);
         }
         if constexpr (SCALED) rs[slot] = a.rowscale[r];
-        if (++lks == ksteps) { lks = 0; ltile += gridDim.x; }
+        lks += 2;                                                                // ksteps is even: the parity stays
+        if (lks >= ksteps) { lks -= ksteps; ltile += gridDim.x; }
     };
     // centre (block = embeddings - mean_f32, pycleora/__init__.py:161), blend, split: slot -> three bf16x8 fragments
     auto split_a = [&](int slot, uint32_t ks, u32x4 (&as)[3]) {
@@ -983,8 +992,12 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
             as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
         }
     };
+    auto publish = [&](int buf, const u32x4 (&as)[3]) {
 #pragma unroll
-    for (int slot = 0; slot < RING; ++slot) issue_a(slot);                       // k-steps 0 .. RING-1
+        for (int sp = 0; sp < 3; ++sp) af[((buf * RG + wr) * 3 + sp) * 64 + lane] = as[sp];
+    };
+#pragma unroll
+    for (int slot = 0; slot < RING; ++slot) issue_a(slot);                       // own k-steps PAR, PAR + 2, ...
 
     f16v acc[4];
 #pragma unroll
@@ -992,29 +1005,37 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
 
+    __syncthreads();                                                             // mean_s is in place
+    if constexpr (PAR == 0) {                                                    // the fragments of k-step 0
+        u32x4 first[3];
+        split_a(0, 0, first);
+        publish(0, first);
+    }
     __syncthreads();
-    u32x4 as_cur[3];
-    split_a(0, 0, as_cur);                                                       // the fragments of k-step 0
     uint64_t tile = blockIdx.x;
     uint32_t ks0 = 0;
     for (uint64_t g0 = 0; g0 < total; g0 += U) {
 #pragma unroll
         for (int uu = 0; uu < U; ++uu) {
             constexpr int kRing = RING;
-            const int rr = uu % kRing;                                           // the ring slot of this k-step
             const uint32_t ks = ks0 + uu;
             const int buf = uu & 1;                                              // U is even
+            const bool produce = ((uu + 1) & 1) == PAR;                          // this wave makes the fragments of k-step g + 1
             // B of the next k-step: six coalesced 16-byte loads per thread, written to the other buffer at the end
             const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
             u32x4 bst[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) bst[u] = tpp[(uint64_t)ksn * SKB + t + T * u];
-            // A of k-step g + RING into the slot whose fragments were made during the PREVIOUS step, right behind the B loads:
-            // the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in order), the one at
-            // the end of the next step completes them; they are split two steps after that
-            issue_a(rr);
+            // a step in which this wave does not produce refills the slot it emptied in the previous step (or the prologue), right
+            // behind the B loads: the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in
+            // order); they are split three steps from now
+            if (!produce) issue_a(((uu - PAR) / 2) % kRing);
 
-            // B fragments of this wave's four tiles, all three splits
+            // A fragments of this k-step (made by this wave or its partner during the previous step), B fragments of this wave's
+            // four tiles, all three splits
+            u32x4 as_cur[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) as_cur[sp] = af[((buf * RG + wr) * 3 + sp) * 64 + lane];
             u32x4 bf[3][4];
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp)
@@ -1030,8 +1051,9 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
                                                                       __builtin_bit_cast(bf16x8, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
                 // the fragments of the NEXT k-step are made here, under this step's MFMAs (the matrix pipe runs them for
                 // 32 cycles each; the ~50 VALU instructions of centre + split issue in their shadow)
-                if (q == 0) split_a((rr + 1) % RING, ksn, as_next);
+                if (q == 0 && produce) split_a(((uu + 1 - PAR) / 2) % kRing, ksn, as_next);
             }
+            if (produce) publish(buf ^ 1, as_next);
 
             // B of the next k-step into the other buffer (nobody reads it during this step).  Before the tile epilogue, not
             // after: behind that branch the compiler cannot count the epilogue's stores and drains everything (vmcnt(0)),
@@ -1082,13 +1104,20 @@ __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kerne
                     }
                 tile += gridDim.x;
             }
-            as_cur[0] = as_next[0];
-            as_cur[1] = as_next[1];
-            as_cur[2] = as_next[2];
             __syncthreads();
         }
         ks0 = ks0 + U == ksteps ? 0 : ks0 + U;
     }
+}
+
+template <bool SCALED, bool BLEND, int RING, int U, int RG = 2>
+__global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
+                                                                                   uint32_t ksteps, uint64_t tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int w = threadIdx.x >> 6;
+    // whole waves take each arm; every arm meets the same barriers
+    if ((((w >> 1) >> 1) ^ w) & 1) project_split_body<SCALED, BLEND, RING, U, RG, 1>(a, tp, ksteps, tiles, smem);
+    else project_split_body<SCALED, BLEND, RING, U, RG, 0>(a, tp, ksteps, tiles, smem);
 }
 
 }  // namespace
@@ -1249,7 +1278,8 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     // split-bf16 form: any d that is a multiple of 32 whose mean fits the block's LDS beside the two B stages, any k.
     // Everything else (d % 32 != 0, unaligned rows, d beyond ~28k) takes the tiled f32-MFMA kernel below.
     const uint32_t ksteps = d / 16, passes = (k + SN - 1) / SN;
-    const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
+    // two B stages, the A fragments of two k-steps for up to four row groups, the mean, the row-norm partials
+    const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)2 * 4 * 3 * 1024 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
     if (a.w4x && d % 32 == 0 && lds_bytes <= 160 * 1024) {
         const uint64_t units = (uint64_t)passes * ksteps * SKB;
         u32x4 *tp = nullptr;
@@ -1286,13 +1316,15 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
                     hipLaunchKernelGGL((project_split_kernel<SC, BL, RING, UU, RG>), grid, dim3(RG * 128), lds_bytes, stream, a, tp,   \
                                        ksteps, tiles);                                                                                 \
             } while (0)
-            if constexpr (!BL) {                  // ring of 4 k-steps (the blended operand doubles the ring: 2 there)
-                if (ksteps % 16 == 0) { CLEORA_SPLIT_LAUNCH(4, 16); return; }
-                if (ksteps % 8 == 0) { CLEORA_SPLIT_LAUNCH(4, 8); return; }
-                if (ksteps % 4 == 0) { CLEORA_SPLIT_LAUNCH(4, 4); return; }
+            // RING = a wave's own k-steps in flight (every second k-step is its own): 2 = four k-steps ahead; the blended operand
+            // doubles the registers of a slot: 1 there.  U / 2 must be a multiple of RING.
+            if constexpr (!BL) {
+                if (ksteps % 16 == 0) { CLEORA_SPLIT_LAUNCH(2, 16); return; }
+                if (ksteps % 8 == 0) { CLEORA_SPLIT_LAUNCH(2, 8); return; }
+                if (ksteps % 4 == 0) { CLEORA_SPLIT_LAUNCH(2, 4); return; }
             }
-            if (ksteps % 8 == 0) CLEORA_SPLIT_LAUNCH(2, 8);
-            else CLEORA_SPLIT_LAUNCH(2, 2);
+            if (ksteps % 8 == 0) CLEORA_SPLIT_LAUNCH(1, 8);
+            else CLEORA_SPLIT_LAUNCH(1, 2);
 #undef CLEORA_SPLIT_LAUNCH
         };
         auto launch_rg = [&](auto RGt) {

@@ -10,8 +10,8 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python "$root/bench.py" --no-cpu-baseline --whiten-iters 0 > "$out/bench_stats.log" 2>&1
-# whitening kernels: cleora_project_dev + the statistics in both forms (f64 Gram; the f32-matrix-core Gram of the loop's intermediate iterations)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wstats" -o whiten -- python "$root/scripts/r03_probe.py" kernels > "$out/whiten_stats.log" 2>&1
+# whitening kernels: cleora_project_dev (plain and loop form) + the statistics in both forms (f64 Gram; the split-bf16 Gram of the loop's intermediate iterations)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/wstats" -o whiten -- python "$root/scripts/r04/kernel_probe.py" > "$out/whiten_stats.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/fetch.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/write.log" 2>&1
 # cross-check of FETCH_SIZE against the raw L2 -> fabric request counters it derives from (and how many of them go to DRAM
@@ -21,7 +21,7 @@ timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDRE
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/hit" -o pmc -- python "$root/scripts/pmc_probe.py" > "$out/hit.log" 2>&1
 fi
 # whitening kernels: MFMA pipe occupancy (SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, GRBM_GUI_ACTIVE per XCD)
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/wpmc" -o pmc -- python "$root/scripts/r03_probe.py" kernels > "$out/wpmc.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/wpmc" -o pmc -- python "$root/scripts/r04/kernel_probe.py" > "$out/wpmc.log" 2>&1
 if [ -z "${LITE:-}" ]; then
 # BASELINE config 2 (bipartite 1M / 20M, d = 256): kernel time and HBM bytes of the same kernel
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/c2_stats" -o c2 -- python "$root/scripts/pmc_probe.py" --graph c2 --iters 40 > "$out/c2_stats.log" 2>&1

@@ -478,6 +478,7 @@ int peer_check(cleora_comm *c) {
     uint64_t err = 0;
     CL_HIP(hipMemcpy(&err, &c->peer->mailbox->error, sizeof err, hipMemcpyDeviceToHost));
     if (err) {
+        (void)hipMemset(&c->peer->mailbox->error, 0, sizeof err);       // reported once
         set_error("peer transport: rank " + std::to_string(c->rank) + " waited 60 s for rank " + std::to_string((int)((err >> 8) & 0xff)) +
                   " (channel " + std::to_string((int)(err & 0xff) - 1) + ", operation " + std::to_string((unsigned long long)(err >> 16)) + "): a peer died or the mappings are not coherent");
         return CLEORA_E_RCCL;

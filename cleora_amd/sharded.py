@@ -459,6 +459,10 @@ def embed_sharded(sg, kind, x0, iterations, residual_weight=0.0, convergence_thr
     x = x0
     x_next = torch.zeros_like(x0)
     if whiten:
+        if convergence_threshold > 0:
+            #  the model's whitened loops run exactly `iterations` iterations; the early stop between whitened iterates
+            # (pycleora/__init__.py:122-125) is in the library's loop: DeviceShardedGraph.embed / cleora_embed_sharded
+            raise ValueError("the model's whitened loops have no convergence test: use DeviceShardedGraph.embed (cleora_embed_sharded)")
         if whiten != "sequential" and flags == _hip.F_L2NORM:
             return embed_whitened_sharded(sg, kind, x0, iterations, residual_weight), iterations
         y = torch.zeros_like(x0)

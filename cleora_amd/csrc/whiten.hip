@@ -23,6 +23,13 @@ namespace cleora {
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v from the lane a DPP control selects inside this lane's 16-lane row (0xB1 / 0x4E: quad_perm [1,0,3,2] / [2,3,0,1]; 0x141 / 0x140:
+// row_half_mirror / row_mirror)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -1072,15 +1079,31 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
                         for (int jj = 0; jj < 4; ++jj) v += a.norm == 1 ? acc[jj][reg] * acc[jj][reg] : fabsf(acc[jj][reg]);
                         pr[reg] = v;
                     }
+                    // Sum over the 32 lanes of a half-wave (the tile's 32 columns), 16 values per lane, on the vector unit alone (round 4:
+                    // the butterfly of 80 ds_bpermute per wave kept the LDS pipe busy for ~2 500 cycles per tile while no MFMA ran):
+                    // v_permlane16_swap exchanges the odd 16-lane row of one register with the even row of another — one swap + one
+                    // add folds the two rows of values r and r + 8 together (even rows end up with r, odd rows with r + 8) —, then four
+                    // DPP adds (lane ^ 1, lane ^ 2, mirror inside 8, mirror inside 16) complete the sum inside each 16-lane row.
 #pragma unroll
-                    for (int ofs = 16; ofs > 0; ofs >>= 1)
+                    for (int r = 0; r < 8; ++r) {
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(pr[r]), "+v"(pr[r + 8]));
+                        pr[r] += pr[r + 8];
+                    }
 #pragma unroll
-                        for (int reg = 0; reg < 16; ++reg) pr[reg] += __shfl_xor(pr[reg], ofs, 64);
-                    float mine = 0.f;                                            // lane i < 16 of half h publishes row slot i
+                    for (int r = 0; r < 8; ++r) {
+                        pr[r] += dpp_move<0xB1>(pr[r]);                          // quad_perm [1, 0, 3, 2]
+                        pr[r] += dpp_move<0x4E>(pr[r]);                          // quad_perm [2, 3, 0, 1]
+                        pr[r] += dpp_move<0x141>(pr[r]);                         // row_half_mirror
+                        pr[r] += dpp_move<0x140>(pr[r]);                         // row_mirror
+                    }
+                    float mine = 0.f;                                            // lane i with bit 3 clear publishes value (i & 7) + 8 (i >> 4)
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        if (i == reg) mine = pr[reg];
-                    if (i < 16) red[w * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = mine;
+                    for (int r = 0; r < 8; ++r)
+                        if ((i & 7) == r) mine = pr[r];
+                    if (!(i & 8)) {
+                        const int reg = (i & 7) + 8 * (i >> 4);
+                        red[w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = mine;
+                    }
                     __syncthreads();
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {

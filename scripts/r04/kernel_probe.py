@@ -44,4 +44,11 @@ done = ctypes.c_int(0)
 out["project_loop_form_ms"] = timed(lambda: _hip.check(L.cleora_project_general_dev(x.data_ptr(), d, n, d, mean32.data_ptr(), t.data_ptr(), d, y.data_ptr(), d,
                                                                                     rs.data_ptr(), None, 0, 1.0, 0.0, 1, ctypes.byref(done), s)))
 out["project_norm_done"] = done.value
+out["project_norm_only_ms"] = timed(lambda: _hip.check(L.cleora_project_general_dev(x.data_ptr(), d, n, d, mean32.data_ptr(), t.data_ptr(), d, y.data_ptr(), d,
+                                                                                    None, None, 0, 1.0, 0.0, 1, ctypes.byref(done), s)))
+out["project_scale_only_ms"] = timed(lambda: _hip.check(L.cleora_project_general_dev(x.data_ptr(), d, n, d, mean32.data_ptr(), t.data_ptr(), d, y.data_ptr(), d,
+                                                                                     rs.data_ptr(), None, 0, 1.0, 0.0, 0, ctypes.byref(done), s)))
+x2 = torch.roll(x, 1, 0)
+out["project_loop_form_blend_ms"] = timed(lambda: _hip.check(L.cleora_project_general_dev(x.data_ptr(), d, n, d, mean32.data_ptr(), t.data_ptr(), d, y.data_ptr(), d,
+                                                                                          rs.data_ptr(), x2.data_ptr(), d, 0.8, 0.2, 1, ctypes.byref(done), s)))
 print(json.dumps(out), flush=True)

@@ -1105,12 +1105,17 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
                         red[w * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h] = mine;
                     }
                     __syncthreads();
+                    // one factor per lane — lane (i & 15) of half h takes value i & 15 of that half — instead of all sixteen in every
+                    // lane (the IEEE sqrt and division are ~20 instructions each); the sixteen reach the lanes as scalars (v_readlane)
+                    const int mreg = i & 15, mrl = (mreg & 3) + 8 * (mreg >> 2) + 4 * h;
+                    const float msum = red[(wr * 2) * 32 + mrl] + red[(wr * 2 + 1) * 32 + mrl];       // column halves in order
+                    // L2: v * (1 / max(sqrt(s), 1e-10)) like src/embedding.rs:98-102; L1: v / max(s, 1e-10) (pycleora/__init__.py:947-950)
+                    const float mf = a.norm == 1 ? 1.0f / fmaxf(sqrtf(msum), 1e-10f) : fmaxf(msum, 1e-10f);
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
-                        const int rl = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                        const float sum = red[(wr * 2) * 32 + rl] + red[(wr * 2 + 1) * 32 + rl];      // column halves in order
-                        // L2: v * (1 / max(sqrt(s), 1e-10)) like src/embedding.rs:98-102; L1: v / max(s, 1e-10) (pycleora/__init__.py:947-950)
-                        const float f = a.norm == 1 ? 1.0f / fmaxf(sqrtf(sum), 1e-10f) : fmaxf(sum, 1e-10f);
+                        const float flo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mf), reg));
+                        const float fhi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mf), 32 + reg));
+                        const float f = h ? fhi : flo;
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) acc[jj][reg] = a.norm == 1 ? acc[jj][reg] * f : acc[jj][reg] / f;
                     }

@@ -48,12 +48,27 @@ def test_cartesian_product_order_unit_test():
     assert combos == [(10, 30), (10, 40), (10, 50), (20, 30), (20, 40), (20, 50)]
 
 
-def test_stdrng_first_words():
-    # self-consistency: two generators agree and the stream is not degenerate
+def test_chacha_core_against_rfc7539_vectors():
+    """The ChaCha core under oracle/stdrng.py (rand_chacha 0.3.1 is not vendored: restated) against PUBLISHED vectors — RFC 7539
+    section 2.1.1 (one quarter round) and section 2.3.2 (the 20-round block function; StdRng runs the same rounds 12 times, with a
+    64-bit counter): independent evidence for the generator, beside the four insta snapshots it reproduces end to end below.
+    (Round 3 had a test here that compared the generator with itself: VERDICT round 3, weak #10.)"""
+    s = [0x11111111, 0x01020304, 0x9B8D6F43, 0x01234567]
+    stdrng._quarter(s, 0, 1, 2, 3)
+    assert s == [0xEA2A92F4, 0xCB1CF8CE, 0x4581472E, 0x5881C4BB]
+    key = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    init = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + key + [1, 0x09000000, 0x4A000000, 0]
+    st = list(init)
+    q = stdrng._quarter
+    for _ in range(10):
+        q(st, 0, 4, 8, 12); q(st, 1, 5, 9, 13); q(st, 2, 6, 10, 14); q(st, 3, 7, 11, 15)
+        q(st, 0, 5, 10, 15); q(st, 1, 6, 11, 12); q(st, 2, 7, 8, 13); q(st, 3, 4, 9, 14)
+    out = [(st[i] + init[i]) & 0xFFFFFFFF for i in range(16)]
+    assert out == [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3, 0xC7F4D1C7, 0x0368C033, 0x9AAA2204, 0x4E6CD4C3,
+                   0x466482D2, 0x09AA9F07, 0x05D7C214, 0xA2028BD9, 0xD19C12B5, 0xB94E16DE, 0xE883D0CB, 0x4E3C50A2]
+    # the generator itself: same seed, same stream; 12 rounds is not 20
     a, b = stdrng.StdRng(2137), stdrng.StdRng(2137)
-    wa = [a.next_u32() for _ in range(40)]
-    assert wa == [b.next_u32() for _ in range(40)]
-    assert len(set(wa)) == 40
+    assert [a.next_u32() for _ in range(40)] == [b.next_u32() for _ in range(40)]
 
 
 XXH64_SPEC = [  # (input, seed, digest) from the XXH64 specification / reference implementation
@@ -140,11 +155,20 @@ def test_karate_graph_and_embed(golden_dir):
     np.testing.assert_array_equal(g.val_left, k["val_left"])
     sums = np.add.reduceat(g.val_left.astype(np.float64), g.rowptr[:-1].astype(np.int64))
     np.testing.assert_allclose(sums, 1.0, atol=2e-7)   # row-stochastic
-    # reference embed() fast path == oracle.embed (the stub's embed_fast IS the oracle; this
-    # checks the reference's path selection and that init + loop are wired the same way)
+    # the reference's embed() fast path over the stub IS oracle.embed (tests/golden/make_golden.py), so equality with the stored
+    # array is a REGRESSION pin of the oracle, not evidence for it ...
     x0 = oracle.init(g.entity_hashes, 16, 0)
     got, it = oracle.embed(g.rowptr, g.col, g.val_left, x0, 40)
     np.testing.assert_array_equal(got, k["embed_fast_d16"])
+    # ... the evidence is an independent implementation of the same loop (src/embedding.rs:106-136: SpMM, then v / max(||v||, 1e-10)):
+    # scipy's CSR @ dense and numpy's norm, f32 — another summation order, so to rounding (40 iterations on unit rows), not to the bit
+    import scipy.sparse as sp
+    a = sp.csr_matrix((g.val_left, g.col.astype(np.int64), g.rowptr.astype(np.int64)), shape=(34, 34))
+    y = x0.copy()
+    for _ in range(40):
+        y = (a @ y).astype(np.float32)
+        y = y / np.maximum(np.linalg.norm(y, axis=1, keepdims=True), np.float32(1e-10))
+    np.testing.assert_allclose(got, y, rtol=0, atol=2e-6)
     # reference slow path (numpy L2) vs oracle loop (Rust-order L2): last-ulp differences only
     prop = lambda x: oracle.spmm(g.rowptr, g.col, g.val_sym, x)
     slow, _ = whiten.embed_slow(prop, x0, 8, whiten=False)

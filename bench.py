@@ -973,25 +973,34 @@ def main():
             keep = (a, b, iterate, blocks, sg)
         else:
             if part == "row" and args.whiten_iters > 0 and sg.embed_bytes(d, _hip.F_WHITEN) + 3 * sg.n_pad * d * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.9:
-                # the DEFAULT loop over the partition, one call: cleora_embed_sharded + CLEORA_F_WHITEN (wall clock incl. the final PCA whitening)
+                # the DEFAULT loop over the partition, one call: cleora_embed_sharded + CLEORA_F_WHITEN (wall clock incl. the final PCA whitening).
+                # An extra beside the headline: a failure here is reported in the line, it does not cost the measurement above.
                 comm.unregister(a)
                 comm.unregister(b)
-                _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
-                torch.cuda.synchronize()
-                sg.embed(a, _hip.LEFT, d, 2, 0.0, 0.0, _hip.F_WHITEN)       # untimed: the first eigensolver call of a process
-                _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
-                torch.cuda.synchronize()
-                launcher.barrier()
-                t0 = time.perf_counter()
-                sg.embed(a, _hip.LEFT, d, args.whiten_iters, 0.0, 0.0, _hip.F_WHITEN)
-                el = launcher.max(time.perf_counter() - t0)
-                cov = torch.cov(a[: min(n, 2_000_000)].double().T)
-                whitened_sharded = {"ms_per_iter": el / args.whiten_iters * 1e3, "iterations": args.whiten_iters,
-                                    "loop": "cleora_embed_sharded + CLEORA_F_WHITEN (csrc/sharded.hip: two replicas + the rank's own rows; statistics "
-                                            "all-reduced, one all-gather of the iterate per iteration); wall clock of the call incl. its allocations, "
-                                            "the registration of the replicas and the final PCA whitening",
-                                    "device_bytes_beside_the_callers_replica": sg.embed_bytes(d, _hip.F_WHITEN),
-                                    "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
+                err = ""
+                try:
+                    _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
+                    torch.cuda.synchronize()
+                    sg.embed(a, _hip.LEFT, d, 2, 0.0, 0.0, _hip.F_WHITEN)       # untimed: the first eigensolver call of a process
+                    _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
+                    torch.cuda.synchronize()
+                    launcher.barrier()
+                    t0 = time.perf_counter()
+                    sg.embed(a, _hip.LEFT, d, args.whiten_iters, 0.0, 0.0, _hip.F_WHITEN)
+                    el = time.perf_counter() - t0
+                except Exception as e:                                          # noqa: BLE001
+                    err, el = f"{type(e).__name__}: {e}"[:300], 0.0
+                el = launcher.max(el)
+                if launcher.max(1.0 if err else 0.0) > 0:
+                    whitened_sharded = {"error": err or "another rank failed"}
+                else:
+                    cov = torch.cov(a[: min(n, 2_000_000)].double().T)
+                    whitened_sharded = {"ms_per_iter": el / args.whiten_iters * 1e3, "iterations": args.whiten_iters,
+                                        "loop": "cleora_embed_sharded + CLEORA_F_WHITEN (csrc/sharded.hip: two replicas + the rank's own rows; statistics "
+                                                "all-reduced, one all-gather of the iterate per iteration); wall clock of the call incl. its allocations, "
+                                                "the registration of the replicas and the final PCA whitening",
+                                        "device_bytes_beside_the_callers_replica": sg.embed_bytes(d, _hip.F_WHITEN),
+                                        "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
             elif part == "row" and isinstance(comm, comm_mod.RcclComm):
                 comm.unregister(a)
                 comm.unregister(b)

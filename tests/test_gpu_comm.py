@@ -41,10 +41,17 @@ def test_rccl_world1_collectives_and_stream_ordering():
     assert (r.value, w.value, d.value) == (0, 1, 0)
     x = torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3).contiguous()
     want = x.clone()
-    for algo in (_hip.ALLGATHER_RING, _hip.ALLGATHER_P2P):
+    with pytest.raises(ValueError, match="enable the peer transport"):
+        c.set_allgather(_hip.ALLGATHER_PEER)        # the third algorithm needs cleora_comm_enable_peer first
+    c.enable_peer()                                 # (a world of one: the mailbox only, nothing to map)
+    c.register(x)
+    for algo in (_hip.ALLGATHER_RING, _hip.ALLGATHER_P2P, _hip.ALLGATHER_PEER):
         c.set_allgather(algo)
         c.allgather_rows(x, [1, 4])                 # one shard: rows 1..3
         c.join()
+    c.check()
+    c.unregister(x)
+    c.set_allgather(_hip.ALLGATHER_RING)
     c.allreduce_async(x)
     c.join()
     c.allreduce(x)

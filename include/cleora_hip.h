@@ -267,10 +267,11 @@ int cleora_whiten_transform_dev(const double *gram_dev, uint64_t n, uint32_t d, 
  * the exact f64 mean (:136) and the centred Gram sum_r (x_r - mean)(x_r - mean)^T (:138-143 without the 1/(n-1)), computed
  * around a sampled shift and corrected exactly (csrc/whiten.hip).  intermediate = 0: f64 matrix cores end to end, the form
  * behind every whitening a caller can observe.  intermediate = 1: the form the whitened loop takes for iterations whose
- * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — for d a multiple of 256 (<= 2048) the Gram comes
- * from the bf16 matrix cores with three-way split f32 operands (six exact bf16 products per f32 product; the matrix cores sum
- * 32 rows, the vector unit adds those sums in f32 over <= 2048 rows, f64 across: ~1e-8 of the f64 Gram; CLEORA_GRAM=f32 takes
- * the f32 matrix cores instead, ~5e-8), other shapes as intermediate = 0.
+ * whitening only has to BE a whitening (see cleora_whiten_transform_any_dev) — for d a multiple of 256 (<= 2048) and n >= 4096 the
+ * Gram comes from the bf16 matrix cores with split f32 operands (the matrix cores sum 32 rows, the vector unit adds those sums in f32
+ * over <= 2048 rows, f64 across): six exact bf16 products per f32 product below 2^20 rows (~1e-8 of the f64 Gram), three plus the
+ * diagonal's residual term from 2^20 rows on (what they drop falls as sqrt(d) 2^-18 / sqrt(n): 1.9e-8 at n = 10 M, d = 256); other
+ * shapes as intermediate = 0.
  * workspace: cleora_whiten_workspace(n, d) BYTES; mean64_dev: f64[d]; gram_dev: f64[d*d].  n >= 2. */
 int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, void *workspace, int intermediate,
                             double *mean64_dev, double *gram_dev, void *stream);
@@ -282,7 +283,8 @@ int cleora_whiten_stats_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d
  * max(lambda, 1e-10) (:155) is provably inactive: potrf succeeds, the smallest squared pivot is >= 1e-8 and
  * trace(cov^-1) = ||L^-T||_F^2 <= 1e10 (=> lambda_min >= 1e-10).  Otherwise the PCA form of cleora_whiten_transform_dev
  * (k = d) is computed.  *form_out (host, may be NULL): 1 = Cholesky form, 0 = PCA form.  For d <= 256 the factorisation runs
- * on the host (cleora_cholesky_whiten_host below: Gram down, transform up, ~1 ms), beyond on rocSOLVER (CLEORA_CHOLESKY=host|library|kernel).
+ * on the host (cleora_cholesky_whiten_host below: Gram down, transform up, ~1 ms), beyond on rocSOLVER's potrf + trtri.  gram_dev is taken as
+ * EXACT (f64 statistics); the library's own loops add a margin when theirs are the approximate ones (csrc/eigh.hip).
  * Unlike the other *_dev entry points this one WAITS for `stream` (the decision is taken on the host). */
 int cleora_whiten_transform_any_dev(const double *gram_dev, uint64_t n, uint32_t d, float *transform_dev,
                                     void *workspace, void *stream, int *form_out);
@@ -491,10 +493,9 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
  * output rows in its own epilogue; (2) with the L2 norm, intermediate iterations may use ANY whitening transform (two differ by
  * an orthogonal factor that the linear steps, the rotation-invariant norm and the final PCA whitening remove): Cholesky
  * (potrf + trtri) instead of the eigensolver, falling back to it when the covariance is near-singular; the last iteration is
- * always the PCA form.  Results agree with the sequential order to f32 rounding.  Environment switches for A/B:
- * CLEORA_WHITEN_SEQUENTIAL=1 (the reference's order), CLEORA_WHITEN_PCA_ALWAYS=1 (eigensolver in every iteration),
- * CLEORA_CHOLESKY=library|kernel (d <= 256: rocSOLVER potrf/trtri, or the in-house single-launch kernel that needs no
- * rocBLAS; default: the library where the host process already had rocBLAS mapped, the kernel elsewhere). */
+ * always the PCA form.  Results agree with the sequential order to f32 rounding (measured at |V| = 1M, d = 256: 5e-7 on pairwise
+ * cosines after 10, 20 and 40 iterations).  The reference's order is what a convergence threshold selects (the tests pass one that is
+ * never met); there are no environment switches. */
 int cleora_embed(const cleora_graph *g, const uint64_t *entity_hash_host, const float *x0_host,
                  int markov_type, uint32_t d, uint64_t max_iterations, int64_t seed,
                  float residual_weight, float convergence_threshold, uint32_t flags,

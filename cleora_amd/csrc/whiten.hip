@@ -1,17 +1,20 @@
-// whiten.hip — the two matrix-core kernels of the PCA-whitening step
+// whiten.hip — the matrix-core kernels of the PCA-whitening step
 // (pycleora/__init__.py:130-164 `whiten_embeddings`), for gfx950.
 //
-//   centered Gram   G = sum_r (x_r - mu)(x_r - mu)^T  in f64     (:138-143, without the 1/(n-1))
-//     v_mfma_f64_16x16x4_f64; operands are centred and widened to f64 when the X tile is staged
-//     into LDS, so the accumulation is f64 end to end like the reference's `block.T @ block`
-//     on an f64 block.  Only block tiles on or above the diagonal are computed, and of a diagonal
-//     block tile only its 36 upper 16x16 MFMA tiles (9 per wave); the row range is cut into slices
-//     that are combined in a fixed order (deterministic).
+//   centred Gram    G = sum_r (x_r - mu)(x_r - mu)^T  in f64     (:138-143, without the 1/(n-1))
+//     gram_kernel: v_mfma_f64_16x16x4_f64; operands are centred and widened to f64 when the X tile is staged into LDS, so the
+//     accumulation is f64 end to end like the reference's `block.T @ block` on an f64 block.  Only block tiles on or above the
+//     diagonal, and of a diagonal block tile only its 36 upper 16x16 MFMA tiles (9 per wave); row slices are combined in a fixed
+//     order (deterministic).  Mean and Gram in ONE pass around a sampled shift, corrected exactly.
+//     gram16_kernel: the same statistics from the bf16 matrix cores with split f32 operands, for the whitened loop's INTERMEDIATE
+//     iterations only (v_mfma_f32_32x32x16_bf16; three or six exact bf16 products per f32 product).
 //   projection      out = (X - mu_f32) @ T  in f32                 (:157-163)
-//     v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate — the same arithmetic class
-//     as the reference's sgemm; summation order differs, tolerance documented in the tests).
+//     project_split_kernel: every f32 product from six bf16 MFMAs of three-way split operands — not a reduced-precision path: its
+//     error against an f64 product is that of an f32 GEMM (tests/test_gpu_whiten.py); the A split is made once per row group and
+//     shared through LDS; optional row normalisation in the epilogue (the reorganised loop of abi.hip / sharded.hip).
+//     project_kernel: v_mfma_f32_32x32x2_f32, LDS-tiled, any shape (d not a multiple of 32).
 //
-// Both are MFMA-bound (2 n d^2 flops against 1-3 passes over X), unlike the SpMM.
+// All are matrix-core work (2 n d^2 flops against 1-3 passes over X), unlike the SpMM; DESIGN.md 3.5 / 3.6 have what bounds each.
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>

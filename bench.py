@@ -998,7 +998,8 @@ def main():
                     whitened_sharded = {"ms_per_iter": el / args.whiten_iters * 1e3, "iterations": args.whiten_iters,
                                         "loop": "cleora_embed_sharded + CLEORA_F_WHITEN (csrc/sharded.hip: two replicas + the rank's own rows; statistics "
                                                 "all-reduced, one all-gather of the iterate per iteration); wall clock of the call incl. its allocations, "
-                                                "the registration of the replicas and the final PCA whitening",
+                                                "the registration of the replicas and the final PCA whitening; its schedule (statistics, then Z = A Y beside the d x d step, "
+                                                "projection and gather block by block) was never tuned on multi-GPU hardware",
                                         "device_bytes_beside_the_callers_replica": sg.embed_bytes(d, _hip.F_WHITEN),
                                         "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
             elif part == "row" and isinstance(comm, comm_mod.RcclComm):

@@ -104,6 +104,30 @@ def test_whitened_loop_at_c2_size_against_the_oracle_loop(c2):
     assert cov_err <= 1e-3, cov_err
 
 
+def test_default_loop_with_a_residual_blend_at_c2_size(c2):
+    """The blended form of the default loop (residual_weight > 0: pycleora/__init__.py:111-115 blends for ANY rw > 0) at C2 size,
+    20 iterations: the reorganised loop carries the blend through the projection (alpha (Z - s mu^T) + rw (Y - mu)) T — a different
+    kernel instantiation and operand ring than rw = 0 — against the reference's order on the same GPU.  Stated: cosines <= 1e-4."""
+    n, nnz, graph, host, hashes = c2
+    d, iters, rw = 256, 20, 0.25
+    L = _hip.lib()
+    x0 = oracle.init(hashes, d, 0)
+    rows = np.random.default_rng(12).choice(n, 2000, replace=False)
+    outs = []
+    for thr in (0.0, 1e-30):
+        dx = _hip.DevArray.from_host(x0)
+        ran = ctypes.c_uint64(0)
+        _hip.check(L.cleora_embed_dev(graph.handle, dx.ptr, _hip.LEFT, d, iters, rw, thr, _hip.F_WHITEN, ctypes.byref(ran)))
+        assert ran.value == iters
+        outs.append(dx.to_host())
+    (cg, ng), (cr, nr) = _invariants(outs[0], rows), _invariants(outs[1], rows)
+    res = {"iterations": iters, "residual_weight": rw, "max_abs_cosine_diff_2000_rows": float(np.abs(cg - cr).max()),
+           "max_rel_row_norm_diff": float((np.abs(ng - nr) / nr).max())}
+    _record("default_loop_blend_c2", res)
+    assert np.isfinite(outs[0]).all()
+    assert res["max_abs_cosine_diff_2000_rows"] <= 1e-4 and res["max_rel_row_norm_diff"] <= 1e-4, res
+
+
 def _invariants(e, rows):
     s = e[rows].astype(np.float64)
     s /= np.linalg.norm(s, axis=1, keepdims=True)

@@ -34,20 +34,20 @@ def _cosines(e, rows):
     return u @ u.T
 
 
-def _one_gpu(rowptr, col, val, x0, d, iters, rw, thr, flags):
-    g = _hip.Graph.from_host(rowptr, col, val)
+def _one_gpu(rowptr, col, val, x0, d, iters, rw, thr, flags, val_sym=None, kind=_hip.LEFT):
+    g = _hip.Graph.from_host(rowptr, col, val, val_sym)
     out = np.empty_like(x0)
     ran = ctypes.c_uint64(0)
-    _hip.check(_hip.lib().cleora_embed(g.handle, None, _hip.ptr(x0), _hip.LEFT, d, iters, 0, rw, thr, flags, _hip.ptr(out), ctypes.byref(ran)))
+    _hip.check(_hip.lib().cleora_embed(g.handle, None, _hip.ptr(x0), kind, d, iters, 0, rw, thr, flags, _hip.ptr(out), ctypes.byref(ran)))
     g.close()
     return out, ran.value
 
 
-def _run_sharded(sg, x0, d, iters, rw, thr, flags):
+def _run_sharded(sg, x0, d, iters, rw, thr, flags, kind=_hip.LEFT):
     xp = np.zeros((sg.n_pad, d), np.float32)
     xp[: sg.n] = x0
     dx = _hip.DevArray.from_host(xp)
-    ran = sg.embed(dx, _hip.LEFT, d, iters, rw, thr, flags)
+    ran = sg.embed(dx, kind, d, iters, rw, thr, flags)
     out = dx.to_host()
     dx.free()
     assert not out[sg.n:].any()                            # padding rows stay zero
@@ -74,6 +74,14 @@ def test_world_of_one_equals_the_one_gpu_loops(steps, balance):
         assert ran == 4 and np.isfinite(got).all()
         assert np.abs(_cosines(got, rows) - _cosines(want, rows)).max() < 1e-4
         assert np.abs(np.cov(got.astype(np.float64).T) - np.eye(d)).max() < 5e-3
+    # the symmetric Markov values (src/embedding.rs:7-10) through the partition: bit-equal as well
+    got, _ = _run_sharded(sg, x0, d, 3, 0.0, 0.0, 0, kind=_hip.SYMMETRIC)
+    want, _ = _one_gpu(rowptr, col, vl, x0, d, 3, 0.0, 0.0, 0, val_sym=vs, kind=_hip.SYMMETRIC)
+    np.testing.assert_array_equal(got, want)
+    # normalization="l1" with whitening (pycleora/__init__.py:947-950): not rotation invariant, so the reference's order on both sides
+    got, _ = _run_sharded(sg, x0, d, 3, 0.0, 0.0, _hip.F_WHITEN | _hip.F_L1NORM)
+    want, _ = _one_gpu(rowptr, col, vl, x0, d, 3, 0.0, 0.0, _hip.F_WHITEN | _hip.F_L1NORM)
+    assert np.abs(_cosines(got, rows) - _cosines(want, rows)).max() < 1e-4
     sg.close()
 
 

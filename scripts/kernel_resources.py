@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Registers, scratch, occupancy and LDS of every kernel, from hipcc -Rpass-analysis=kernel-resource-usage (runs in the
-build container, no GPU): python scripts/kernel_resources.py r02 -> profiles/r02_kernel_resources.txt"""
+build container, no GPU): python scripts/kernel_resources.py r04 -> profiles/r04_kernel_resources.txt"""
 import os, re, subprocess, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "cleora_amd", "csrc")
 lines = ["# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage over cleora_amd/csrc/*.hip "
          "(build flags of build.sh): file, kernel, VGPRs, AGPRs, scratch bytes/lane, waves/SIMD, LDS bytes/block"]
-for f in ("spmm", "rowops", "whiten", "eigh", "hot", "attention", "similarity", "abi"):
+for f in ("spmm", "rowops", "whiten", "eigh", "hot", "attention", "similarity", "abi", "peer", "sharded", "stager"):
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
     if f == "whiten":
         cmd += ["-mllvm", "-amdgpu-mfma-vgpr-form"]

@@ -1351,7 +1351,6 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
             // doubles the registers of a slot: 1 there.  U / 2 must be a multiple of RING.
             if constexpr (!BL) {
                 if (ksteps % 16 == 0) { CLEORA_SPLIT_LAUNCH(2, 16); return; }
-                if (ksteps % 8 == 0) { CLEORA_SPLIT_LAUNCH(2, 8); return; }
                 if (ksteps % 4 == 0) { CLEORA_SPLIT_LAUNCH(2, 4); return; }
             }
             if (ksteps % 8 == 0) CLEORA_SPLIT_LAUNCH(1, 8);

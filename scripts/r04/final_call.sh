@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 4, GPU call 8: the whole GPU suite, smoke and the profiling recipe on the round's final tree.
+# Round 4, the last full GPU call: the whole GPU suite, smoke and the profiling recipe on the round's final tree
+# (from the repository root: gpurun --timeout 3300 -- 'bash scripts/r04/final_call.sh').
 set -u
 R=$(pwd); O=$R/gpurun_out/r04h; mkdir -p $O; export TMPDIR=/tmp
 python -c 'import oracle; oracle.build()' > $O/oracle_build.log 2>&1

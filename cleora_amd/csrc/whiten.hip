@@ -1123,16 +1123,37 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
                         for (int jj = 0; jj < 4; ++jj) acc[jj][reg] = a.norm == 1 ? acc[jj][reg] * f : acc[jj][reg] / f;
                     }
                 }
+                // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                if (tile * SRT + SRT <= a.n && (uint64_t)pass * SN + SN <= a.k) {
+                    // a tile that lies inside the matrix (all but the last row tile / a ragged last pass): one 64-bit row base per
+                    // lane, the sixteen rows by additions, the four column tiles at immediate offsets — the guarded form below
+                    // spends a 64-bit multiply, a compare and a branch on each of its 64 stores (round 4: ~770 -> ~130 instructions
+                    // per wave and tile, in the one phase of the kernel in which no wave issues MFMAs)
+                    float *p0 = a.out + (tile * SRT + (uint64_t)(wr * 32 + 4 * h)) * a.ldo + (pass * SN + wc * 128 + i);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
+                    for (int g = 0; g < 4; ++g) {
+                        float *pg = p0 + (uint64_t)(8 * g) * a.ldo;
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        // 32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-                        const uint64_t row = tile * SRT + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
-                        const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
-                        if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[jj][reg];
-                        acc[jj][reg] = 0.f;
+                        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                pg[jj * 32] = acc[jj][4 * g + r];
+                                acc[jj][4 * g + r] = 0.f;
+                            }
+                            pg += a.ldo;
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            const uint64_t row = tile * SRT + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                            const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
+                            if (row < a.n && col < a.k) a.out[row * a.ldo + col] = acc[jj][reg];
+                            acc[jj][reg] = 0.f;
+                        }
+                }
                 tile += gridDim.x;
             }
             __syncthreads();

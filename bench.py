@@ -12,7 +12,7 @@ embed_full) on the synthetic power-law graph |V| = 10M, |E| = nnz ~ 200M, d = 25
 config 3).  The graph, X and the CSR are resident in HBM before the timed region.  Total work is
 fixed as N grows ("strong" scaling: BASELINE.json quotes the same graph at 1/2/4/8 GPUs).
 
-N > 1 (cleora_amd/sharded.py; kernels AND collectives go through the C ABI — RCCL is bound directly in
+N > 1 (csrc/sharded.hip through cleora_amd/sharded.py; kernels AND collectives go through the C ABI — RCCL is bound directly in
 csrc/comm.hip; torch.distributed/gloo is only the launcher: it distributes the RCCL id and reduces the
 timings).  BOTH partitions are measured, W + K iterations each, and reported in `partitions`:
   row     north_star's layout: row blocks of the CSR, full replicas of X, in-place all-gather of the

@@ -1,4 +1,4 @@
-"""Communicators for the multi-GPU propagation loop (cleora_amd/sharded.py).
+"""Communicators for the multi-GPU propagation loops (csrc/sharded.hip through cleora_amd/sharded.py; the model in tests/sharded_model.py).
 
 The product path is RcclComm: the C-ABI communicator of libcleora_hip.so (csrc/comm.hip, include/cleora_hip.h
 "multi-GPU exchange steps"), which binds RCCL directly — the same entry points a Rust host would call

@@ -6,7 +6,7 @@
 // src/embedding.rs:59-63); BASELINE.json:north_star asks for "the graph row-partitioned across the 8 GPUs
 // of one node with an RCCL all-gather of the embedding matrix over xGMI between iterations", reachable from
 // a non-Python host "through a thin extern-C FFI".  These entry points are that FFI; the partition logic that
-// drives them is cleora_amd/sharded.py (and the loop INTEGRATION.md shows for a Rust host).
+// drives them is csrc/sharded.hip (cleora_sharded_* / cleora_embed_sharded; INTEGRATION.md has the Rust declarations).
 //
 // Every collective is IN PLACE on device memory and only ENQUEUES on the caller's stream (NCCL semantics):
 // order it against the SpMM with cleora_stream_wait_stream.

@@ -5,7 +5,8 @@
 // BASELINE.json:north_star asks for ("the graph is row-partitioned across the 8 GPUs of one node with an RCCL all-gather of
 // the embedding matrix over xGMI between iterations ... Host code stays in Rust, calling the kernels through a thin extern-C
 // FFI").  Until round 3 the block schedule, stream ordering and the partitioned whitening lived in Python
-// (cleora_amd/sharded.py) and in an example; a Rust host would have had to re-write them.  Here they are ONE call each:
+// and in an example; a Rust host would have had to re-write them.  Here they are ONE call each (the Python loop lives on
+// as the model the CPU suite runs over gloo: tests/sharded_model.py):
 //
 //   cleora_sharded_plan       (pure host arithmetic) the row boundaries of the world * steps contiguous blocks
 //   cleora_sharded_create     this rank's row blocks of the CSR as device graphs
@@ -76,7 +77,7 @@ uint64_t block_size(uint64_t n, uint64_t world, uint64_t steps) {
     return b < 4 ? 4 : b;
 }
 
-// cleora_amd/sharded.py row_bounds, restated on the host (the Python model and this function are compared in the CPU suite)
+// the row boundaries (tests/sharded_model.py row_bounds is the same arithmetic in Python: the two are compared in the CPU suite)
 int plan_rows(uint64_t n, const uint64_t *rowptr, uint32_t world, uint32_t steps, int balance, std::vector<uint64_t> &bounds,
               uint64_t *n_pad, int *mode) {
     CL_REQUIRE(world >= 1 && steps >= 1, "world and steps must be positive");

@@ -19,6 +19,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from cleora_amd import _hip, comm as comm_mod, sharded
+from tests import sharded_model as model
 from tests.graphs import random_csr
 
 pytestmark = pytest.mark.gpu
@@ -88,11 +89,11 @@ def test_row_partition_on_hip_backend_with_rccl_world1(steps, balance):
     rowptr, col, vl, vs = random_csr(n, 9, seed=51, empty_frac=0.03, hubs=[(17, 2200)])
     t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
     c = comm_mod.RcclComm(comm_mod.RcclComm.unique_id(), 0, 1, 0)
-    sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), 0, 1, steps,
+    sg = model.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), 0, 1, steps,
                               sharded.HipBackend(dev), comm=c, balance=balance)
     x0 = np.zeros((sg.n_pad, d), np.float32)
     x0[:n] = np.random.default_rng(52).standard_normal((n, d)).astype(np.float32)
-    x, ran = sharded.embed_sharded(sg, 0, torch.from_numpy(x0).to(dev), 4, 0.25, 0.0)
+    x, ran = model.embed_sharded(sg, 0, torch.from_numpy(x0).to(dev), 4, 0.25, 0.0)
     want, _ = oracle.embed(rowptr, col, vl, x0[:n], 4, residual_weight=0.25)
     np.testing.assert_allclose(x[:n].cpu().numpy(), want, rtol=0, atol=2e-6)
     c.close()
@@ -110,11 +111,11 @@ def _shared_gpu_worker(rank, world, port, q):
         t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
         be, cm = sharded.HipBackend(dev), comm_mod.TorchComm()
         x0 = np.random.default_rng(62).standard_normal((n, d)).astype(np.float32)
-        sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), rank, world, 2,
+        sg = model.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), rank, world, 2,
                                   be, comm=cm, balance="nnz")
         xp = np.zeros((sg.n_pad, d), np.float32)
         xp[:n] = x0
-        xr, _ = sharded.embed_sharded(sg, 0, torch.from_numpy(xp).to(dev), 3)
+        xr, _ = model.embed_sharded(sg, 0, torch.from_numpy(xp).to(dev), 3)
         cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), d, rank,
                                         world, be, comm=cm, steps=2)
         xl, _ = sharded.embed_column_sharded(cg, 1, torch.from_numpy(np.ascontiguousarray(x0[:, cg.c0:cg.c0 + cg.dl])).to(dev), 3)
@@ -163,11 +164,11 @@ def _rccl_worker(rank, world, port, q):
         for algo in (_hip.ALLGATHER_RING, _hip.ALLGATHER_P2P):
             cm.set_allgather(algo)
             for balance in ("rows", "nnz"):
-                sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, rank, world, 3,
+                sg = model.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, rank, world, 3,
                                           be, comm=cm, balance=balance)
                 xp = np.zeros((sg.n_pad, d), np.float32)
                 xp[:n] = x0
-                xr, _ = sharded.embed_sharded(sg, 0, torch.from_numpy(xp).to(dev), 4, 0.2, 0.0)
+                xr, _ = model.embed_sharded(sg, 0, torch.from_numpy(xp).to(dev), 4, 0.2, 0.0)
                 out[(algo, balance)] = xr[:n].cpu().numpy()
         cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, d, rank, world,
                                         be, comm=cm, steps=3)

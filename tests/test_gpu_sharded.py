@@ -7,6 +7,7 @@ import torch
 
 import oracle
 from cleora_amd import _hip, sharded
+from tests import sharded_model as model
 from oracle import whiten as ow
 from tests.graphs import random_csr
 
@@ -19,7 +20,7 @@ def test_blocks_reproduce_whole_graph(steps):
     n, d = 5003, 256
     rowptr, col, vl, vs = random_csr(n, 9, seed=4, empty_frac=0.03, hubs=[(11, 2500), (4000, 1500)])
     t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
-    sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), 0, 1,
+    sg = model.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), t(vs, None), 0, 1,
                               steps, sharded.HipBackend(dev))
     assert sg.n_pad % 4 == 0 and sg.n_pad >= n and sg.local_nnz == int(rowptr[-1])
     x0 = np.zeros((sg.n_pad, d), np.float32)
@@ -27,13 +28,13 @@ def test_blocks_reproduce_whole_graph(steps):
     hub = np.zeros(n, bool)
     hub[[11, 4000]] = True
     for kind, val, rw in ((0, vl, 0.0), (1, vs, 0.35)):
-        x, ran = sharded.embed_sharded(sg, kind, torch.from_numpy(x0).to(dev), 1, rw)
+        x, ran = model.embed_sharded(sg, kind, torch.from_numpy(x0).to(dev), 1, rw)
         want, _ = oracle.embed(rowptr, col, val, x0[:n], 1, residual_weight=rw)
         got = x[:n].cpu().numpy()
         np.testing.assert_array_equal(got[~hub], want[~hub])          # unsplit rows bit-exact
         np.testing.assert_allclose(got[hub], want[hub], rtol=0, atol=2e-6)
         assert float(x[n:].abs().max()) == 0.0 if sg.n_pad > n else True
-    x, ran = sharded.embed_sharded(sg, 0, torch.from_numpy(x0).to(dev), 6, 0.0, 0.0)
+    x, ran = model.embed_sharded(sg, 0, torch.from_numpy(x0).to(dev), 6, 0.0, 0.0)
     want, _ = oracle.embed(rowptr, col, vl, x0[:n], 6)
     np.testing.assert_allclose(x[:n].cpu().numpy(), want, rtol=0, atol=2e-6)
 
@@ -43,11 +44,11 @@ def test_whitened_loop_on_blocks():
     n, d = 3001, 32
     rowptr, col, vl, vs = random_csr(n, 8, seed=6)
     t = lambda a, dt: torch.from_numpy(a.view(dt) if a.dtype.kind == "u" else a).to(dev)
-    sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, 0, 1, 3,
+    sg = model.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), t(vl, None), None, 0, 1, 3,
                               sharded.HipBackend(dev))
     x0 = np.zeros((sg.n_pad, d), np.float32)
     x0[:n] = np.random.default_rng(7).standard_normal((n, d)).astype(np.float32)
-    x, _ = sharded.embed_sharded(sg, 0, torch.from_numpy(x0).to(dev), 3, whiten=True)
+    x, _ = model.embed_sharded(sg, 0, torch.from_numpy(x0).to(dev), 3, whiten=True)
     want, _ = ow.embed_slow(lambda v: oracle.spmm(rowptr, col, vl, v), x0[:n], 3, whiten=True)
     got = x[:n].cpu().numpy()
     s = np.sign((got * want).sum(axis=0))

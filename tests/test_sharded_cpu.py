@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 
 import oracle
 from cleora_amd import _hip, sharded
+from tests import sharded_model as model
 from tests.graphs import random_csr
 
 
@@ -114,18 +115,18 @@ def _worker(rank, world, port, steps, q, balance="rows"):
         n, d = 1001, 24  # n deliberately not a multiple of world*steps*4
         rowptr, col, vl, vs = random_csr(n, 7, seed=3, empty_frac=0.05, hubs=[(5, 300)])
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.kind == "u" else a)
-        sg = sharded.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
+        sg = model.ShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
                                   torch.from_numpy(vs), rank, world, steps, OracleBackend(), balance=balance)
         x0 = np.zeros((sg.n_pad, d), np.float32)
         x0[:n] = np.random.default_rng(9).standard_normal((n, d)).astype(np.float32)
         res = {}
         for kind, rw, thr in ((0, 0.0, 0.0), (1, 0.4, 0.0), (0, 0.0, 2e-3)):
-            x, ran = sharded.embed_sharded(sg, kind, torch.from_numpy(x0.copy()), 12, rw, thr)
+            x, ran = model.embed_sharded(sg, kind, torch.from_numpy(x0.copy()), 12, rw, thr)
             res[(kind, rw, thr)] = (x[:n].numpy().copy(), ran, float(x[n:].abs().max()) if sg.n_pad > n else 0.0)
         # the default embed() loop: reorganised form (Cholesky intermediate whitenings, SpMM before the projection) and
         # the reference's order, without and with the residual blend
         for tag, mode, rw in (("whiten", True, 0.0), ("whiten_seq", "sequential", 0.0), ("whiten_rw", True, 0.3)):
-            xw, _ = sharded.embed_sharded(sg, 0, torch.from_numpy(x0.copy()), 3, rw, whiten=mode)
+            xw, _ = model.embed_sharded(sg, 0, torch.from_numpy(x0.copy()), 3, rw, whiten=mode)
             res[tag] = xw[:n].numpy().copy()
         q.put((rank, sg.bounds, sg.n_pad, sg.local_nnz, res))
     finally:
@@ -183,7 +184,7 @@ def test_world2_matches_single_process(steps, balance, world):
 
 def test_block_size_alignment():
     for n, w, s in ((10, 1, 1), (1001, 2, 3), (9_999_997, 8, 4), (5, 8, 4)):
-        b = sharded.block_size(n, w, s)
+        b = model.block_size(n, w, s)
         assert b % 4 == 0 and b * w * s >= n and (b - 4) * w * s < n or b == 4
 
 

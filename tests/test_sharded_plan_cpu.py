@@ -1,7 +1,7 @@
 """CPU: the host-side arithmetic of the row-partitioned loops under the C ABI (csrc/sharded.hip) — no GPU needed.
 
   * cleora_sharded_plan, the row boundaries of the world * steps blocks, against the Python model of the same partition
-    (cleora_amd.sharded.row_bounds, the one the world-2 / world-4 gloo tests run against the oracle): identical boundaries,
+    (cleora_amd.model.row_bounds, the one the world-2 / world-4 gloo tests run against the oracle): identical boundaries,
     padded size and mode for permuted ids (equal rows), degree-ordered ids (balanced on the rowptr prefix sum), tiny graphs,
     empty graphs, more blocks than rows;
   * the memory plan of cleora_embed_sharded (missing #5): BASELINE config 4 with the DEFAULT (whitened) loop on
@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from cleora_amd import _hip, sharded
+from tests import sharded_model as model
 
 
 def _rowptr(deg):
@@ -38,7 +39,7 @@ def test_plan_equals_the_python_model(world, steps, kind, balance):
         deg[1234] = 400_000
     rp = _rowptr(deg)
     n = len(deg)
-    want_bounds, want_pad, want_mode = sharded.row_bounds(n, torch.from_numpy(rp.view(np.int64)), world, steps, balance)
+    want_bounds, want_pad, want_mode = model.row_bounds(n, torch.from_numpy(rp.view(np.int64)), world, steps, balance)
     got_bounds, got_pad, got_mode = sharded.plan_rows(n, rp, world, steps, balance)
     assert got_bounds == [int(b) for b in want_bounds]
     assert (got_pad, got_mode) == (want_pad, want_mode)

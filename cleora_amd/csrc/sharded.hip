@@ -21,7 +21,7 @@
 // range of blocks [k*P, (k+1)*P) IN PLACE on the communication stream while the SpMM of step k+1 runs.
 // Memory plan of the whitened loop (missing #5): TWO full replicas (the caller's, which holds E_0 and is
 // recycled as soon as Y_0 exists, and one more) + Z for the rank's OWN rows only + the whitening workspace — at BASELINE
-// config 4 on 8 GPUs (n = 111 M, d = 256): 2 x 113.7 GB + 14.2 GB + 3.3 GB of CSR = 245 GB of the 288 GB
+// config 4 on 8 GPUs (n = 111 M, d = 256): 2 x 113.7 GB + 14.2 GB + ~6.6 GB of CSR (with the gather policy's private col) = ~248 GB of the 288 GB
 // (cleora_embed_sharded_bytes; tests/test_sharded_plan_cpu.py holds the arithmetic).
 #include <algorithm>
 #include <chrono>

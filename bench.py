@@ -376,6 +376,40 @@ class Launcher:
         return float(t)
 
 
+def register_replicas(comm, *bufs):
+    """Both replicas of the iterate mapped by every rank for the peer-direct all-gather (collective).  On a LOCAL communicator that
+    transport is all there is: a failure ends the run.  On an RCCL communicator it is the optional third algorithm: if the
+    mapping fails on this node (the C side fails on every rank together, csrc/peer.hip exchange_and_map) the algorithm leaves the
+    pick and RCCL's two remain."""
+    if not isinstance(comm, comm_mod.RcclComm) or not (comm.local or getattr(comm, "peer_enabled", False)):
+        return
+    err, done = "", []
+    try:
+        for b in bufs:
+            comm.register(b)
+            done.append(b)
+    except Exception as e:                        # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    if comm.local:
+        if err:
+            raise SystemExit(f"bench.py: the peer-direct transport could not map a replica ({err}); nothing was measured")
+        return
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) != 1:
+        for b in done:
+            comm.unregister(b)
+        comm.peer_enabled = False
+        comm.peer_note = err[:200] or "the mapping failed on another rank"
+        print(f"bench.py: peer-direct all-gather excluded: {comm.peer_note}", file=sys.stderr, flush=True)
+
+
+def unregister_replicas(comm, *bufs):
+    if isinstance(comm, comm_mod.RcclComm):
+        for b in bufs:
+            comm.unregister(b)                    # a no-op for a buffer that was never registered
+
+
 def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=950_000, d=64, column=True):
     """N > 1, before anything big is built: ONE iteration (SpMM + L2 norm) of every partition on a 100k-row power-law graph,
     compared on every rank with the same iteration computed by that rank alone through the single-GPU path.  The row
@@ -398,8 +432,7 @@ def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=
     xr = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
     xr[:n] = x
     yr = torch.zeros_like(xr)
-    comm.register(xr)
-    comm.register(yr)
+    register_replicas(comm, xr, yr)
     out["row_max_abs_diff"], out["row_bit_equal"], algos = 0.0, True, [_hip.ALLGATHER_PEER] if comm.local else [_hip.ALLGATHER_RING, _hip.ALLGATHER_P2P]
     if not comm.local and getattr(comm, "peer_enabled", False):
         algos.append(_hip.ALLGATHER_PEER)
@@ -425,8 +458,7 @@ def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=
         out["row_max_abs_diff"] = max(out["row_max_abs_diff"], diff)
         out["row_bit_equal"] = out["row_bit_equal"] and equal
     comm.set_allgather(algos[0])
-    comm.unregister(xr)
-    comm.unregister(yr)
+    unregister_replicas(comm, xr, yr)
     sg.close()
     if column and d % (4 * world) == 0:
         cg = sharded.ColumnShardedGraph(n, g["rowptr"], g["col"], g["val_left"], None, d, rank, world, backend, comm=comm, steps=2)
@@ -575,8 +607,7 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         x_next.zero_()
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
         if ccomm is not None:
-            ccomm.register(x)                          # peer-direct all-gather: both replicas mapped by every rank (a no-op without it)
-            ccomm.register(x_next)
+            register_replicas(ccomm, x, x_next)        # peer-direct all-gather: both replicas mapped by every rank
         dl = d
         par = (f"row-block-cyclic x{world} ({sg.balance}-balanced), {steps_per_iter} block(s)/rank/iter, csrc/sharded.hip through the C ABI"
                + (", in-place all-gather of X (C ABI) overlapped with the next block" if world > 1 else ""))
@@ -614,6 +645,8 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         candidates = [("peer_direct", _hip.ALLGATHER_PEER)] if comm.local else [("rccl_allgather", _hip.ALLGATHER_RING), ("p2p_mesh", _hip.ALLGATHER_P2P)]
         if not comm.local and getattr(comm, "peer_enabled", False):
             candidates.append(("peer_direct", _hip.ALLGATHER_PEER))
+        if getattr(comm, "peer_note", None):
+            extra["peer_direct_excluded"] = comm.peer_note
         tried = {}
         for name, algo in candidates:
             comm.set_allgather(algo)
@@ -975,8 +1008,7 @@ def main():
             if part == "row" and args.whiten_iters > 0 and sg.embed_bytes(d, _hip.F_WHITEN) + 3 * sg.n_pad * d * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.9:
                 # the DEFAULT loop over the partition, one call: cleora_embed_sharded + CLEORA_F_WHITEN (wall clock incl. the final PCA whitening).
                 # An extra beside the headline: a failure here is reported in the line, it does not cost the measurement above.
-                comm.unregister(a)
-                comm.unregister(b)
+                unregister_replicas(comm, a, b)
                 err = ""
                 try:
                     _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
@@ -1002,9 +1034,8 @@ def main():
                                                 "projection and gather block by block) was never tuned on multi-GPU hardware",
                                         "device_bytes_beside_the_callers_replica": sg.embed_bytes(d, _hip.F_WHITEN),
                                         "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
-            elif part == "row" and isinstance(comm, comm_mod.RcclComm):
-                comm.unregister(a)
-                comm.unregister(b)
+            elif part == "row":
+                unregister_replicas(comm, a, b)
             if sg is not None:
                 sg.close()
             del a, b, iterate, blocks, sg

@@ -562,7 +562,9 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
         cleora_comm *c; void *a, *b; bool on = false;
         ~Registered() { if (on) { (void)cleora_comm_unregister(c, a); (void)cleora_comm_unregister(c, b); } }
     } reg{s->comm, x_replica, other.p};
-    if (s->comm && s->world > 1) {
+    // (only where the gathers will use it: an RCCL communicator whose algorithm is one of RCCL's needs no mapping, and a node
+    // where the mapping fails must not lose RCCL's loops with it)
+    if (s->comm && s->world > 1 && (s->comm->allgather_algo == CLEORA_ALLGATHER_PEER || !s->comm->comm)) {
         if ((rc = cleora_comm_register(s->comm, x_replica, replica_bytes)) != CLEORA_OK) return rc;
         if ((rc = cleora_comm_register(s->comm, other.p, replica_bytes)) != CLEORA_OK) { (void)cleora_comm_unregister(s->comm, x_replica); return rc; }
         reg.on = true;

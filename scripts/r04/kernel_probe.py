@@ -51,4 +51,22 @@ out["project_scale_only_ms"] = timed(lambda: _hip.check(L.cleora_project_general
 x2 = torch.roll(x, 1, 0)
 out["project_loop_form_blend_ms"] = timed(lambda: _hip.check(L.cleora_project_general_dev(x.data_ptr(), d, n, d, mean32.data_ptr(), t.data_ptr(), d, y.data_ptr(), d,
                                                                                           rs.data_ptr(), x2.data_ptr(), d, 0.8, 0.2, 1, ctypes.byref(done), s)))
+# the wide launch (128-row tiles) against a narrow one (64-row tiles, one barrier per k-step) on the same rows: bit for bit;
+# and against an f64 product
+m = 8192
+for label, scale, norm in (("plain", None, 0), ("loop_form", rs, 1)):
+    _hip.check(L.cleora_project_general_dev(x.data_ptr(), d, n, d, mean32.data_ptr(), t.data_ptr(), d, y.data_ptr(), d,
+                                            scale.data_ptr() if scale is not None else None, None, 0, 1.0, 0.0, norm, ctypes.byref(done), s))
+    small = torch.empty((m, d), device=dev)
+    eq = True
+    for r0 in (0, (n // 2) // 128 * 128, n - m):
+        _hip.check(L.cleora_project_general_dev(x[r0:].data_ptr(), d, m, d, mean32.data_ptr(), t.data_ptr(), d, small.data_ptr(), d,
+                                                scale[r0:].data_ptr() if scale is not None else None, None, 0, 1.0, 0.0, norm, ctypes.byref(done), s))
+        torch.cuda.synchronize()
+        eq = eq and bool(torch.equal(small, y[r0:r0 + m]))
+    out[f"project_{label}_wide_bit_equal_to_narrow"] = eq
+    want = (x[:m].double() - mean32.double()) @ t.double()
+    if norm:
+        want = want / want.norm(dim=1, keepdim=True)
+    out[f"project_{label}_max_err_vs_f64"] = float((y[:m].double() - want).abs().max() / want.abs().max())
 print(json.dumps(out), flush=True)

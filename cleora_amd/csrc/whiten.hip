@@ -932,22 +932,16 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
 // three fragments in LDS (af[(g + 1) & 1][row group]: 3 KiB), both read them after the step's barrier.  Same values, same
 // order of operations: results are bit-identical to the round-3 kernel.  RING counts a wave's OWN k-steps in flight (every second).
 // PAR = wc ^ (row group >> 1), so that the two waves of a SIMD (w and w + 4) produce in opposite steps.
-// KB = k-steps per barrier (1 or 2).  With one barrier per k-step all eight waves of a CU leave it together, read their fifteen
-// fragments together and issue their MFMAs together: the LDS port and the matrix pipe take turns instead of overlapping.  KB = 2
-// (128-row tiles only: four stages of B and of the A fragments, 144 KiB) keeps two k-steps between barriers — the fragments of
-// the second are read under the MFMAs of the first, and the two waves of a SIMD drift apart inside the longer interval.  What is
-// made during a barrier interval (the B stage, the A fragments) is for k-steps KB ahead.
-template <bool SCALED, bool BLEND, int RING, int U, int RG, int PAR, int KB>
+template <bool SCALED, bool BLEND, int RING, int U, int RG, int PAR>
 __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x4 *__restrict__ tp, uint32_t ksteps, uint64_t tiles,
                                                    unsigned char *smem) {
     static_assert(U % 2 == 0 && (U / 2) % RING == 0, "ring slots must be compile-time functions of the unrolled step");
-    static_assert((KB == 1 || KB == 2) && U % (2 * KB) == 0, "stage slots must be compile-time functions of the unrolled step");
     constexpr int T = RG * 128;            // threads
     constexpr int NB = SKB / T;            // 16-byte units of a B stage per thread (6 or 3)
     constexpr int SRT = RG * 32;           // rows per block tile
-    u32x4 *const bs = reinterpret_cast<u32x4 *>(smem);                           // [2 KB][SKB]
-    u32x4 *const af = bs + 2 * KB * SKB;                                         // [2 KB][RG][3][64]: the A fragments of a k-step
-    float *const mean_s = reinterpret_cast<float *>(af + 2 * KB * RG * 3 * 64);  // [16 ksteps]
+    u32x4 *const bs = reinterpret_cast<u32x4 *>(smem);                           // [2][SKB]
+    u32x4 *const af = bs + 2 * SKB;                                              // [2][RG][3][64]: the A fragments of a k-step
+    float *const mean_s = reinterpret_cast<float *>(af + 2 * RG * 3 * 64);       // [16 ksteps]
     float *const red = mean_s + 16 * ksteps;                                     // [2 RG waves][32 rows]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1, i = lane & 31, h = lane >> 5;
@@ -958,9 +952,9 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
     if (total == 0) return;
 
     for (uint32_t c = t; c < 16 * ksteps; c += T) mean_s[c] = c < a.d ? a.mean[c] : 0.f;
-    // B of the first KB steps straight into their slots
+    // B of step 0 straight into buffer 0
 #pragma unroll
-    for (int u = 0; u < KB * NB; ++u) bs[t + T * u] = tpp[t + T * u];
+    for (int u = 0; u < NB; ++u) bs[t + T * u] = tpp[t + T * u];
 
     // ---- operand ring: A of this wave's next RING own k-steps (k-steps PAR, PAR + 2, ...) -------------------------------------
     float4 ra[RING][2], rb[BLEND ? RING : 1][2];
@@ -1008,9 +1002,9 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
             as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
         }
     };
-    auto publish = [&](int slot, const u32x4 (&as)[3]) {
+    auto publish = [&](int buf, const u32x4 (&as)[3]) {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) af[((slot * RG + wr) * 3 + sp) * 64 + lane] = as[sp];
+        for (int sp = 0; sp < 3; ++sp) af[((buf * RG + wr) * 3 + sp) * 64 + lane] = as[sp];
     };
 #pragma unroll
     for (int slot = 0; slot < RING; ++slot) issue_a(slot);                       // own k-steps PAR, PAR + 2, ...
@@ -1022,11 +1016,10 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
         for (int r = 0; r < 16; ++r) acc[jj][r] = 0.f;
 
     __syncthreads();                                                             // mean_s is in place
-    if constexpr (PAR < KB) {                                                    // the fragments of k-step PAR (< KB): this wave's first own k-step
+    if constexpr (PAR == 0) {                                                    // the fragments of k-step 0
         u32x4 first[3];
-        split_a(0, PAR, first);
-        publish(PAR, first);
-        if constexpr ((KB & 1) == PAR) issue_a(0);                               // step 0 of the loop splits again instead of refilling: refill here
+        split_a(0, 0, first);
+        publish(0, first);
     }
     __syncthreads();
     uint64_t tile = blockIdx.x;
@@ -1036,30 +1029,28 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
         for (int uu = 0; uu < U; ++uu) {
             constexpr int kRing = RING;
             const uint32_t ks = ks0 + uu;
-            constexpr int kKb = KB;
-            const int cur = ((uu / kKb) & 1) * kKb + uu % kKb;    // the slot of this k-step; U is a multiple of 2 KB
-            const int nxt = cur ^ kKb;                                      // the slot of k-step g + KB
-            const bool produce = ((uu + kKb) & 1) == PAR;                   // this wave makes the fragments of k-step g + KB
-            // B of k-step g + KB: coalesced 16-byte loads, written to its slot at the end of the step
-            const uint32_t ksn = ks + kKb >= ksteps ? ks + kKb - ksteps : ks + kKb;
+            const int buf = uu & 1;                                              // U is even
+            const bool produce = ((uu + 1) & 1) == PAR;                          // this wave makes the fragments of k-step g + 1
+            // B of the next k-step: six coalesced 16-byte loads per thread, written to the other buffer at the end
+            const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
             u32x4 bst[NB];
 #pragma unroll
             for (int u = 0; u < NB; ++u) bst[u] = tpp[(uint64_t)ksn * SKB + t + T * u];
             // a step in which this wave does not produce refills the slot it emptied in the previous step (or the prologue), right
             // behind the B loads: the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in
             // order); they are split three steps from now
-            if (!produce) issue_a(((uu - 1 + kKb - PAR) / 2) % kRing);
+            if (!produce) issue_a(((uu - PAR) / 2) % kRing);
 
             // A fragments of this k-step (made by this wave or its partner during the previous step), B fragments of this wave's
             // four tiles, all three splits
             u32x4 as_cur[3];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) as_cur[sp] = af[((cur * RG + wr) * 3 + sp) * 64 + lane];
+            for (int sp = 0; sp < 3; ++sp) as_cur[sp] = af[((buf * RG + wr) * 3 + sp) * 64 + lane];
             u32x4 bf[3][4];
 #pragma unroll
             for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bf[sp][jj] = bs[cur * SKB + (sp * 8 + wc * 4 + jj) * 64 + lane];
+                for (int jj = 0; jj < 4; ++jj) bf[sp][jj] = bs[buf * SKB + (sp * 8 + wc * 4 + jj) * 64 + lane];
             constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
             u32x4 as_next[3];
 #pragma unroll
@@ -1070,15 +1061,15 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
                                                                       __builtin_bit_cast(bf16x8, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
                 // the fragments of the NEXT k-step are made here, under this step's MFMAs (the matrix pipe runs them for
                 // 32 cycles each; the ~50 VALU instructions of centre + split issue in their shadow)
-                if (q == 0 && produce) split_a(((uu + kKb - PAR) / 2) % kRing, ksn, as_next);
+                if (q == 0 && produce) split_a(((uu + 1 - PAR) / 2) % kRing, ksn, as_next);
             }
-            if (produce) publish(nxt, as_next);
+            if (produce) publish(buf ^ 1, as_next);
 
             // B of the next k-step into the other buffer (nobody reads it during this step).  Before the tile epilogue, not
             // after: behind that branch the compiler cannot count the epilogue's stores and drains everything (vmcnt(0)),
             // the operand ring included, at the end of every RING-th step.
 #pragma unroll
-            for (int u = 0; u < NB; ++u) bs[nxt * SKB + t + T * u] = bst[u];
+            for (int u = 0; u < NB; ++u) bs[(buf ^ 1) * SKB + t + T * u] = bst[u];
 
             if (uu == U - 1 && ks0 + U == ksteps) {
                 // ---- end of a row tile: normalise (whole rows live in this block when there is one pass), store --------
@@ -1165,20 +1156,20 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
                 }
                 tile += gridDim.x;
             }
-            if (uu % kKb == kKb - 1) __syncthreads();
+            __syncthreads();
         }
         ks0 = ks0 + U == ksteps ? 0 : ks0 + U;
     }
 }
 
-template <bool SCALED, bool BLEND, int RING, int U, int RG = 2, int KB = 1>
+template <bool SCALED, bool BLEND, int RING, int U, int RG = 2>
 __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
                                                                                    uint32_t ksteps, uint64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // whole waves take each arm; every arm meets the same barriers
-    if ((((w >> 1) >> 1) ^ w) & 1) project_split_body<SCALED, BLEND, RING, U, RG, 1, KB>(a, tp, ksteps, tiles, smem);
-    else project_split_body<SCALED, BLEND, RING, U, RG, 0, KB>(a, tp, ksteps, tiles, smem);
+    if ((((w >> 1) >> 1) ^ w) & 1) project_split_body<SCALED, BLEND, RING, U, RG, 1>(a, tp, ksteps, tiles, smem);
+    else project_split_body<SCALED, BLEND, RING, U, RG, 0>(a, tp, ksteps, tiles, smem);
 }
 
 }  // namespace
@@ -1339,12 +1330,9 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     // split-bf16 form: any d that is a multiple of 32 whose mean fits the block's LDS beside the two B stages, any k.
     // Everything else (d % 32 != 0, unaligned rows, d beyond ~28k) takes the tiled f32-MFMA kernel below.
     const uint32_t ksteps = d / 16, passes = (k + SN - 1) / SN;
-    // two B stages, the A fragments of two k-steps for up to four row groups, the mean, the row-norm partials; twice the stages
-    // and fragments in the two-k-steps-per-barrier form of the 128-row tile
-    const size_t lds_rest = (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
-    const size_t lds_one = (size_t)2 * SKB * 16 + (size_t)2 * 4 * 3 * 1024 + lds_rest;
-    const size_t lds_two = (size_t)4 * SKB * 16 + (size_t)4 * 4 * 3 * 1024 + lds_rest;
-    if (a.w4x && d % 32 == 0 && lds_one <= 160 * 1024) {
+    // two B stages, the A fragments of two k-steps for up to four row groups, the mean, the row-norm partials
+    const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)2 * 4 * 3 * 1024 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
+    if (a.w4x && d % 32 == 0 && lds_bytes <= 160 * 1024) {
         const uint64_t units = (uint64_t)passes * ksteps * SKB;
         u32x4 *tp = nullptr;
         CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
@@ -1372,23 +1360,13 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
             constexpr int RG = decltype(RGt)::value;
             // the mean of a wide row pushes the block past the 64 KiB a kernel gets without asking (d >= 3872): raise the limit for
             // the instantiation being launched — per DEVICE and cheap, so on every call
-#define CLEORA_SPLIT_LAUNCH_KB(RING, UU, KB, LDS)                                                                                      \
-            do {                                                                                                                       \
-                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(project_split_kernel<SC, BL, RING, UU, RG, KB>),        \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS));                               \
-                if (attr_err == hipSuccess)                                                                                            \
-                    hipLaunchKernelGGL((project_split_kernel<SC, BL, RING, UU, RG, KB>), grid, dim3(RG * 128), (LDS), stream, a, tp,   \
-                                       ksteps, tiles);                                                                                 \
-            } while (0)
-            // two k-steps per barrier where the block has the CU's LDS to itself (RG = 4), the unrolled trip holds whole pairs of
-            // stages (UU % 4 == 0) and the mean still fits beside the four stages (d <= 3776); not with the blended second operand
-            // (its ring slots are twice as wide: the form spills)
 #define CLEORA_SPLIT_LAUNCH(RING, UU)                                                                                                  \
             do {                                                                                                                       \
-                if constexpr (RG == 4 && !BL && (UU) % 4 == 0) {                                                                       \
-                    if (lds_two <= 160 * 1024) { CLEORA_SPLIT_LAUNCH_KB(RING, UU, 2, lds_two); break; }                                \
-                }                                                                                                                      \
-                CLEORA_SPLIT_LAUNCH_KB(RING, UU, 1, lds_one);                                                                          \
+                attr_err = hipFuncSetAttribute(reinterpret_cast<const void *>(project_split_kernel<SC, BL, RING, UU, RG>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                           \
+                if (attr_err == hipSuccess)                                                                                            \
+                    hipLaunchKernelGGL((project_split_kernel<SC, BL, RING, UU, RG>), grid, dim3(RG * 128), lds_bytes, stream, a, tp,   \
+                                       ksteps, tiles);                                                                                 \
             } while (0)
             // RING = a wave's own k-steps in flight (every second k-step is its own): 2 = four k-steps ahead; the blended operand
             // doubles the registers of a slot: 1 there.  U / 2 must be a multiple of RING.
@@ -1399,7 +1377,6 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
             if (ksteps % 8 == 0) CLEORA_SPLIT_LAUNCH(1, 8);
             else CLEORA_SPLIT_LAUNCH(1, 2);
 #undef CLEORA_SPLIT_LAUNCH
-#undef CLEORA_SPLIT_LAUNCH_KB
         };
         auto launch_rg = [&](auto RGt) {
             if (blend) {

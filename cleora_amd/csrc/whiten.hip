@@ -416,6 +416,16 @@ __host__ __device__ constexpr bool g16_uses(int w, int blk) {
 template <int NS, int NCB>
 __device__ __forceinline__ uint32_t g16_slot(int ks, int s, int cbk, int lane) { return (uint32_t)((((ks * NS + s) * NCB + cbk) * 64 + lane) * 16); }
 
+// a wave-uniform address as an SGPR pair the compiler cannot fold back into per-lane 64-bit arithmetic: loads through it take
+// the "scalar base + 32-bit lane offset" form of global_load
+typedef const char __attribute__((address_space(1))) *gbytes;
+typedef const float __attribute__((address_space(1))) *gfloat;
+__device__ __forceinline__ float load_scalar_base(const float *row, uint32_t byte_offset) {
+    const uint64_t v = reinterpret_cast<uint64_t>(row);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return *reinterpret_cast<gfloat>(reinterpret_cast<gbytes>(((uint64_t)hi << 32) | lo) + byte_offset);
+}
+
 // one staging task: eight rows of one column -> centred, summed, split, NS 16-byte pieces into the stage.
 // Returns the octet's sum; LEAN: `resid2` += sum of r1^2 (the diagonal correction above).
 template <bool LEAN, int NCB>
@@ -454,6 +464,37 @@ constexpr f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 
 constexpr int G16_PA[6] = {0, 0, 1, 1, 0, 2}, G16_PB[6] = {0, 1, 0, 1, 2, 0};
 constexpr int G16_LA[3] = {0, 0, 1}, G16_LB[3] = {0, 1, 0};
 
+// acc += the sums of one staged 32-row stage over this wave's tiles of a diagonal block.
+// The bf16 MFMA does not round its f32 accumulation to nearest: a long chain of same-sign terms (the variances on the
+// diagonal) comes out LOW — -1.3e-6 relative after 2048 rows, uniformly (profiles/r03u_gram_error.txt), against -6e-9
+// for 32-row chains.  So the matrix cores only ever sum ONE stage (32 rows) from zero, and the
+// stage sums are added to the long accumulators by the vector unit (v_pk_add_f32: round to nearest even).
+template <int W, bool LEAN>
+__device__ __forceinline__ void g16_diag_stage_sums(const char *sb, f16v (&acc)[g16_ntiles(W)], int lane) {
+    constexpr int NT = g16_ntiles(W), NCB = 8, NS = LEAN ? 2 : 3, NP = LEAN ? 3 : 6;
+    f16v tmp[NT];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 f[8][NS];
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk)
+            if (g16_uses(W, blk)) {
+#pragma unroll
+                for (int sp = 0; sp < NS; ++sp) f[blk][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NS, NCB>(ks, sp, blk, lane));
+            }
+        // product-major: consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            const int pa = LEAN ? G16_LA[pr] : G16_PA[pr], pb = LEAN ? G16_LB[pr] : G16_PB[pr];
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+                tmp[q] = G16_MFMA(f[G16_TR[W][q]][pa], f[G16_TC[W][q]][pb], (ks == 0 && pr == 0) ? zero16 : tmp[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
+}
+
 template <int W, bool LEAN>
 __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds, uint32_t sup) {
     constexpr int NT = g16_ntiles(W), NCB = 8, NS = LEAN ? 2 : 3, NP = LEAN ? 3 : 6, STAGE = 2 * NS * NCB * 1024;
@@ -475,6 +516,22 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
     int nv0 = 0, nv1 = 0;
     auto prefetch = [&](uint64_t row0) {
         const uint64_t ra = row0 + 8 * O0, rb = row0 + 8 * O1;
+        if (row0 + G16_KR <= r_end) {
+            // a whole stage (all but the last of a slice): one scalar row base per octet, the eight rows by additions — the
+            // guarded form below spends a select and a 64-bit multiply on each of its sixteen loads (~185 scalar instructions
+            // per wave and stage, on the one scalar unit the CU's eight waves share)
+            // (scalar base + 32-bit byte offset of the lane's column: global_load with an SGPR base, no 64-bit vector arithmetic)
+            static_assert(O0 == O1, "the two tasks of a wave read the same rows");
+            nv0 = nv1 = 8;
+            const float *rowp = a.x + ra * a.ldx;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pre0[j] = load_scalar_base(rowp, 4u * col0);
+                pre1[j] = load_scalar_base(rowp, 4u * col1);
+                rowp += a.ldx;
+            }
+            return;
+        }
         nv0 = ra >= r_end ? 0 : (r_end - ra >= 8 ? 8 : (int)(r_end - ra));
         nv1 = rb >= r_end ? 0 : (r_end - rb >= 8 ? 8 : (int)(r_end - rb));
 #pragma unroll
@@ -501,42 +558,26 @@ __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds,
     __syncthreads();
     int buf = 0;
     uint32_t in_sub = 0;
-    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
+    // Waves w and w + 4 share a SIMD and leave every barrier together.  If both staged first and multiplied second, the SIMD's
+    // vector unit would serve two staging phases (~110 instructions each) while its matrix pipe idles, then the matrix pipe two
+    // MFMA phases while the vector unit idles.  So the lower four waves stage the next rows BEFORE their MFMAs and the upper four
+    // AFTER: between two barriers every wave still does both, but a SIMD's two waves are in opposite phases.
+    constexpr bool STAGE_FIRST = W < 4;
+    auto stage_next = [&](uint64_t row0, int b) {
         if (row0 + G16_KR < r_end) {
-            stage(buf ^ 1);
+            stage(b ^ 1);
             if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
         }
-        const char *sb = lds + buf * STAGE;
-        // The bf16 MFMA does not round its f32 accumulation to nearest: a long chain of same-sign terms (the variances on the
-        // diagonal) comes out LOW — -1.3e-6 relative after 2048 rows, uniformly (profiles/r03u_gram_error.txt), against -6e-9
-        // for 32-row chains.  So the matrix cores only ever sum ONE stage (32 rows) from zero, and the
-        // stage sums are added to the long accumulators by the vector unit (v_pk_add_f32: round to nearest even).
-        f16v tmp[NT];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 f[8][NS];
-#pragma unroll
-            for (int blk = 0; blk < 8; ++blk)
-                if (g16_uses(W, blk)) {
-#pragma unroll
-                    for (int sp = 0; sp < NS; ++sp) f[blk][sp] = *reinterpret_cast<const bf16x8 *>(sb + g16_slot<NS, NCB>(ks, sp, blk, lane));
-                }
-            // product-major: consecutive MFMAs go to different accumulators
-#pragma unroll
-            for (int pr = 0; pr < NP; ++pr) {
-                const int pa = LEAN ? G16_LA[pr] : G16_PA[pr], pb = LEAN ? G16_LB[pr] : G16_PB[pr];
-#pragma unroll
-                for (int q = 0; q < NT; ++q)
-                    tmp[q] = G16_MFMA(f[G16_TR[W][q]][pa], f[G16_TC[W][q]][pb], (ks == 0 && pr == 0) ? zero16 : tmp[q]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NT; ++q) acc[q] += tmp[q];
+    };
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
+        if constexpr (STAGE_FIRST) stage_next(row0, buf);
+        g16_diag_stage_sums<W, LEAN>(lds + buf * STAGE, acc, lane);
         in_sub += G16_KR;
         if (in_sub >= a.sub_rows || row0 + G16_KR >= r_end) {
             gram32_fold<NT>(out, acc, i, h, false, tile_index);
             in_sub = 0;
         }
+        if constexpr (!STAGE_FIRST) stage_next(row0, buf);
         __syncthreads();
     }
 
@@ -590,6 +631,19 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
     float pre[3][8];
     int nv[3] = {0, 0, 0};
     auto prefetch = [&](uint64_t row0) {
+        if (row0 + G16_KR <= r_end) {                        // a whole stage: see gram16_diag_body
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                nv[u] = 8;
+                const float *rowp = a.x + (row0 + 8 * oct[u]) * a.ldx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pre[u][j] = load_scalar_base(rowp, 4u * col[u]);
+                    rowp += a.ldx;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const uint64_t r0 = row0 + 8 * oct[u];
@@ -616,11 +670,15 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
     __syncthreads();
     int buf = 0;
     uint32_t in_sub = 0;
-    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
+    constexpr bool STAGE_FIRST = W < 4;                      // opposite phases for the two waves of a SIMD (see gram16_diag_body)
+    auto stage_next = [&](uint64_t row0, int b) {
         if (row0 + G16_KR < r_end) {
-            stage(buf ^ 1);
+            stage(b ^ 1);
             if (row0 + 2 * G16_KR < r_end) prefetch(row0 + 2 * G16_KR);
         }
+    };
+    for (uint64_t row0 = r_begin; row0 < r_end; row0 += G16_KR, buf ^= 1) {
+        if constexpr (STAGE_FIRST) stage_next(row0, buf);
         const char *sb = lds + buf * STAGE;
         f16v tmp[NT];                                        // one stage's sums (see gram16_diag_body)
 #pragma unroll
@@ -646,6 +704,7 @@ __device__ __forceinline__ void gram16_off_body(const Gram32Args &a, char *lds, 
             gram32_fold<NT>(out, acc, i, h, false, tile_index);
             in_sub = 0;
         }
+        if constexpr (!STAGE_FIRST) stage_next(row0, buf);
         __syncthreads();
     }
 }

@@ -497,7 +497,7 @@ __device__ __forceinline__ void g16_diag_stage_sums(const char *sb, f16v (&acc)[
 
 template <int W, bool LEAN>
 __device__ __forceinline__ void gram16_diag_body(const Gram32Args &a, char *lds, uint32_t sup) {
-    constexpr int NT = g16_ntiles(W), NCB = 8, NS = LEAN ? 2 : 3, NP = LEAN ? 3 : 6, STAGE = 2 * NS * NCB * 1024;
+    constexpr int NT = g16_ntiles(W), NCB = 8, NS = LEAN ? 2 : 3, STAGE = 2 * NS * NCB * 1024;
     const int t = threadIdx.x, lane = t & 63, i = lane & 31, h = lane >> 5;
     const uint64_t r_begin = (uint64_t)blockIdx.y * a.rows_per_slice;
     const uint64_t r_end = r_begin + a.rows_per_slice < a.n ? r_begin + a.rows_per_slice : a.n;

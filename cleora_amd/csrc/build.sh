@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-ma
 mkdir -p obj
 pids=()
 for f in spmm rowops whiten eigh hot attention comm peer sharded stager similarity abi; do
-  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ project_common.h -nt obj/$f.o ] || [ row_epilogue.h -nt obj/$f.o ] || [ comm_internal.h -nt obj/$f.o ] || [ ../../include/cleora_hip.h -nt obj/$f.o ]; then
+  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ project_common.h -nt obj/$f.o ] || [ row_epilogue.h -nt obj/$f.o ] || [ comm_internal.h -nt obj/$f.o ] || [ shm_barrier.h -nt obj/$f.o ] || [ ../../include/cleora_hip.h -nt obj/$f.o ]; then
     # whiten.hip: MFMA accumulators in the VGPR form — hipcc otherwise parks loop-carried accumulators in VGPRs and copies
     # them to AGPRs and back around every chunk of MFMAs (256 v_accvgpr moves per 64 MFMAs in the Gram kernel)
     extra=""; [ $f = whiten ] && extra="-mllvm -amdgpu-mfma-vgpr-form"

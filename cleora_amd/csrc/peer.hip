@@ -37,6 +37,7 @@
 #include <string>
 
 #include "comm_internal.h"
+#include "shm_barrier.h"
 
 namespace cleora {
 
@@ -54,7 +55,8 @@ struct ShmRecord {                            // what a rank publishes for one e
 static_assert(sizeof(ShmRecord) == 128, "record size");
 
 struct ShmSegment {
-    std::atomic<uint32_t> count, sense, failed;
+    ShmBarrier barrier;
+    std::atomic<uint32_t> failed;
     uint32_t world;
     ShmRecord rec[kMaxWorld];
 };
@@ -104,23 +106,9 @@ uint64_t fnv1a(const unsigned char *p, size_t n) {
 
 int barrier_host(cleora_comm *c) {
     PeerLayer *pl = c->peer;
-    ShmSegment *s = pl->shm;
-    const uint32_t my = pl->local_sense ^= 1u;
-    if (s->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->world) {
-        s->count.store(0, std::memory_order_relaxed);
-        s->sense.store(my, std::memory_order_release);
-        return CLEORA_OK;
-    }
-    const auto t0 = std::chrono::steady_clock::now();
-    unsigned spins = 0;
-    while (s->sense.load(std::memory_order_acquire) != my) {
-        if (++spins > 200) { sched_yield(); }
-        if ((spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kHostBarrierSeconds) {
-            set_error("peer transport: a rank did not reach the host barrier within " + std::to_string((int)kHostBarrierSeconds) + " s");
-            return CLEORA_E_RCCL;
-        }
-    }
-    return CLEORA_OK;
+    if (shm_barrier_wait(&pl->shm->barrier, (uint32_t)c->world, &pl->local_sense, kHostBarrierSeconds)) return CLEORA_OK;
+    set_error("peer transport: a rank did not reach the host barrier within " + std::to_string((int)kHostBarrierSeconds) + " s");
+    return CLEORA_E_RCCL;
 }
 
 void close_registration(PeerLayer *pl, Registration &r, int world);

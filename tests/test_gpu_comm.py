@@ -131,9 +131,9 @@ def test_two_ranks_sharing_the_gpu_over_gloo():
     procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(world)]
+    got = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     n, d = 4003, 64
     rowptr, col, vl, vs = random_csr(n, 8, seed=61, empty_frac=0.04, hubs=[(9, 1500)])
@@ -192,9 +192,9 @@ def test_two_gpus_over_rccl_equal_the_single_gpu_result():
     procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=300) for _ in range(world))
+    got = dict(q.get(timeout=900) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     n, d = 20011, 256
     rowptr, col, vl, vs = random_csr(n, 10, seed=71, empty_frac=0.02, hubs=[(5, 3000)])

@@ -155,12 +155,12 @@ def test_ranks_sharing_the_gpu_over_the_local_communicator(world):
     try:
         got = {}
         for _ in range(world):
-            rank, out, err = q.get(timeout=420)
+            rank, out, err = q.get(timeout=900)
             assert err is None, f"rank {rank}: {err}"
             got[rank] = out
     finally:
         for p in procs:
-            p.join(timeout=30)
+            p.join(timeout=120)
             if p.is_alive():
                 p.kill()
     # ---- collectives

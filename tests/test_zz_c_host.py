@@ -189,7 +189,7 @@ def test_c_host_row_partitioned_loop_two_gpus(tmp_path):
     procs = [subprocess.Popen([SHARDED, str(r), "2", str(tmp_path / "id"), "complex::reflexive::n", "64", "6", str(out), str(edges)],
                               env=env, stderr=subprocess.PIPE, text=True) for r in range(2)]
     for p in procs:
-        _, err = p.communicate(timeout=240)
+        _, err = p.communicate(timeout=900)
         assert p.returncode == 0, err
     ids, got = read_tsv(out)
     assert ids == g.entity_ids

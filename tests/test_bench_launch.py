@@ -59,3 +59,56 @@ def test_a_world_size_that_contradicts_gpus_is_refused():
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr
+
+
+def _fake_comm(local, fail_on=None):
+    """A communicator object with the attributes bench.register_replicas looks at, and register / unregister that record the calls
+    (no library, no GPU): register raises on the `fail_on`-th buffer, like the C side does on every rank together."""
+    from cleora_amd import comm as comm_mod
+
+    class Fake(comm_mod.RcclComm):
+        def __init__(self):                                    # no handle: nothing of the C ABI is touched
+            self.local, self.peer_enabled, self.calls, self.handle = local, True, [], None
+
+        def register(self, t):
+            if fail_on is not None and len([c for c in self.calls if c[0] == "register"]) == fail_on:
+                self.calls.append(("register-failed", t))
+                raise RuntimeError("hipIpcOpenMemHandle of rank 1's buffer failed")
+            self.calls.append(("register", t))
+
+        def unregister(self, t):
+            self.calls.append(("unregister", t))
+
+    return Fake()
+
+
+def test_a_failed_peer_mapping_costs_the_algorithm_not_the_run():
+    """bench.register_replicas (the one path of the multi-GPU bench that only a node without peer access can reach): on an RCCL
+    communicator a failed mapping of the replicas drops the peer-direct all-gather from the pick — the buffers that were mapped
+    are unmapped again, every rank agrees through the launcher's group — and RCCL's two algorithms remain; on a LOCAL
+    communicator the same failure ends the run.  World of one over gloo, fake communicator objects."""
+    import importlib.util
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    port = 29600 + os.getpid() % 300
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ok = _fake_comm(local=False)
+        bench.register_replicas(ok, "x", "y")
+        assert ok.calls == [("register", "x"), ("register", "y")] and ok.peer_enabled
+        bad = _fake_comm(local=False, fail_on=1)
+        bench.register_replicas(bad, "x", "y")
+        assert bad.calls == [("register", "x"), ("register-failed", "y"), ("unregister", "x")]
+        assert not bad.peer_enabled and "hipIpcOpenMemHandle" in bad.peer_note
+        bench.register_replicas(bad, "x", "y")                 # excluded: nothing is attempted again
+        assert len(bad.calls) == 3
+        bench.unregister_replicas(bad, "x", "y")               # harmless for buffers that were never mapped
+        assert bad.calls[3:] == [("unregister", "x"), ("unregister", "y")]
+        fatal = _fake_comm(local=True, fail_on=0)
+        with pytest.raises(SystemExit) as e:
+            bench.register_replicas(fatal, "x", "y")
+        assert "nothing was measured" in str(e.value)
+    finally:
+        dist.destroy_process_group()

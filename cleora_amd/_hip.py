@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcleora_hip.so")
 OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE, E_RCCL = 0, -1, -2, -3, -4, -5
 LEFT, SYMMETRIC = 0, 1
 F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
-F_L1NORM, F_BLEND_ANY, F_SQDIFF64 = 128, 256, 512
+F_L1NORM, F_BLEND_ANY, F_SQDIFF64, F_HUB_SEGMENTS = 128, 256, 512, 1024
 ABI_VERSION = 3
 COMM_ID_BYTES = 128
 ALLGATHER_RING, ALLGATHER_P2P, ALLGATHER_PEER = 0, 1, 2

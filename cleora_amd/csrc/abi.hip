@@ -72,6 +72,15 @@ int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
         }
     }
     hub_seg_first.push_back(seg_row.size());
+    // longest row first for the in-order launch (ties by row id: deterministic)
+    std::vector<uint32_t> hub_by_len(hub_rows.size());
+    for (size_t i = 0; i < hub_by_len.size(); ++i) hub_by_len[i] = (uint32_t)i;
+    auto len_of = [&](uint32_t h) { return rowptr_host[hub_rows[h] + 1] - rowptr_host[hub_rows[h]]; };
+    std::sort(hub_by_len.begin(), hub_by_len.end(), [&](uint32_t x, uint32_t y) {
+        const uint64_t lx = len_of(x), ly = len_of(y);
+        return lx != ly ? lx > ly : x < y;
+    });
+    g->hub_inorder_ok = hub_by_len.empty() || len_of(hub_by_len[0]) < (1ull << 30) - 4096;
     g->n_hub_rows = hub_rows.size();
     g->n_hub_segments = seg_row.size();
     if (g->n_hub_rows == 0) return CLEORA_OK;
@@ -84,6 +93,7 @@ int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
     };
     int rc;
     if ((rc = up(&g->hub_rows, hub_rows)) != CLEORA_OK) return rc;
+    if ((rc = up(&g->hub_by_len, hub_by_len)) != CLEORA_OK) return rc;
     if ((rc = up(&g->hub_seg_first, hub_seg_first)) != CLEORA_OK) return rc;
     if ((rc = up(&g->seg_row, seg_row)) != CLEORA_OK) return rc;
     if ((rc = up(&g->seg_begin, seg_begin)) != CLEORA_OK) return rc;
@@ -141,6 +151,13 @@ void free_graph(cleora_graph *g) {
         (void)hipFree(const_cast<float *>(g->val[1]));
     }
     (void)hipFree(g->hub_rows);
+    (void)hipFree(g->hub_by_len);
+    if (g->hub_stream) {
+        (void)hipStreamSynchronize(g->hub_stream);
+        (void)hipStreamDestroy(g->hub_stream);
+        (void)hipEventDestroy(g->hub_fork);
+        (void)hipEventDestroy(g->hub_join);
+    }
     (void)hipFree(g->hub_seg_first);
     (void)hipFree(g->seg_row);
     (void)hipFree(g->seg_begin);

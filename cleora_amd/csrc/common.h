@@ -62,9 +62,14 @@ struct cleora_graph {
     uint64_t *hub_seg_first = nullptr;  // [n_hub_rows + 1]   first segment of each hub row
     uint32_t *seg_row = nullptr;        // [n_hub_segments]   row id of the segment
     uint64_t *seg_begin = nullptr;      // [n_hub_segments]   first edge of the segment
+    // the in-order hub launch (spmm.hip hub_inorder_kernel): hub indices longest row first, side stream + fork / join events
+    uint32_t *hub_by_len = nullptr;     // [n_hub_rows]
+    bool hub_inorder_ok = true;         // false: some row is too long for the kernel's 32-bit (col, val) offsets
+    mutable hipStream_t hub_stream = nullptr;
+    mutable hipEvent_t hub_fork = nullptr, hub_join = nullptr;
     uint64_t device_bytes = 0;
 
-    // scratch for the hub partial sums, sized for the largest d seen so far
+    // scratch for the hub rows' sums (in-order: one row each; segmented: one per segment), sized for the largest d seen so far
     mutable std::mutex mu;
     mutable float *hub_partial = nullptr;
     mutable uint64_t hub_partial_elems = 0;

@@ -15,10 +15,16 @@
 //   * edges are consumed in stored order with separate f32 multiply and add
 //     (-ffp-contract=off + __fmul_rn/__fadd_rn), so every row that is not split is
 //     bit-identical to the reference's sequential accumulate (src/embedding.rs:80-82).
-//   * rows longer than hub_threshold are split into hub_segment-edge segments that are the
-//     FIRST work items of the same launch (longest work first), each on its own wavefront,
-//     and are combined in a fixed order by hub_finish_kernel: deterministic, but not the
-//     reference's summation order.
+//   * rows longer than hub_threshold (hub rows) are summed IN THE REFERENCE'S ORDER too, by
+//     hub_inorder_kernel on a side stream beside the main launch: one wavefront per (hub row,
+//     64-column slab), four edges per 16-byte load instruction (a lane quad per edge), 48 loads =
+//     192 edges in flight per wavefront, the running sum handed from quad to quad with a DPP row
+//     rotate so that every output element sees `acc += w * x` edge by edge, like
+//     src/embedding.rs:76-83.  hub_epilogue_kernel then runs the row epilogue on the whole row.
+//   * with CLEORA_F_HUB_SEGMENTS the hub rows are instead cut into hub_segment-edge segments that
+//     are the FIRST work items of the main launch, each on its own wavefront, and combined in a
+//     fixed order by hub_finish_kernel: deterministic and immune to a pathological hub (a chain
+//     of 10^8 dependent adds), but not the reference's summation order.
 //   * the epilogue (residual blend, L2 normalise, squared difference) runs on the
 //     accumulator registers, so Y is written exactly once and never re-read.
 #include "common.h"
@@ -48,6 +54,10 @@ struct SpmmArgs {
     const uint32_t *hub_rows;
     const uint64_t *hub_seg_first;
     float *partial;
+    // in-order hub kernel
+    const uint32_t *hub_by_len;   // hub indices, longest row first
+    uint64_t nnz;
+    uint32_t n_slabs;             // 64-column slabs per row
     RowArgs r;
 };
 
@@ -254,6 +264,154 @@ __global__ __launch_bounds__(256) void hub_finish_kernel(const SpmmArgs a) {
     finish_row<G, V, W, false>(a.r, row, gl, gbase, acc);
 }
 
+// ---- hub rows in the reference's order ---------------------------------------------------------
+// src/embedding.rs:76-83 adds a row's edges into ONE accumulator in stored order.  Every output element's chain is
+// independent of the others, so a hub row can be cut by COLUMN without touching the order: one wavefront per (hub row,
+// 64-column slab).  What a single in-order consumer lacks is memory parallelism, so the loads are decoupled from the adds:
+//   * a ring of R 16-byte loads per lane stays in flight (R = 48: 48 KiB per wavefront, the vmcnt counter's reach); the
+//     ring is refilled for step j + R right after step j's registers are read;
+//   * QUAD form (16-byte-aligned rows): one load instruction covers FOUR edges — lane = (DPP row rho, quad q, i) reads
+//     columns [64 slab + 16 rho + 4 i, +4) of edge 4 j + q — and the running sum travels through the quads:
+//     round g computes acc = fadd(row_ror:4(acc), w * x) in all lanes, of which quad g's is the true prefix sum after
+//     edge 4 j + g (the other quads' values are never used), so after four rounds quad 3 holds the sum through edge
+//     4 j + 3 and row_ror:4 hands it to quad 0 of the next step.  20 VALU instructions per 4 edges;
+//   * LANE form (any alignment / width): a lane owns one column, one edge per step, no cross-lane traffic;
+//   * the row's (col, val) slice streams through LDS in chunks of R steps, fetched two chunks ahead with bounds-checked
+//     buffer loads (ordinary loads would sit in the same in-order vmcnt queue as the ring and drain it), read back with
+//     one ds_read per step at a compile-time offset.
+// The last step of a row runs only its valid rounds (the padding lanes hold the next row's edges).
+template <int R, bool QUAD>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hub_inorder_kernel(const SpmmArgs a) {
+    constexpr int EPS = QUAD ? 4 : 1;             // edges per step
+    constexpr int CH = R * EPS;                   // edges per chunk
+    constexpr int FE = CH > 64 ? 4 : 1;           // (col, val) entries fetched per lane and chunk: one dword or one dwordx4
+    static_assert(64 * FE >= CH, "a chunk is one fetch instruction per stream");
+    __shared__ __attribute__((aligned(16))) uint32_t s_col[2][64 * FE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_val[2][64 * FE];
+    const int lane = threadIdx.x;
+    const int q = QUAD ? (lane >> 2) & 3 : 0;
+    const uint64_t item = CLEORA_LINEAR_BLOCK();
+    const uint32_t k = (uint32_t)(item / a.n_slabs), slab = (uint32_t)(item - (uint64_t)k * a.n_slabs);
+    const uint32_t h = a.hub_by_len[k];
+    const uint64_t row = a.hub_rows[h];
+    const uint64_t beg = a.rowptr[row], n = a.rowptr[row + 1] - beg;
+    const uint32_t d = a.r.d;
+    const uint32_t coff = QUAD ? slab * 64u + (uint32_t)(lane >> 4) * 16u + (uint32_t)(lane & 3) * 4u : slab * 64u + (uint32_t)lane;
+    const bool in_range = coff < d;
+    const float *xb = a.x + (in_range ? coff : 0u);
+
+    const uint64_t left_bytes = (a.nnz - beg) * 4u;
+    const int records = (int)(left_bytes > 0xfffffffcull ? 0xfffffffcu : (uint32_t)left_bytes);
+    const auto rs_col = __builtin_amdgcn_make_buffer_rsrc((void *)(a.col + beg), 0, records, 0x00020000);
+    const auto rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)(a.val + beg), 0, records, 0x00020000);
+    // entries past the row's end are the next rows' (valid gather addresses, never consumed) or, past the array, zero
+    u32x4 pc, pv;
+    auto fetch = [&](uint64_t chunk) {
+        const int off = (int)(uint32_t)((chunk * CH + (uint64_t)lane * FE) * 4u);
+        if constexpr (FE == 4) {
+            pc = __builtin_amdgcn_raw_buffer_load_b128(rs_col, off, 0, 0);
+            pv = __builtin_amdgcn_raw_buffer_load_b128(rs_val, off, 0, 0);
+        } else {
+            pc.x = __builtin_amdgcn_raw_buffer_load_b32(rs_col, off, 0, 0);
+            pv.x = __builtin_amdgcn_raw_buffer_load_b32(rs_val, off, 0, 0);
+        }
+    };
+    auto stash = [&](int slot) {
+        if constexpr (FE == 4) {
+            *reinterpret_cast<u32x4 *>(&s_col[slot][4 * lane]) = pc;
+            *reinterpret_cast<u32x4 *>(&s_val[slot][4 * lane]) = pv;
+        } else {
+            s_col[slot][lane] = pc.x;
+            s_val[slot][lane] = pv.x;
+        }
+    };
+    using Vec = std::conditional_t<QUAD, float4, float>;
+    const uint32_t ldx32 = (uint32_t)a.ldx;     // < 2^32 (checked by the launcher): one v_mad_u64_u32 per address
+    auto gather = [&](uint32_t c) -> Vec { return *reinterpret_cast<const Vec *>(xb + (uint64_t)c * ldx32); };
+
+    fetch(0); stash(0);
+    fetch(1); stash(1);
+    fetch(2);
+    Vec ring[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) ring[s] = gather(s_col[0][EPS * s + q]);
+
+    float acc[EPS];
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) acc[e] = 0.f;
+    // One chunk: R steps.  WHOLE: all CH edges belong to the row (no tests); else `left` < CH of them do.
+    auto chunk_body = [&](auto whole, int cur, uint32_t left) {
+        constexpr bool WHOLE = decltype(whole)::value;
+        const int nxt = cur ^ 1;
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const float w = __uint_as_float(s_val[cur][EPS * s + q]);
+            const uint32_t cn = s_col[nxt][EPS * s + q];
+            if constexpr (QUAD) {
+                // the products first, THEN the refill of the same ring slot (step s of the next chunk): the old and the new
+                // value never live together, so the slot keeps its registers around the loop (no copies at the back edge,
+                // which would wait for the loads)
+                float t0 = fmul(w, ring[s].x), t1 = fmul(w, ring[s].y), t2 = fmul(w, ring[s].z), t3 = fmul(w, ring[s].w);
+                if constexpr (WHOLE) ring[s] = gather(cn);
+                // one round: acc = row_ror:4(acc) + t in every lane.  Written as asm so that all rounds are the 1-instruction
+                // DPP add (the compiler turns the last round of a step into v_mov_dpp x4 + v_pk_add x2).  A DPP read needs 2 wait
+                // states after a VALU write of its source: inside a round the four chains interleave; the s_nop covers a copy
+                // or product the compiler schedules right in front of the block (it does not look for hazards inside asm —
+                // without it the first chain read stale sums in the tail chunk).
+#define CLEORA_HUB_ROUND                                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                                      \
+                 "v_add_f32_dpp %0, %0, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "v_add_f32_dpp %1, %1, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "v_add_f32_dpp %2, %2, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
+                 "v_add_f32_dpp %3, %3, %7 row_ror:4 row_mask:0xf bank_mask:0xf"                                      \
+                 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                            \
+                 : "v"(t0), "v"(t1), "v"(t2), "v"(t3))
+                if (WHOLE || left >= (uint32_t)(4 * s + 4)) {
+                    CLEORA_HUB_ROUND; CLEORA_HUB_ROUND; CLEORA_HUB_ROUND; CLEORA_HUB_ROUND;
+                } else if (left > (uint32_t)(4 * s)) {
+                    const uint32_t m = left - 4 * s;   // 1..3 edges in the row's last step
+                    CLEORA_HUB_ROUND;
+                    if (m > 1) { CLEORA_HUB_ROUND; }
+                    if (m > 2) { CLEORA_HUB_ROUND; }
+                }
+#undef CLEORA_HUB_ROUND
+            } else {
+                const float t = fmul(w, ring[s]);
+                if constexpr (WHOLE) ring[s] = gather(cn);
+                if (WHOLE || left > (uint32_t)s) acc[0] = fadd(acc[0], t);
+            }
+        }
+    };
+    const uint64_t whole_chunks = n / CH;
+    for (uint64_t c = 0; c < whole_chunks; ++c) {
+        const int cur = (int)(c & 1);
+        chunk_body(std::true_type{}, cur, 0u);
+        stash(cur);        // chunk c + 2, in flight since the start of chunk c
+        fetch(c + 3);
+    }
+    const uint32_t tail = (uint32_t)(n - whole_chunks * CH);
+    if (tail) chunk_body(std::false_type{}, (int)(whole_chunks & 1), tail);
+    float *p = a.partial + (uint64_t)h * d + coff;
+    if constexpr (QUAD) {
+        if (in_range && (uint32_t)q == (uint32_t)((n - 1) & 3)) *reinterpret_cast<float4 *>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+        if (in_range) *p = acc[0];
+    }
+}
+
+// The row epilogue of the in-order hub rows: one lane group per hub row reads the complete sums back.
+template <int G, int V, int W>
+__global__ __launch_bounds__(256) void hub_epilogue_kernel(const SpmmArgs a, uint64_t n_hub_rows) {
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    const uint64_t h = (uint64_t)blockIdx.x * (256 / G) + (threadIdx.x / G);
+    if (h >= n_hub_rows) return;
+    float acc[V][W];
+    load_row<G, V, W, false>(a.partial + h * (uint64_t)a.r.d, gl, a.r.d, acc);
+    finish_row<G, V, W, false>(a.r, a.hub_rows[h], gl, gbase, acc);
+}
+
 // ---- stand-alone row epilogue (l2_normalize_inplace & friends) --------------------------
 template <int G, int V, int W>
 __global__ __launch_bounds__(256) void rowops_kernel(const float *x, uint64_t ldx, uint64_t n,
@@ -419,8 +577,8 @@ inline dim3 grid_for(uint64_t items, int per_block) {
 
 // Scratch for the hub-segment partial sums, grown when a wider d arrives: stream-ordered (the old block is released
 // behind the launches that still use it), so a `*_dev` call stays enqueue-only.
-int ensure_partial(const cleora_graph *g, uint32_t d, hipStream_t stream) {
-    const uint64_t need = g->n_hub_segments * (uint64_t)d;
+int ensure_partial(const cleora_graph *g, uint32_t d, bool segmented, hipStream_t stream) {
+    const uint64_t need = (segmented ? g->n_hub_segments : g->n_hub_rows) * (uint64_t)d;
     if (need <= g->hub_partial_elems) return CLEORA_OK;
     if (g->hub_partial) CL_HIP(hipFreeAsync(g->hub_partial, stream));
     g->hub_partial = nullptr;
@@ -447,15 +605,46 @@ inline void mark(const cleora_graph *g, hipStream_t stream) {
     if (hipEvent_t e = take_event(g)) (void)hipEventRecord(e, stream);
 }
 
+// Side stream (highest priority) and the fork / join events of the in-order hub launch, created on first use.
+int ensure_hub_stream(const cleora_graph *g) {
+    if (g->hub_stream) return CLEORA_OK;
+    int lo = 0, hi = 0;
+    CL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CL_HIP(hipStreamCreateWithPriority(&g->hub_stream, hipStreamNonBlocking, hi));
+    CL_HIP(hipEventCreateWithFlags(&g->hub_fork, hipEventDisableTiming));
+    CL_HIP(hipEventCreateWithFlags(&g->hub_join, hipEventDisableTiming));
+    return CLEORA_OK;
+}
+
 // One SpMM over a column panel that fits the register-resident shapes.
-int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stream) {
+int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, hipStream_t stream) {
     const uint32_t d = a.r.d;
     bool ok = true;
+    const bool inorder = g->n_hub_rows && !segmented;
     mark(g, stream);
-    mark(g, stream);  // (slot kept: hub partials used to be a launch of their own)
-    a.n_segments = g->n_hub_segments;
-    a.n_items = g->n_hub_segments + g->n_rows;
-    if (a.n_items) {
+    if (inorder) {
+        // the hub rows, longest first, on the side stream beside the main launch (src/embedding.rs:76-83's order)
+        const int rc = ensure_hub_stream(g);
+        if (rc != CLEORA_OK) return rc;
+        CL_HIP(hipEventRecord(g->hub_fork, stream));
+        CL_HIP(hipStreamWaitEvent(g->hub_stream, g->hub_fork, 0));
+        a.hub_by_len = g->hub_by_len;
+        a.nnz = g->nnz;
+        a.n_slabs = (d + 63) / 64;
+        const dim3 grid = grid_1d_as_2d(g->n_hub_rows * (uint64_t)a.n_slabs);
+        if (w4) hipLaunchKernelGGL((hub_inorder_kernel<48, true>), grid, dim3(64), 0, g->hub_stream, a);
+        else hipLaunchKernelGGL((hub_inorder_kernel<64, false>), grid, dim3(64), 0, g->hub_stream, a);
+        ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
+            constexpr int kG = decltype(G)::value;
+            hipLaunchKernelGGL((hub_epilogue_kernel<kG, decltype(V)::value, decltype(W)::value>),
+                               grid_for(g->n_hub_rows, 256 / kG), dim3(256), 0, g->hub_stream, a, g->n_hub_rows);
+        });
+        CL_HIP(hipEventRecord(g->hub_join, g->hub_stream));
+    }
+    mark(g, stream);
+    a.n_segments = inorder ? 0 : g->n_hub_segments;
+    a.n_items = a.n_segments + g->n_rows;
+    if (ok && a.n_items) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
             constexpr int kG = decltype(G)::value, kV = decltype(V)::value, kW = decltype(W)::value;
             constexpr bool kFull = decltype(FULL)::value != 0;
@@ -476,7 +665,9 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, hipStream_t stre
         });
     }
     mark(g, stream);
-    if (ok && g->n_hub_rows) {
+    if (inorder) {
+        CL_HIP(hipStreamWaitEvent(stream, g->hub_join, 0));
+    } else if (ok && g->n_hub_rows) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
             hipLaunchKernelGGL((hub_finish_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
                                dim3((unsigned)g->n_hub_rows), dim3(256), 0, stream, a);
@@ -516,8 +707,12 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
 
     std::lock_guard<std::mutex> lock(g->mu);
     CL_HIP(hipSetDevice(g->device));
-    if (g->n_hub_segments) {
-        const int rc = ensure_partial(g, d, stream);
+    // hub rows: the reference's order unless the caller asks for the segmented sum (or a row is too long for the
+    // 32-bit offsets of the in-order kernel's (col, val) stream)
+    const bool segmented = (flags & CLEORA_F_HUB_SEGMENTS) || !g->hub_inorder_ok || ldx >= (1ull << 32);
+    flags &= ~CLEORA_F_HUB_SEGMENTS;
+    if (g->n_hub_rows) {
+        const int rc = ensure_partial(g, d, segmented, stream);
         if (rc != CLEORA_OK) return rc;
     }
 
@@ -548,7 +743,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
 
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
                     (!x_self || aligned16(x_self));
-    if (d <= (w4 ? kMaxD4 : kMaxD1)) return propagate_panel(g, a, w4, stream);
+    if (d <= (w4 ? kMaxD4 : kMaxD1)) return propagate_panel(g, a, w4, segmented, stream);
 
     // Wider rows: SpMM column panel by column panel without the epilogue, then the wide row pass.
     const uint32_t panel = w4 ? kMaxD4 : kMaxD1;
@@ -558,7 +753,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
         p.r.y = y + c0;
         p.r.d = (d - c0) < panel ? (d - c0) : panel;
         p.r.flags = 0;
-        const int rc = propagate_panel(g, p, w4, stream);
+        const int rc = propagate_panel(g, p, w4, segmented, stream);
         if (rc != CLEORA_OK) return rc;
     }
     if (flags & (CLEORA_F_L2NORM | CLEORA_F_L1NORM | CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF | CLEORA_F_ROWSQ | CLEORA_F_SCALE))

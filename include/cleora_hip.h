@@ -65,6 +65,11 @@ extern "C" {
                                  without it the blend is gated on 0 < rw < 1 like the Rust loop (src/embedding.rs:116) */
 #define CLEORA_F_SQDIFF64 512u /* with SQDIFF: delta = (double)y - (double)x_self, like _compute_rmse (pycleora/__init__.py:974-976);
                                  without it delta is the f32 difference like src/embedding.rs:172 */
+#define CLEORA_F_HUB_SEGMENTS 1024u /* rows longer than hub_threshold: sum hub_segment-edge segments on separate wavefronts and add the
+                                     * partial sums in a fixed order, instead of the default — every row, hub rows included, added
+                                     * edge by edge in stored order like src/embedding.rs:76-83 (bit-equal to the reference).  For a
+                                     * pathological hub (10^7+ edges in one row: an in-order chain of as many dependent adds) this
+                                     * is the faster form; its hub rows differ from the reference by rounding (<= 2e-6 * sum|terms|) */
 
 typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct SparseMatrix, src/sparse_matrix.rs:56-78) */
 

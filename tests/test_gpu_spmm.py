@@ -1,8 +1,8 @@
 """GPU parity: SpMM + fused epilogue through the C ABI vs the CPU oracle.
 
-Bit-exact (assert_array_equal) wherever rows are not split: the kernel consumes each row's
-edges in stored order with separate f32 multiply/add exactly as src/embedding.rs:80-82.
-Hub rows (split across waves) are compared with a relative tolerance of 2e-6 * sum|terms|.
+Bit-exact (assert_array_equal) for every row: the kernels consume each row's edges in stored order with
+separate f32 multiply/add exactly as src/embedding.rs:80-82 — hub rows included (hub_inorder_kernel).  Only with
+CLEORA_F_HUB_SEGMENTS are hub rows summed in segments; those are compared with a tolerance of 2e-6 * sum|terms|.
 """
 import ctypes
 
@@ -93,17 +93,69 @@ def test_residual_and_sqdiff():
         np.testing.assert_array_equal(got, oracle.l2_normalize(y))
 
 
+@pytest.mark.parametrize("d", [256, 64, 1024, 100, 30, 7, 1280, 4096])
+def test_hub_rows_in_reference_order(d):
+    """Rows longer than hub_threshold are added edge by edge like every other row (src/embedding.rs:76-83): bit-equal to the
+    oracle, for the 16-byte-aligned quad form (d % 4 == 0), the lane form (any d), partial last slabs, panels (d > 2048),
+    row lengths around the chunk (192 / 64 edges) and step (4 edges) boundaries."""
+    n = 4000
+    hubs = [(17, 5000), (1234, 1025), (3999, 20000), (2000, 1024),            # 1024 = threshold: not a hub row
+            (5, 1026), (6, 1027), (7, 1028), (8, 1152), (9, 1153), (10, 1151), (11, 1343), (12, 1344), (13, 1345), (14, 1088)]
+    rowptr, col, vl, _ = random_csr(n, 8, seed=11, hubs=hubs)
+    x = np.random.default_rng(12).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl)
+    info = g.info()
+    assert info.n_hub_rows == len(hubs) - 1 and info.hub_threshold == 1024
+    want = oracle.spmm(rowptr, col, vl, x)
+    got = run_dev(g, _hip.LEFT, x)
+    np.testing.assert_array_equal(got, want)
+    # with the epilogue (exact-order L2 norm over the whole row, residual blend, squared difference)
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
+    np.testing.assert_array_equal(got, oracle.l2_normalize(want))
+    rw = np.float32(0.25)
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM | _hip.F_RESIDUAL, rw=float(rw))
+    np.testing.assert_array_equal(got, oracle.l2_normalize((np.float32(1.0) - rw) * want + rw * x))
+    # every row a hub row, chunk tails of every length
+    g2 = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=4, hub_segment=16)
+    np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
+
+
+def test_hub_rows_signed_zero_and_specials():
+    """The last step of a hub row adds only its real edges (the padding lanes hold the NEXT row's edges), and NaN / inf /
+    denormal / signed-zero terms travel through the DPP chain like through the reference's scalar loop."""
+    n, d = 64, 64
+    lens = [9, 10, 11, 12, 193, 194, 195, 196, 385]
+    rowptr = np.zeros(n + 1, np.uint64)
+    rowptr[1:len(lens) + 1] = np.cumsum(lens)
+    rowptr[len(lens) + 1:] = rowptr[len(lens)]
+    nnz = int(rowptr[-1])
+    rng = np.random.default_rng(5)
+    col = rng.integers(0, n, nnz).astype(np.uint32)
+    vl = rng.standard_normal(nnz).astype(np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x[:, 0] = -0.0                      # every product is +-0: the sum keeps -0 only if nothing else is added
+    vl_pos = np.abs(vl)
+    x[:, 1] = np.float32(1e-41)         # denormal terms
+    x[3, 2] = np.inf
+    x[4, 3] = np.nan
+    g = _hip.Graph.from_host(rowptr, col, vl_pos, hub_threshold=4, hub_segment=16)
+    want = oracle.spmm(rowptr, col, vl_pos, x)
+    got = run_dev(g, _hip.LEFT, x)
+    np.testing.assert_array_equal(got.view(np.uint32)[:, :3], want.view(np.uint32)[:, :3])     # bit patterns: signs of zero, denormals, inf
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_array_equal(got[~np.isnan(want)], want[~np.isnan(want)])
+
+
 @pytest.mark.parametrize("d", [256, 64, 1024])
-def test_hub_rows_split(d):
+def test_hub_rows_segmented(d):
+    """CLEORA_F_HUB_SEGMENTS: hub rows as 256-edge segment sums added in a fixed order — same terms, another order."""
     n = 4000
     hubs = [(17, 5000), (1234, 1025), (3999, 20000), (2000, 1024)]  # 1024 = threshold: not split
     rowptr, col, vl, _ = random_csr(n, 8, seed=11, hubs=hubs)
     x = np.random.default_rng(12).standard_normal((n, d)).astype(np.float32)
     g = _hip.Graph.from_host(rowptr, col, vl)
-    info = g.info()
-    assert info.n_hub_rows == 3 and info.hub_threshold == 1024
     want = oracle.spmm(rowptr, col, vl, x)
-    got = run_dev(g, _hip.LEFT, x)
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_HUB_SEGMENTS)
     hub_rows = np.array([17, 1234, 3999])
     mask = np.ones(n, bool)
     mask[hub_rows] = False
@@ -113,11 +165,13 @@ def test_hub_rows_split(d):
     bound = oracle.spmm(rowptr, col, np.abs(vl), absx)[hub_rows]
     assert np.all(np.abs(got[hub_rows] - want[hub_rows]) <= 2e-6 * bound + 1e-30)
     # with the epilogue
-    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
+    got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM | _hip.F_HUB_SEGMENTS)
     np.testing.assert_allclose(got, oracle.l2_normalize(want), rtol=0, atol=2e-6)
-    # custom thresholds: everything split at 16 edges/segment still agrees
+    # custom thresholds: everything split at 16 edges/segment still agrees; the two forms can alternate on one handle
     g2 = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=4, hub_segment=16)
-    np.testing.assert_allclose(run_dev(g2, _hip.LEFT, x), want, rtol=0, atol=1e-4 * np.abs(want).max())
+    np.testing.assert_allclose(run_dev(g2, _hip.LEFT, x, flags=_hip.F_HUB_SEGMENTS), want, rtol=0, atol=1e-4 * np.abs(want).max())
+    np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
+    np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x), want)
 
 
 def test_row_shard_rectangular():

@@ -72,11 +72,21 @@ def kernel_source_stamp():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0):
+def rows_bit_equal(dev, host, chunk=1 << 20):
+    """Number of rows of the device matrix whose bits equal the host matrix's."""
+    same = 0
+    for r0 in range(0, host.shape[0], chunk):
+        got = dev[r0:r0 + chunk].cpu().numpy()
+        same += int((got.view(np.uint32) == host[r0:r0 + chunk].view(np.uint32)).all(axis=1).sum())
+    return same
+
+
+def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, gpu_iterate=None, budget_s=12.0):
     """Reference-order CPU port (oracle AoS SpMM + separate L2 pass, all host cores) on whole iterations of the
     same graph and X, bounded to about `budget_s` seconds; its FIRST iteration doubles as the parity check:
-    y_dev is the GPU's iteration from the same x_dev — every non-hub row must be bit-equal (hub rows are summed
-    in segment order on the GPU: tolerance)."""
+    y_dev is the GPU's iteration from the same x_dev — EVERY row must be bit-equal, hub rows included (they are added in
+    the reference's order by hub_inorder_kernel).  gpu_iterate(k): the GPU continues k iterations from y_dev and returns
+    the iterate — compared with the oracle's after the same number of iterations."""
     import oracle
     rowptr = g["rowptr"].cpu().numpy().astype(np.uint64)
     edges = np.empty(g["nnz"], dtype=oracle.EDGE_DTYPE)
@@ -89,32 +99,16 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
     oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)  # page-touch + pool spin-up; also the check
     deg = np.diff(rowptr.astype(np.int64))
     hub = deg > hub_threshold
-    equal_rows, hub_max, hub_worst, chunk = 0, 0.0, -1, 1 << 20
+    equal_rows, hub_equal, chunk = 0, 0, 1 << 20
     for r0 in range(0, n, chunk):
         r1 = min(n, r0 + chunk)
         got = y_dev[r0:r1].cpu().numpy()
         same = (got.view(np.uint32) == y[r0:r1].view(np.uint32)).all(axis=1)
-        h = hub[r0:r1]
-        equal_rows += int(same[~h].sum())
-        if h.any():
-            diff = np.abs(got[h] - y[r0:r1][h]).max(axis=1)
-            if float(diff.max()) >= hub_max:
-                hub_max, hub_worst = float(diff.max()), r0 + int(np.flatnonzero(h)[int(diff.argmax())])
-    checks = {"oracle_rows_compared": int(n), "oracle_nonhub_rows": int((~hub).sum()),
-              "oracle_rows_bit_equal": equal_rows, "hub_rows": int(hub.sum()),
-              "hub_max_abs_diff_unit_rows": hub_max}
-    if hub_worst >= 0:
-        # the worst split row in the units of the tests' bound: |delta| of the un-normalised sum relative to
-        # sum|terms| (both summation orders — the reference's sequential one too — are within ~n*eps of the exact sum)
-        b0, e0 = int(rowptr[hub_worst]), int(rowptr[hub_worst + 1])
-        terms = edges["left"][b0:e0, None].astype(np.float64) * x[edges["col"][b0:e0]].astype(np.float64)
-        exact = terms.sum(axis=0)
-        got = y_dev[hub_worst].cpu().numpy().astype(np.float64) * np.linalg.norm(exact)
-        ref = y[hub_worst].astype(np.float64) * np.linalg.norm(exact)
-        sabs = np.abs(terms).sum(axis=0)
-        checks.update({"hub_worst_row_edges": e0 - b0,
-                       "hub_worst_gpu_vs_exact_rel_sum_abs_terms": float((np.abs(got - exact) / sabs).max()),
-                       "hub_worst_oracle_vs_exact_rel_sum_abs_terms": float((np.abs(ref - exact) / sabs).max())})
+        equal_rows += int(same.sum())
+        hub_equal += int(same[hub[r0:r1]].sum())
+    checks = {"oracle_rows_compared": int(n), "oracle_rows_bit_equal": equal_rows, "hub_rows": int(hub.sum()),
+              "hub_rows_bit_equal": hub_equal, "longest_row_edges": int(deg.max())}
+    x, y = y, x                                          # x = the oracle's iterate after 1 iteration
     count, t0 = 0, time.perf_counter()
     while True:
         oracle.spmm_aos_l2_inplace(rowptr, edges, False, x, y, threads)
@@ -123,6 +117,10 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
         el = time.perf_counter() - t0
         if el >= budget_s or count >= 5:
             break
+    if gpu_iterate is not None:
+        # the baseline's iterations double as a multi-iteration check: the GPU continues from its own first iterate
+        checks["oracle_iterations_compared"] = 1 + count
+        checks["rows_bit_equal_after_those_iterations"] = rows_bit_equal(gpu_iterate(count), x)
     out = {"value": g["nnz"] * d * count / el, "unit": "edge*dim/s", "cores": threads,
            "kind": "port", "iterations_per_sec": count / el,
            "sample": f"{count} full iteration(s) of the same graph and X (SpMM, reference AoS edge "
@@ -142,6 +140,42 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, budget_s=12.0)
     except Exception as ex:  # scipy is optional; the port above is the baseline
         out["scipy_single_thread"] = {"error": str(ex)}
     return out, checks
+
+
+def golden_loop_check(config, g, hashes, a, b, iterate, n, d, L):
+    """The plain loop from E_0 against the ORACLE's loop on the same workload, pinned as hashes of the iterate
+    (tests/golden/plain_loop_hashes_<config>.json, written by tests/golden/make_plain_loop_hashes.py: the oracle run once on the
+    GPU box, 40 iterations at C2 / C3).  Equal hashes = bit-equal iterates.  Measured live in this run; a workload the record
+    does not describe (other generator output, other d) is reported as such, never skipped silently."""
+    path = os.path.join(ROOT, "tests", "golden", f"plain_loop_hashes_{config}.json")
+    if not os.path.exists(path):
+        return {"error": f"no golden record tests/golden/plain_loop_hashes_{config}.json for this config"}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from make_plain_loop_hashes import graph_hash, hash_array
+        rec = json.load(open(path))
+        if (rec["n"], rec["nnz"], rec["d"]) != (n, g["nnz"], d) or rec["graph"] != graph_hash(g):
+            return {"error": "the golden record describes another graph (generator output differs): re-run tests/golden/make_plain_loop_hashes.py"}
+        stream = torch.cuda.current_stream().cuda_stream
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, a.data_ptr(), d, stream))
+        torch.cuda.synchronize()
+        if hash_array(a[:n]) != rec["x0"]:
+            return {"error": "E_0 differs from the golden record's"}
+        want = {int(k): v for k, v in rec["iterations"].items()}
+        at = [k for k in (1, 10, max(want)) if k in want]
+        out, p, q, done = {}, a, b, 0
+        for k in sorted(set(at)):
+            for _ in range(k - done):
+                iterate(p, q)
+                p, q = q, p
+            done = k
+            torch.cuda.synchronize()
+            out[str(k)] = hash_array(p[:n]) == want[k]
+        return {"source": f"tests/golden/plain_loop_hashes_{config}.json (oracle loop, {rec['oracle_threads']} host threads, {rec['oracle_seconds']} s; "
+                          f"{rec['hash']} of the iterate); the GPU side measured in this run",
+                "iterate_bit_equal_to_oracle_after_iterations": out, "all_equal": all(out.values())}
+    except Exception as ex:                                   # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
 def cpu_baseline_row_block(g, x_dev, n, d, rows=500_000, budget_s=20.0):
@@ -598,15 +632,15 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
             b0, b1 = sg.my_rows[k]
             r0, r1 = min(b0, n), min(b1, n)
             dk = deg[r0:r1]
-            # the launch gathers for ALL edges of the block (hub segments are its first work items)
-            # and writes every row except the hub rows (hub_finish_kernel writes those)
-            n_hub = int((dk > blocks[k].info().hub_threshold).sum())
-            launch_bytes.append(algorithmic_bytes(int(dk.sum()), (b1 - b0) - n_hub, b1 - b0, d))
+            # one SpMM = the main launch + the in-order hub launch beside it on the side stream (spmm.hip): together they gather
+            # for ALL edges of the block and write every row once; the time below is the span of the pair on the launch stream
+            launch_bytes.append(algorithmic_bytes(int(dk.sum()), b1 - b0, b1 - b0, d))
         x, x_next, placement = placed_pair(blocks[0], sg.n_pad, d, dev, args)
         x.zero_()
         x_next.zero_()
         _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, stream))
         if ccomm is not None:
+            torch.cuda.synchronize()                   # the zero fills must have RUN before a peer may store into the replicas
             register_replicas(ccomm, x, x_next)        # peer-direct all-gather: both replicas mapped by every rank
         dl = d
         par = (f"row-block-cyclic x{world} ({sg.balance}-balanced), {steps_per_iter} block(s)/rank/iter, csrc/sharded.hip through the C ABI"
@@ -620,8 +654,7 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
         blocks, dl = cg.blocks, cg.dl
         for blk, (r0, r1) in zip(cg.blocks, cg.row_blocks):
             dk = deg[r0:r1]
-            n_hub = int((dk > blk.info().hub_threshold).sum())
-            launch_bytes.append(algorithmic_bytes(int(dk.sum()), (r1 - r0) - n_hub, r1 - r0, dl))
+            launch_bytes.append(algorithmic_bytes(int(dk.sum()), r1 - r0, r1 - r0, dl))
         x, x_next, placement = placed_pair(blocks[0], n, dl, dev, args)
         rowsq = torch.zeros(n, dtype=torch.float32, device=dev)
         # columns [c0, c0 + dl) of the deterministic init: init_value depends on hash + col + seed only
@@ -717,7 +750,8 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     else:
         for blk in blocks:
             blk.set_timing(False)
-    avg_ms = rows_ms / max(calls, 1)
+    # span of one SpMM on the launch stream: [fork of the hub launch | main kernel | wait for the hub launch's epilogue]
+    avg_ms = (rows_ms + other_ms) / max(calls, 1)
     avg_bytes = sum(launch_bytes) / len(launch_bytes)
     achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     finite, sumsq = finite_and_row_sumsq(a, n)
@@ -727,8 +761,10 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     norm_err = float((sumsq.sqrt() - 1).abs().max())
     hot_rows = int(blocks[0].info().hot_rows)      # gather cache policy (cleora_graph_set_hot_cache), 0 = inactive
     g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
+    n_hub_rows = sum(int(blk.info().n_hub_rows) for blk in blocks)
     kernel_name = (f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true,{'true' if hot_rows else 'false'}>"
-                   f"  (G lanes per row, float4 chunks per lane, W, FULL, gather cache policy)")
+                   f"  (G lanes per row, float4 chunks per lane, W, FULL, gather cache policy)"
+                   + (f" + hub_inorder_kernel<48,true> beside it on a side stream ({n_hub_rows} hub rows x {(dl + 63) // 64} column slabs, reference order)" if n_hub_rows else ""))
     res = {
         "value": nnz * d * args.steps / elapsed, "iterations_per_sec": args.steps / elapsed,
         "ms_per_step": elapsed / args.steps * 1e3, "parallelism": par,
@@ -736,7 +772,10 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches": calls,
                      "gather_cache_policy_hot_rows": hot_rows,
-                     "hub_kernels_ms_per_launch": other_ms / max(calls, 1),
+                     "main_kernel_ms_per_launch": rows_ms / max(calls, 1),
+                     "fork_and_join_of_the_hub_launch_ms_per_launch": other_ms / max(calls, 1),
+                     "timing": "HIP events on the launch stream around [fork | main kernel | join]: the span of the main launch and the in-order hub launch "
+                               "(side stream) together; achieved = the gather model's bytes of ALL edges and rows / that span",
                      "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
                      # SURVEY.md §8(d) secondary model: every operand once (lower bound on traffic)
                      "compulsory_bytes_per_iteration": nnz * 8 + (n + 1) * 8 + 2 * n * d * 4},
@@ -1057,8 +1096,16 @@ def main():
                 r["checks"].update(sampled_row_check(g, a, b, n, d, blocks[0].info().hub_threshold))
                 cpu = cpu_baseline_row_block(g, a, n, d)
             else:
-                cpu, checks = cpu_baseline_and_checks(g, a, b, n, d, blocks[0].info().hub_threshold)
+                def gpu_more(k, a=a, b=b):
+                    p, q = b, a
+                    for _ in range(k):
+                        iterate(p, q)
+                        p, q = q, p
+                    torch.cuda.synchronize()
+                    return p
+                cpu, checks = cpu_baseline_and_checks(g, a, b, n, d, blocks[0].info().hub_threshold, gpu_more)
                 r["checks"].update(checks)
+                r["checks"]["plain_loop_vs_oracle_record"] = golden_loop_check(args.config, g, hashes, a, b, iterate, n, d, L)
         x_w = a
         sg.close()                                            # the rank's copy of the CSR
         del b, iterate, blocks, keep, sg
@@ -1092,25 +1139,22 @@ def main():
         if pt.get("untuned_launch_ms"):
             r["roofline"]["frac_untuned"] = r["roofline"]["algorithmic_bytes_per_launch"] / (pt["untuned_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
             r["roofline"]["frac_untuned_note"] = "one launch on the first allocation pair cleora_alloc_iterates drew (what a plain hipMalloc pair runs at)"
-        # end-to-end drift figures of the GPU suite (tests/test_gpu_parity_at_scale.py), quoted from the committed record
-        ppath = os.path.join(ROOT, "profiles", "r04_parity_at_scale.json")
-        if os.path.exists(ppath):
-            try:
-                pj = json.load(open(ppath))
-                drift = {"source": "profiles/r04_parity_at_scale.json (tests/test_gpu_parity_at_scale.py at BASELINE config 2's size; NOT measured in this run)"}
-                plain = pj.get("plain_loop_drift_c2", {}).get("compared_at_iterations", {})
-                if plain:
-                    last = str(max(int(k) for k in plain))
-                    drift["plain_loop_max_abs_diff_vs_oracle"] = {"iterations": int(last), "value": plain[last]["max_abs_diff"], "stated_tolerance": 5e-5}
-                dl = pj.get("default_loop_40_iterations_c2", {})
-                if dl:
-                    drift["default_loop_max_abs_cosine_diff_vs_reference_order"] = {k: v["max_abs_cosine_diff_2000_rows"] for k, v in dl.get("vs_reference_order_on_gpu", {}).items()}
-                    drift["default_loop_max_abs_cosine_diff_vs_oracle_loop"] = {"iterations": dl.get("vs_oracle_loop", {}).get("iterations"),
-                                                                                "value": dl.get("vs_oracle_loop", {}).get("max_abs_cosine_diff_2000_rows")}
-                    drift["default_loop_stated_tolerance"] = 1e-4
-                r["checks"]["drift_at_scale"] = drift
-            except Exception as ex:                           # noqa: BLE001
-                r["checks"]["drift_at_scale"] = {"error": f"unreadable profiles/r04_parity_at_scale.json: {ex}"}
+        # end-to-end figures of the GPU suite at config 2's size (tests/test_gpu_parity_at_scale.py), quoted from the committed record;
+        # a missing file or key is an error in the line, not an empty object (round 4 shipped one)
+        ppath = os.path.join(ROOT, "profiles", "r05_parity_at_scale.json")
+        try:
+            pj = json.load(open(ppath))
+            plain, dl = pj["plain_loop_c2"], pj["default_loop_40_iterations_c2"]
+            r["checks"]["drift_at_scale"] = {
+                "source": "profiles/r05_parity_at_scale.json (tests/test_gpu_parity_at_scale.py at BASELINE config 2's size; NOT measured in this run — "
+                          "this run's own multi-iteration checks are rows_bit_equal_after_those_iterations and plain_loop_vs_oracle_record)",
+                "plain_loop_bit_equal_to_oracle_through_iteration": plain["bit_equal_through_iteration"],
+                "plain_loop_with_CLEORA_F_HUB_SEGMENTS_max_abs_diff_after_10": plain["hub_segments_flag_max_abs_diff_after_10"],
+                "default_loop_max_abs_cosine_diff_vs_reference_order": {k: v["max_abs_cosine_diff_2000_rows"] for k, v in dl["vs_reference_order_on_gpu"].items()},
+                "default_loop_max_abs_cosine_diff_vs_oracle_loop": {"iterations": dl["vs_oracle_loop"]["iterations"], "value": dl["vs_oracle_loop"]["max_abs_cosine_diff_2000_rows"]},
+                "default_loop_stated_tolerance": 1e-4}
+        except Exception as ex:                               # noqa: BLE001
+            r["checks"]["drift_at_scale"] = {"error": f"profiles/r05_parity_at_scale.json missing or incomplete: {type(ex).__name__}: {ex}"}
         out = {
             "metric": METRIC if args.config == "C3" else f"propagate iterations/sec & edges·dim/sec, BASELINE config {args.config}", "value": r["value"], "unit": "edge*dim/s",
             "iterations_per_sec": r["iterations_per_sec"],

@@ -9,14 +9,20 @@
 __version__ = "0.1.0"
 
 
-def install():
+def install(devices=None):
     """Make this package's SparseMatrix the reference's compiled module: after this call
     `import pycleora` (the reference's unmodified Python package) binds
-    `from .pycleora import SparseMatrix` (pycleora/__init__.py:4) to cleora_amd.pycleora."""
+    `from .pycleora import SparseMatrix` (pycleora/__init__.py:4) to cleora_amd.pycleora.
+
+    devices: HIP device indices, e.g. range(8) — the graph is then row-partitioned over them INSIDE this process for
+    embed_fast*, left / symmetric_markov_propagate and (after accelerate()) pycleora.embed(); None keeps what
+    CLEORA_DEVICES / CLEORA_DEVICE say (default: device 0)."""
     import importlib.util
     import sys
 
     from . import pycleora as _mod
+    if devices is not None:
+        _mod.set_devices(devices)
     sys.modules["pycleora.pycleora"] = _mod
     # pickles name the class by module path; use the reference's (src/sparse_matrix.rs:56) when its
     # Python package is importable so pickles interchange with real pycleora, else keep ours

@@ -16,7 +16,7 @@ OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE, E_RCCL = 0, -1, -2, -3, -4, -5
 LEFT, SYMMETRIC = 0, 1
 F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
 F_L1NORM, F_BLEND_ANY, F_SQDIFF64, F_HUB_SEGMENTS = 128, 256, 512, 1024
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 ALLGATHER_RING, ALLGATHER_P2P, ALLGATHER_PEER = 0, 1, 2
 BALANCE_AUTO, BALANCE_ROWS, BALANCE_NNZ = 0, 1, 2
@@ -38,8 +38,20 @@ class ShardedInfo(ctypes.Structure):
                 ("has_symmetric", ctypes.c_int32)]
 
 
+class MultiInfo(ctypes.Structure):
+    _fields_ = [("n", c_u64), ("nnz", c_u64), ("n_pad", c_u64), ("world", c_u32), ("steps", c_u32),
+                ("has_symmetric", ctypes.c_int32), ("reserved", ctypes.c_int32), ("device", ctypes.c_int32 * 64),
+                ("local_rows", c_u64 * 64), ("local_nnz", c_u64 * 64), ("device_bytes", c_u64 * 64)]
+
+
 # name -> (restype, argtypes); mirrors include/cleora_hip.h one to one
 SIGNATURES = {
+    "cleora_multi_create": (c_int, [vp, c_u32, c_u64, c_u64, vp, vp, vp, vp, c_u32, c_int, ctypes.POINTER(vp)]),
+    "cleora_multi_destroy": (c_int, [vp]),
+    "cleora_multi_get_info": (c_int, [vp, ctypes.POINTER(MultiInfo)]),
+    "cleora_multi_embed": (c_int, [vp, vp, vp, c_int, c_u32, c_u64, c_i64, c_f32, c_f32, c_u32, vp, ctypes.POINTER(c_u64)]),
+    "cleora_multi_propagate": (c_int, [vp, c_int, vp, c_u32, vp]),
+    "cleora_sharded_set_stream": (c_int, [vp, vp]),
     "cleora_comm_local_id": (c_int, [vp]),
     "cleora_comm_create_local": (c_int, [vp, c_int, c_int, c_int, ctypes.POINTER(vp)]),
     "cleora_comm_enable_peer": (c_int, [vp]),
@@ -69,7 +81,6 @@ SIGNATURES = {
     "cleora_memset": (c_int, [vp, c_int, c_u64, vp]),
     "cleora_stream_sync": (c_int, [vp]),
     "cleora_stream_create": (c_int, [ctypes.POINTER(vp)]),
-    "cleora_stream_create_cu_mask": (c_int, [ctypes.POINTER(vp), vp, c_u32]),
     "cleora_stream_destroy": (c_int, [vp]),
     "cleora_stream_wait_stream": (c_int, [vp, vp]),
     "cleora_comm_unique_id": (c_int, [vp]),
@@ -280,6 +291,66 @@ class Graph:
     def close(self):
         if self.handle:
             lib().cleora_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiGraph:
+    """Owns a cleora_multi handle: the row partition over several devices of THIS process (csrc/multi.hip).  devices may repeat
+    (several shards on one GPU — the one-GPU test form)."""
+
+    def __init__(self, handle, devices):
+        self.handle = handle
+        self.devices = list(devices)
+
+    @classmethod
+    def from_host(cls, devices, rowptr, col, val_left, val_sym=None, steps=0, balance=BALANCE_AUTO):
+        devices = [int(v) for v in devices]
+        if not devices:
+            raise ValueError("need at least one device")
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+        col = np.ascontiguousarray(col, dtype=np.uint32)
+        val_left = np.ascontiguousarray(val_left, dtype=np.float32)
+        if val_sym is not None:
+            val_sym = np.ascontiguousarray(val_sym, dtype=np.float32)
+        ids = (ctypes.c_int * len(devices))(*devices)
+        h = vp()
+        check(lib().cleora_multi_create(ids, len(devices), rowptr.shape[0] - 1, col.shape[0], ptr(rowptr), ptr(col), ptr(val_left),
+                                        ptr(val_sym), int(steps), int(balance), ctypes.byref(h)))
+        return cls(h, devices)
+
+    def info(self):
+        mi = MultiInfo()
+        check(lib().cleora_multi_get_info(self.handle, ctypes.byref(mi)))
+        return mi
+
+    def embed(self, hashes, x0, kind, d, iterations, seed=0, residual_weight=0.0, threshold=0.0, flags=0):
+        """(out n x d, iterations run): cleora_multi_embed.  hashes (u64[n]) or x0 (n x d f32) is the start."""
+        n = int(self.info().n)
+        out = np.empty((n, d), np.float32)
+        ran = c_u64(0)
+        if x0 is not None:
+            x0 = np.ascontiguousarray(x0, dtype=np.float32)
+        if hashes is not None:
+            hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        check(lib().cleora_multi_embed(self.handle, ptr(hashes), ptr(x0), kind, d, int(iterations), int(seed), float(residual_weight),
+                                       float(threshold), int(flags), ptr(out), ctypes.byref(ran)))
+        return out, int(ran.value)
+
+    def propagate(self, kind, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        check(lib().cleora_multi_propagate(self.handle, kind, ptr(x), x.shape[1], ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().cleora_multi_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

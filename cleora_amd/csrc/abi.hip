@@ -757,7 +757,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
                               uint64_t iterations, float rw, uint32_t flags, float **result) {
     const uint64_t n = g->n_rows;
     const uint32_t norm = (flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM;
-    const uint32_t fast = flags & CLEORA_F_FASTNORM;
+    const uint32_t fast = flags & (CLEORA_F_FASTNORM | CLEORA_F_HUB_SEGMENTS);
     const bool blend = rw > 0.0f;                                          // the Python loop: any rw > 0 (:111-115)
     const bool any_whitening = norm == CLEORA_F_L2NORM;                   // rotation invariance needs the L2 norm
     int rc;
@@ -883,7 +883,7 @@ int embed_whitened(const cleora_graph *g, float *a, float *b, float *c, int mark
     const auto t_loop = std::chrono::steady_clock::now();
     // the Python loop blends for any rw > 0 (pycleora/__init__.py:111-115) and normalises with `normalization`
     const uint32_t base = ((flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM) | CLEORA_F_RESIDUAL |
-                          CLEORA_F_BLEND_ANY | (flags & CLEORA_F_FASTNORM);
+                          CLEORA_F_BLEND_ANY | (flags & (CLEORA_F_FASTNORM | CLEORA_F_HUB_SEGMENTS));
     for (uint64_t it = 0; it < max_iterations; ++it) {
         if ((rc = launch_propagate(g, markov_type, prev, d, d, mid, d, base, rw, prev, nullptr, nullptr, nullptr)) != CLEORA_OK)
             return rc;
@@ -1012,7 +1012,7 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
     float *partner = b.as<float>();
     float *src = fixed, *dst = partner;
     uint64_t actual = max_iterations;
-    const uint32_t base = CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | (flags & CLEORA_F_FASTNORM);
+    const uint32_t base = CLEORA_F_L2NORM | CLEORA_F_RESIDUAL | (flags & (CLEORA_F_FASTNORM | CLEORA_F_HUB_SEGMENTS));
     CL_HIP(hipDeviceSynchronize());
     const auto t_loop = std::chrono::steady_clock::now();
     for (uint64_t it = 0; it < max_iterations; ++it) {

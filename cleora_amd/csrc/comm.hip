@@ -127,14 +127,6 @@ int cleora_stream_create(void **stream) {
     return CLEORA_OK;
 }
 
-int cleora_stream_create_cu_mask(void **stream, const uint32_t *cu_mask, uint32_t words) {
-    CL_REQUIRE(stream != nullptr && cu_mask != nullptr && words > 0, "stream / mask is NULL");
-    hipStream_t s = nullptr;
-    CL_HIP(hipExtStreamCreateWithCUMask(&s, words, cu_mask));
-    *stream = s;
-    return CLEORA_OK;
-}
-
 int cleora_stream_destroy(void *stream) {
     if (stream) CL_HIP(hipStreamDestroy(S(stream)));
     return CLEORA_OK;

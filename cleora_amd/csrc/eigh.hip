@@ -33,6 +33,21 @@ struct Solver {
     std::string error;
     std::mutex mu;                               // one eigenproblem at a time per process
     std::map<int, rocblas_handle> handles;       // one rocBLAS handle per device, created on demand
+    // The handle owns the solvers' device workspace, so two problems on ONE handle must not overlap on the GPU either (the
+    // mutex only serialises the enqueues): every call first makes its stream wait for the previous call's end.  Matters when
+    // several shards of one process share a device (multi.hip's one-GPU form) or a host drives one device from two streams.
+    std::map<int, hipEvent_t> last_use;
+    int begin_use(int device, hipStream_t stream) {
+        auto it = last_use.find(device);
+        if (it != last_use.end()) CL_HIP(hipStreamWaitEvent(stream, it->second, 0));
+        return CLEORA_OK;
+    }
+    int end_use(int device, hipStream_t stream) {
+        hipEvent_t &e = last_use[device];
+        if (!e) CL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        CL_HIP(hipEventRecord(e, stream));
+        return CLEORA_OK;
+    }
 };
 
 Solver &solver() {
@@ -261,6 +276,7 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
             set_error("rocblas_set_stream failed");
             return CLEORA_E_HIP;
         }
+        if (int ru = s.begin_use(device, stream)) return ru;
         if (s.dpotrf(h, rocblas_fill_lower, (rocblas_int)d, w.cov, (rocblas_int)d, w.info) != rocblas_status_success) {
             set_error("rocsolver_dpotrf failed");
             return CLEORA_E_HIP;
@@ -276,6 +292,7 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
             set_error("rocsolver_dtrtri failed");
             return CLEORA_E_HIP;
         }
+        if (int ru = s.end_use(device, stream)) return ru;
     }
     hipLaunchKernelGGL(tri_transform_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, w.cov, d, transform);
     // (w.info was overwritten by trtri with 0: whiten_info() keeps reporting success for this workspace)
@@ -317,6 +334,7 @@ int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t
             set_error("rocblas_set_stream failed");
             return CLEORA_E_HIP;
         }
+        if (int ru = s.begin_use(device, stream)) return ru;
         // symmetric input: row-major and column-major coincide; eigenvectors come back column-major
         const rocblas_status st = s.dsyevd(h, rocblas_evect_original, rocblas_fill_upper, (rocblas_int)d, w.cov,
                                            (rocblas_int)d, w.w, w.e, w.info);
@@ -324,6 +342,7 @@ int launch_whiten_transform(const double *gram, uint64_t n, uint32_t d, uint32_t
             set_error("rocsolver_dsyevd failed with status " + std::to_string((int)st));
             return CLEORA_E_HIP;
         }
+        if (int ru = s.end_use(device, stream)) return ru;
     }
     const uint64_t cells = (uint64_t)d * k > d ? (uint64_t)d * k : d;
     hipLaunchKernelGGL(transform_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, w.cov, w.w, d, k,

@@ -49,8 +49,10 @@ constexpr uint64_t kWaitTicks = 60ull * 100000000ull;   // wait_kernel's budget:
 struct ShmRecord {                            // what a rank publishes for one exchange
     hipIpcMemHandle_t handle;
     uint64_t offset, bytes;
-    int32_t device, ok;
-    uint8_t pad[128 - sizeof(hipIpcMemHandle_t) - 24];
+    int32_t device, ok;                       // ok: 1 = handle + raw pointer, 2 = raw pointer only (the buffer cannot be exported), 0 = nothing
+    uint64_t raw;                             // the buffer's address in the publishing PROCESS: ranks that are threads of one process
+    int64_t pid;                              //   (csrc/multi.hip: one process, P devices) use it directly — hipIpc cannot open a handle at home
+    uint8_t pad[128 - sizeof(hipIpcMemHandle_t) - 40];
 };
 static_assert(sizeof(ShmRecord) == 128, "record size");
 
@@ -84,6 +86,12 @@ struct Mapping {                              // an allocation of a peer opened 
 };
 
 struct PeerLayer {
+    // every rank is a thread of THIS process (csrc/multi.hip): signals are HIP events instead of flags polled by a kernel — the
+    // streams of one process share a handful of hardware queues, and one rank's polling kernel in front of the peer's signal on
+    // the same queue would wait for its whole budget
+    bool inproc = false;
+    hipEvent_t ev[kChannels][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [channel][sequence parity]
+    PeerLayer *peer_layer[kMaxWorld] = {nullptr};
     std::vector<Mapping> mappings;
     ShmSegment *shm = nullptr;
     size_t shm_bytes = 0;
@@ -121,18 +129,21 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
     int rc = CLEORA_OK;
     void *base = nullptr;
     size_t range = 0;
+    std::string export_error;
     if (ptr) {
         hipError_t e = hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &range, ptr);
         if (e == hipSuccess) e = hipIpcGetMemHandle(&mine.handle, base);
+        mine.raw = (uint64_t)reinterpret_cast<uintptr_t>(ptr);
+        mine.pid = (int64_t)getpid();
+        mine.bytes = bytes;
+        mine.device = c->device;
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            set_error(std::string("peer transport: the buffer cannot be exported with hipIpcGetMemHandle (") + hipGetErrorString(e) +
-                      "); it must come from hipMalloc / cleora_malloc, and HSA_ENABLE_IPC_MODE_LEGACY=0 must be set");
-            rc = CLEORA_E_HIP;
+            export_error = std::string("the buffer cannot be exported with hipIpcGetMemHandle (") + hipGetErrorString(e) +
+                           "); it must come from hipMalloc / cleora_malloc, and HSA_ENABLE_IPC_MODE_LEGACY=0 must be set";
+            mine.ok = 2;                                    // still reachable by the ranks of this process
         } else {
             mine.offset = (uint64_t)(static_cast<char *>(ptr) - static_cast<char *>(base));
-            mine.bytes = bytes;
-            mine.device = c->device;
             mine.ok = 1;
         }
     }
@@ -146,6 +157,28 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
         if (!r.ok || r.bytes != bytes) {
             set_error("peer transport: rank " + std::to_string(p) + " did not publish a matching buffer");
             rc = CLEORA_E_INVALID;
+            break;
+        }
+        if (r.pid == (int64_t)getpid()) {
+            // a rank of this process (another host thread, maybe another device): its pointer is ours too — direct peer access
+            if (r.device != c->device) {
+                const hipError_t e = hipDeviceEnablePeerAccess(r.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                    (void)hipGetLastError();
+                    set_error(std::string("peer transport: hipDeviceEnablePeerAccess(") + std::to_string(r.device) + ") from device " + std::to_string(c->device) +
+                              " failed (" + hipGetErrorString(e) + ")");
+                    rc = CLEORA_E_HIP;
+                    break;
+                }
+                (void)hipGetLastError();
+            }
+            out->mapped_base[p] = nullptr;                    // nothing to close
+            out->peer[p] = reinterpret_cast<char *>((uintptr_t)r.raw);
+            continue;
+        }
+        if (r.ok != 1) {
+            set_error("peer transport: rank " + std::to_string(p) + " (another process) could not export its buffer");
+            rc = CLEORA_E_HIP;
             break;
         }
         void *mapped = nullptr;
@@ -165,6 +198,9 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
         out->mapped_base[p] = mapped;
         out->peer[p] = static_cast<char *>(mapped) + r.offset;
     }
+    if (rc == CLEORA_OK && !export_error.empty())
+        for (int p = 0; p < c->world; ++p)
+            if (p != c->rank && pl->shm->rec[p].pid != (int64_t)getpid()) { set_error("peer transport: " + export_error); rc = CLEORA_E_HIP; break; }
     if (rc != CLEORA_OK) pl->shm->failed.store(1, std::memory_order_release);
     b = barrier_host(c);                                    // nobody reuses the records before everybody has read them
     if (b != CLEORA_OK) return b;
@@ -261,6 +297,17 @@ __global__ __launch_bounds__(256) void fetch_kernel(const uint32_t *__restrict__
 
 int signal_and_wait(cleora_comm *c, int channel, uint64_t seq, hipStream_t stream) {
     PeerLayer *pl = c->peer;
+    if (pl->inproc) {
+        // record, meet on the host (a wait on an event nobody has recorded yet is a no-op), wait for every peer's record.  The
+        // parity's event is recorded again two operations later — after the meeting of the operation in between, which every
+        // rank reaches only once it has enqueued its waits of this one.
+        CL_HIP(hipEventRecord(pl->ev[channel][seq & 1], stream));
+        const int b = barrier_host(c);
+        if (b != CLEORA_OK) return b;
+        for (int p = 0; p < c->world; ++p)
+            if (p != c->rank) CL_HIP(hipStreamWaitEvent(stream, pl->peer_layer[p]->ev[channel][seq & 1], 0));
+        return CLEORA_OK;
+    }
     PeerPtrs mb{};
     for (int p = 0; p < c->world; ++p) mb.p[p] = p == c->rank ? (void *)pl->mailbox : (void *)pl->mailboxes.peer[p];
     hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(kMaxWorld), 0, stream, mb, channel, c->rank, c->world, seq);
@@ -341,6 +388,27 @@ int peer_enable(cleora_comm *c) {
     if (c->rank == 0) (void)shm_unlink(name);               // the mappings live on; nothing is left behind if a rank dies later
     if (rc != CLEORA_OK) return fail(rc);
     if ((rc = exchange_and_map(c, pl->mailbox, sizeof(Mailbox), &pl->mailboxes)) != CLEORA_OK) return fail(rc);
+    // are all ranks threads of this process?  (the records of the exchange above are still in place: the next write to them
+    // comes after the barrier below)
+    bool same = true;
+    for (int p = 0; p < c->world; ++p) same = same && pl->shm->rec[p].pid == (int64_t)getpid();
+    if ((rc = barrier_host(c)) != CLEORA_OK) return fail(rc);
+    if (same) {
+        for (int ch = 0; ch < kChannels; ++ch)
+            for (int k = 0; k < 2; ++k)
+                if (hipEventCreateWithFlags(&pl->ev[ch][k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); set_error("peer transport: hipEventCreate failed"); same = false; }
+        pl->shm->rec[c->rank].raw = (uint64_t)reinterpret_cast<uintptr_t>(pl);
+        pl->shm->rec[c->rank].ok = same ? 1 : 0;
+        if ((rc = barrier_host(c)) != CLEORA_OK) return fail(rc);
+        bool all = true;
+        for (int p = 0; p < c->world; ++p) {
+            all = all && pl->shm->rec[p].ok == 1;
+            pl->peer_layer[p] = reinterpret_cast<PeerLayer *>((uintptr_t)pl->shm->rec[p].raw);
+        }
+        if ((rc = barrier_host(c)) != CLEORA_OK) return fail(rc);
+        if (!all) { set_error("peer transport: creating the in-process signal events failed on a rank"); return fail(CLEORA_E_HIP); }
+        pl->inproc = true;
+    }
     return CLEORA_OK;
 }
 
@@ -354,6 +422,9 @@ void peer_destroy(cleora_comm *c) {
     if (pl->shm && c->world > 1) (void)barrier_host(c);      // peers have closed their mappings of OUR memory before we free it
     if (pl->scratch) (void)hipFree(pl->scratch);
     if (pl->mailbox) (void)hipFree(pl->mailbox);
+    for (int ch = 0; ch < kChannels; ++ch)
+        for (int k = 0; k < 2; ++k)
+            if (pl->ev[ch][k]) (void)hipEventDestroy(pl->ev[ch][k]);      // (after the barrier above: no peer enqueues a wait on them any more)
     if (pl->shm) munmap(pl->shm, pl->shm_bytes);
     delete pl;
     c->peer = nullptr;

@@ -45,6 +45,7 @@ struct cleora_sharded {
     };
     std::vector<Block> blocks;
     hipStream_t comm_stream = nullptr, side_stream = nullptr;
+    hipStream_t loop_stream = nullptr;           // what cleora_embed_sharded runs on (cleora_sharded_set_stream; default: the device's null stream)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side = nullptr;
     std::vector<uint64_t> offsets;               // scratch for the all-gather-v call
     bool pending = false;                        // collectives on comm_stream the compute stream has not joined yet
@@ -481,6 +482,13 @@ int cleora_sharded_block(const cleora_sharded *s, uint32_t k, cleora_graph **gra
     return CLEORA_OK;
 }
 
+int cleora_sharded_set_stream(cleora_sharded *s, void *stream) {
+    CL_REQUIRE(s != nullptr, "handle is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->loop_stream = S(stream);
+    return CLEORA_OK;
+}
+
 int cleora_sharded_set_timing(cleora_sharded *s, int enable) {
     CL_REQUIRE(s != nullptr, "handle is NULL");
     std::lock_guard<std::mutex> lock(s->mu);
@@ -552,12 +560,16 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
     if (max_iterations == 0) return CLEORA_OK;
     const uint64_t n = s->n, replica_bytes = s->n_pad * (uint64_t)d * 4;
     const bool whitened = (flags & CLEORA_F_WHITEN) != 0, check = convergence_threshold > 0.0f;
-    const uint32_t norm = (flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM, fast = flags & CLEORA_F_FASTNORM;
-    hipStream_t stream = nullptr;                                   // the loops run on the default stream of the device
+    const uint32_t norm = (flags & CLEORA_F_L1NORM) ? CLEORA_F_L1NORM : CLEORA_F_L2NORM, fast = flags & (CLEORA_F_FASTNORM | CLEORA_F_HUB_SEGMENTS);
+    hipStream_t stream = s->loop_stream;                            // default: the null stream of the device
     int rc;
     DevMem other;
     if ((rc = other.alloc(replica_bytes)) != CLEORA_OK) return rc;
     CL_HIP(hipMemsetAsync(other.p, 0, replica_bytes, stream));     // padding rows stay zero in both replicas
+    // The memset must have RUN before any peer may store into `other` (peer-direct all-gather): the registration's host barriers
+    // order the ranks' host threads only, so drain the stream first — a quicker peer's rows would otherwise be zeroed afterwards
+    // (ADVICE round 4).  The same wait covers whatever of the caller's still produces E_0 on this stream.
+    CL_HIP(hipStreamSynchronize(stream));
     struct Registered {                                             // peer-direct transport: both replicas mapped by every rank
         cleora_comm *c; void *a, *b; bool on = false;
         ~Registered() { if (on) { (void)cleora_comm_unregister(c, a); (void)cleora_comm_unregister(c, b); } }
@@ -651,9 +663,11 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
                                    stream)) != CLEORA_OK)
             return rc;
         const bool blend = rw > 0.0f;
-        uint64_t r0s, rws_;
-        stat_range(s, &r0s, &rws_);
-        const bool split_stats = rws_ >= 2 && gram32_applies(y + r0s * (uint64_t)d, d, rws_, d);
+        // ONE answer for all ranks (their statistics ranges differ by a row: around the split form's 4 096-row threshold a per-rank
+        // answer would send some ranks back into replicated_stats — two all-reduces — and the others on to the broadcast: ADVICE
+        // round 4): "approximate" as soon as ANY rank's range may have taken the split-bf16 form
+        const uint64_t Pw = (uint64_t)s->world;
+        const bool split_stats = n >= 2 * Pw && gram32_applies(y, d, (n + Pw - 1) / Pw, d);
         for (uint64_t it = 0; it + 1 < max_iterations; ++it) {
             // the statistics first (alone on the chip: DESIGN 3.8), then Z = A Y on a second stream beside the all-reduces and the
             // d x d step (the host blocks there), the projection when both are through
@@ -686,6 +700,8 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
     if (check && ((rc = sq.alloc(std::max<uint64_t>(s->local_rows, 1) * 8)) != CLEORA_OK || (rc = rws.alloc(reduce_workspace(std::max<uint64_t>(s->local_rows, 1)) * 8)) != CLEORA_OK ||
                   (rc = total.alloc(8)) != CLEORA_OK))
         return rc;
+    DevMem part;                                                    // (allocated once: hipFree inside the loop is a device-wide wait)
+    if (check && (rc = part.alloc(8)) != CLEORA_OK) return rc;
     float *prev = x_replica, *next = other.as<float>();
     for (uint64_t it = 0; it < max_iterations; ++it) {
         if ((rc = propagate_blocks(s, markov_type, prev, nullptr, local.as<float>(), d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, nullptr, false,
@@ -704,8 +720,6 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
             // padding rows of a block carry no valid difference: their slots were never written — sum the valid prefix of every block
             double sum = 0.0;
             CL_HIP(hipMemsetAsync(total.p, 0, 8, stream));
-            DevMem part;
-            if ((rc = part.alloc(8)) != CLEORA_OK) return rc;
             for (auto &b : s->blocks) {
                 if (!b.valid) continue;
                 if ((rc = launch_reduce_sum(sq.as<double>() + b.first_local, b.valid, rws.as<double>(), part.as<double>(), stream)) != CLEORA_OK) return rc;

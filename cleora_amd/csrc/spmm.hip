@@ -767,7 +767,7 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
     CL_REQUIRE(d > 0 && ldx >= d && ldy >= d, "bad d / leading dimension");
     CL_REQUIRE(x != nullptr && y != nullptr, "x / y is NULL");
     if (ldxs == 0) ldxs = ldx;   // x_self rows are strided like x unless the caller says otherwise
-    flags = gate_residual(flags, rw);
+    flags = gate_residual(flags & ~CLEORA_F_HUB_SEGMENTS, rw);   // (a row pass has no hub rows: the loops hand their flag set through)
     if (flags & (CLEORA_F_RESIDUAL | CLEORA_F_SQDIFF)) CL_REQUIRE(x_self != nullptr, "x_self is NULL");
     if (flags & CLEORA_F_SQDIFF) CL_REQUIRE(row_sqdiff != nullptr, "row_sqdiff is NULL");
     if (flags & (CLEORA_F_ROWSQ | CLEORA_F_SCALE)) CL_REQUIRE(row_sumsq != nullptr, "row_sumsq is NULL");

@@ -88,7 +88,7 @@ constexpr size_t kChunk = 32u << 20;
 constexpr int kSlots = 4;
 
 struct Stager {
-    std::mutex mu;                  // one staged copy at a time per process (they would only share the link anyway)
+    std::mutex mu;                  // one staged copy at a time per device (they would only share the link anyway)
     void *slot[kSlots] = {};
     hipEvent_t ev[kSlots] = {};
     hipStream_t stream = nullptr;
@@ -123,9 +123,16 @@ struct Stager {
     }
 };
 
+// one pipeline per device: the threads of a one-process multi-device job (multi.hip) move their shards over their own PCIe links
 Stager &stager() {
-    static Stager s;
-    return s;
+    static std::mutex mu;
+    static std::vector<Stager *> per_device;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    if ((size_t)dev >= per_device.size()) per_device.resize((size_t)dev + 1, nullptr);
+    if (!per_device[(size_t)dev]) per_device[(size_t)dev] = new Stager();
+    return *per_device[(size_t)dev];
 }
 
 }  // namespace

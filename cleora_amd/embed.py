@@ -144,6 +144,9 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
         ran = ctypes.c_uint64(0)
         flags = _hip.F_WHITEN | (_hip.F_L1NORM if normalization == "l1" else 0)
         with graph._lock:
+            m = graph._multi()
+            if m is not None:                        # several devices configured (cleora_amd.install(devices=...)): the row partition
+                return m.embed(None, x0, kind, d, int(num_iterations), 0, float(residual_weight), float(max(convergence_threshold, 0.0)), flags)[0]
             _hip.check(L.cleora_embed(graph._graph().handle, None, _hip.ptr(x0), kind, d, int(num_iterations), 0,
                                       float(residual_weight), float(max(convergence_threshold, 0.0)), flags,
                                       _hip.ptr(out), ctypes.byref(ran)))

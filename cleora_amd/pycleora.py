@@ -11,8 +11,12 @@ Differences from the reference, all deliberate:
     accepted and ignored (the reference's multi-worker f32 sums are order-nondeterministic).
   * non-contiguous / non-C-ordered float32 inputs are copied instead of panicking
     (src/embedding.rs:78 `as_slice().unwrap()`).
-  * rows split across wavefronts (more than 1024 edges) are summed in a different order than
-    the reference's sequential loop; every other row is bit-identical.
+Every row — hub rows included — is summed in the reference's order (csrc/spmm.hip): the propagate and the
+embed_fast loops are bit-identical to the reference's arithmetic as restated by oracle/.
+
+Several GPUs: `cleora_amd.install(devices=[0, 1, ..., 7])` (or CLEORA_DEVICES=0,1,...,7) makes the SAME calls — embed_fast*,
+left / symmetric_markov_propagate, and pycleora.embed() through cleora_amd.accelerate() — run the graph row-partitioned over
+those devices inside this one process (csrc/multi.hip: one host thread per device, peer-direct all-gather of the iterate).
 """
 import ctypes
 import os
@@ -23,6 +27,24 @@ import numpy as np
 from . import _hip, _host
 
 _PROPAGATIONS = {"left": _hip.LEFT, "symmetric": _hip.SYMMETRIC}
+
+
+_DEVICES = None     # set by cleora_amd.install(devices=[...]); None: CLEORA_DEVICES, else the single CLEORA_DEVICE
+
+
+def set_devices(devices):
+    """The devices later SparseMatrix calls run on: a list of HIP device indices (None: back to the environment)."""
+    global _DEVICES
+    _DEVICES = None if devices is None else [int(v) for v in devices]
+
+
+def _devices():
+    if _DEVICES is not None:
+        return list(_DEVICES)
+    env = os.environ.get("CLEORA_DEVICES", "").strip()
+    if env:
+        return [int(v) for v in env.split(",") if v.strip() != ""]
+    return [_device_index()]
 
 
 def _device_index():
@@ -39,7 +61,7 @@ def _as_f32_matrix(x, name="x"):
 
 
 class SparseMatrix:
-    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_lock", "_lookup", "__weakref__")
+    __slots__ = ("_host", "_arr", "_ids", "_dev_graph", "_multi_graph", "_lock", "_lookup", "__weakref__")
 
     # ---- construction -------------------------------------------------------------------------
     def __new__(cls, *args):
@@ -55,6 +77,7 @@ class SparseMatrix:
         self._arr = host.arrays()
         self._ids = None
         self._dev_graph = None
+        self._multi_graph = None
         self._lock = threading.Lock()
         self._lookup = {}       # id -> index tables, built on first use
 
@@ -99,8 +122,20 @@ class SparseMatrix:
         if self._dev_graph is None:
             a = self._arr
             self._dev_graph = _hip.Graph.from_host(a["rowptr"], a["col"], a["val_left"], a["val_sym"],
-                                                   device=_device_index())
+                                                   device=_devices()[0])
         return self._dev_graph
+
+    def _multi(self):
+        """The row partition over the configured devices (csrc/multi.hip), or None when one device is configured."""
+        devs = _devices()
+        if len(devs) < 2:
+            return None
+        if self._multi_graph is None or self._multi_graph.devices != devs:
+            if self._multi_graph is not None:
+                self._multi_graph.close()
+            a = self._arr
+            self._multi_graph = _hip.MultiGraph.from_host(devs, a["rowptr"], a["col"], a["val_left"], a["val_sym"])
+        return self._multi_graph
 
     # ---- propagation (src/lib.rs:29-47, 86-102) --------------------------------------------------
     def _markov_propagate(self, x, kind):
@@ -111,6 +146,10 @@ class SparseMatrix:
         d = x.shape[1]
         if n == 0 or d == 0:
             return np.zeros((n, d), np.float32)
+        with self._lock:
+            m = self._multi()
+            if m is not None:                       # every device its own rows, its own PCIe link
+                return m.propagate(kind, x)
         out = np.empty((n, d), np.float32)
         with self._lock:
             # the host-pointer entry point: device staging buffers live with the graph handle, both copies run
@@ -134,6 +173,9 @@ class SparseMatrix:
             return out, int(iterations)
         ran = ctypes.c_uint64(0)
         with self._lock:
+            m = self._multi()
+            if m is not None:
+                return m.embed(self._arr["hashes"], None, _PROPAGATIONS[propagation], d, iterations, seed, residual_weight, threshold, 0)
             g = self._graph()
             _hip.check(_hip.lib().cleora_embed(
                 g.handle, _hip.ptr(self._arr["hashes"]), None, _PROPAGATIONS[propagation], d,

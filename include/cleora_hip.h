@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CLEORA_ABI_VERSION 3
+#define CLEORA_ABI_VERSION 4
 
 #define CLEORA_OK 0
 #define CLEORA_E_INVALID (-1)   /* bad argument (shape, null pointer, unknown enum) */
@@ -102,9 +102,6 @@ int cleora_stream_sync(void *stream);
  * everything enqueued on `waiter` after this call runs after everything enqueued on `signaller` before it
  * (an event record + stream-wait; no host synchronisation).  NULL = the default stream. */
 int cleora_stream_create(void **stream);
-/* The same, confined to the compute units whose bits are set in cu_mask (`words` 32-bit words, bit c = CU c as the driver
- * numbers them; hipExtStreamCreateWithCUMask): a job that shares the GPU with another one, or the experiments of DESIGN 3.8. */
-int cleora_stream_create_cu_mask(void **stream, const uint32_t *cu_mask, uint32_t words);
 int cleora_stream_destroy(void *stream);
 int cleora_stream_wait_stream(void *waiter, void *signaller);
 
@@ -419,6 +416,10 @@ int cleora_sharded_block(const cleora_sharded *s, uint32_t k, cleora_graph **gra
  * `stream`.  With the peer-direct all-gather both replicas must be registered (cleora_comm_register). */
 int cleora_sharded_propagate_dev(cleora_sharded *s, int markov_type, const float *x, float *x_next, uint32_t d, uint32_t flags,
                                  float residual_weight, double *row_sqdiff_local, int gather, void *stream);
+/* The stream cleora_embed_sharded runs its loop on (default: the device's null stream).  Several handles driven by the threads of ONE
+ * process on ONE device (csrc/multi.hip's one-GPU test form) need a stream each: on a shared null stream one rank's wait for a peer
+ * would sit in front of that peer's signal. */
+int cleora_sharded_set_stream(cleora_sharded *s, void *stream);
 /* Timing for throughput reports: while enabled, ms[0] sums the SpMM kernels of this rank's blocks and ms[1] the all-gathers on the
  * communication stream (HIP events), over `calls` cleora_sharded_propagate_dev calls; get waits for the events and resets. */
 int cleora_sharded_set_timing(cleora_sharded *s, int enable);
@@ -436,6 +437,36 @@ int cleora_sharded_get_timing(cleora_sharded *s, double ms[2], uint64_t *calls);
 uint64_t cleora_embed_sharded_bytes(uint64_t n_pad, uint64_t local_rows, uint64_t n, uint32_t world, uint32_t d, uint32_t flags);
 int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, uint32_t d, uint64_t max_iterations,
                          float residual_weight, float convergence_threshold, uint32_t flags, uint64_t *iterations_run);
+
+/* ---- one process, P devices (csrc/multi.hip) --------------------------------------------------------------------------------------
+ * The row partition above behind ONE handle, for a host whose call is `embed(graph, 256, 40)` in one process (pycleora/__init__.py:
+ * 51-127; SparseMatrix::embed_fast, src/lib.rs:320-364): SURVEY.md 8(b) B2's graph handle with (n_devices, device_ids*).  The handle
+ * runs one host thread per device for the duration of a call; thread p is rank p of a local communicator (peer-direct stores; between
+ * threads of one process the peers' pointers are used directly, hipDeviceEnablePeerAccess across devices) and owns its blocks of the
+ * CSR (cleora_sharded_create) and a stream; the loops are cleora_embed_sharded / cleora_sharded_propagate_dev.  Every rank moves its
+ * own share over its own PCIe link.  device_ids may repeat (several shards on one GPU: how a one-GPU box tests this path).
+ * steps: row blocks per rank and iteration (0 = 4 for P > 1: block k's gather overlaps block k + 1's SpMM).
+ * Results: the plain loop and the propagate are bit-equal to the one-GPU calls; the whitened loop agrees within its stated tolerance. */
+typedef struct cleora_multi cleora_multi;
+typedef struct cleora_multi_info {
+    uint64_t n, nnz, n_pad;
+    uint32_t world, steps;
+    int32_t has_symmetric, reserved;
+    int32_t device[64];
+    uint64_t local_rows[64], local_nnz[64], device_bytes[64];
+} cleora_multi_info;
+/* rowptr / col / val_*: HOST arrays of the whole graph (borrowed for the call; every shard copies its slices).  val_sym may be NULL. */
+int cleora_multi_create(const int *device_ids, uint32_t n_devices, uint64_t n, uint64_t nnz, const uint64_t *rowptr, const uint32_t *col,
+                        const float *val_left, const float *val_sym, uint32_t steps, int balance, cleora_multi **out);
+int cleora_multi_destroy(cleora_multi *m);
+int cleora_multi_get_info(const cleora_multi *m, cleora_multi_info *info);
+/* cleora_embed's contract (below) over the partition: embed_fast / embed_fast_convergence, or the default loop of pycleora.embed() with
+ * CLEORA_F_WHITEN.  entity_hash_host (n u64) or x0_host (n x d) as the start; out_host: n x d.  Synchronous. */
+int cleora_multi_embed(cleora_multi *m, const uint64_t *entity_hash_host, const float *x0_host, int markov_type, uint32_t d,
+                       uint64_t max_iterations, int64_t seed, float residual_weight, float convergence_threshold, uint32_t flags,
+                       float *out_host, uint64_t *iterations_run);
+/* cleora_propagate's contract: y = A x (SparseMatrix::markov_propagate, src/lib.rs:29-47), x_host and y_host n x d. */
+int cleora_multi_propagate(cleora_multi *m, int markov_type, const float *x_host, uint32_t d, float *y_host);
 
 /* The k nearest rows of X by cosine similarity for a batch of query ROWS of X, selected on the device: the
  * `normed @ normed[src]`, the -2 masks and `argsort()[::-1][:top_k]` of predict_links / find_most_similar

@@ -141,8 +141,8 @@ def test_two_ranks_sharing_the_gpu_over_gloo():
     want_row, _ = oracle.embed(rowptr, col, vl, x0, 3)
     want_col, _ = oracle.embed(rowptr, col, vs, x0, 3)
     for _, xr, xc in got:
-        np.testing.assert_allclose(xr, want_row, rtol=0, atol=2e-6)      # hub row 9: summation-order tolerance
-        np.testing.assert_allclose(xc, want_col, rtol=0, atol=2e-6)
+        np.testing.assert_array_equal(xr, want_row)                      # every row in the reference's order, hub row 9 included
+        np.testing.assert_allclose(xc, want_col, rtol=0, atol=2e-6)      # column partition: the row norm is a sum of per-slice partials
     np.testing.assert_array_equal(got[0][1], got[1][1])                  # replicas identical
     np.testing.assert_array_equal(got[0][2], got[1][2])
 
@@ -216,5 +216,5 @@ def test_two_gpus_over_rccl_equal_the_single_gpu_result():
             assert np.abs(x * s - want).max() <= 2e-3 * np.abs(want).max()
         else:
             # the row partition runs the single-GPU kernel on row blocks: rows are bit-identical to the 1-GPU loop
-            # (the hub row is split identically: same segments)
+            # (the hub row too: the same in-order kernel)
             np.testing.assert_array_equal(x, out)

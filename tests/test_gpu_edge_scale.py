@@ -95,7 +95,7 @@ def test_wide_rows_panel_path():
 @pytest.mark.parametrize("config", ["C2_bipartite_1M_20M", "C3_powerlaw_10M_200M"])
 def test_properties_at_baseline_sizes(config):
     """BASELINE configs 2 and 3 at full size: row-stochasticity, linearity, determinism, unit norms,
-    independence from the hub split, and a sampled-row check against the oracle."""
+    independence from the hub threshold, and whole-graph bit-equality with the oracle (hub rows included)."""
     import torch
     from cleora_amd import synth
     dev = torch.device("cuda:0")
@@ -133,12 +133,17 @@ def test_properties_at_baseline_sizes(config):
     graph.set_hot_cache(-1)
     # 3. linearity: A(2x) = 2 A x exactly (power-of-two scaling commutes with every rounding)
     assert torch.equal(prop(graph, x * 2.0), y1 * 2.0)
-    # 4. hub split changes only the split rows, and only within summation-order tolerance
+    # 4. the hub threshold decides which KERNEL adds a row, never the result: rows of 301..1024 edges go through
+    #    hub_inorder_kernel on graph2 and through the main kernel on graph — same bits; the segmented form
+    #    (CLEORA_F_HUB_SEGMENTS) changes only the split rows, within summation-order tolerance
     y3 = prop(graph2, x)
+    assert torch.equal(y3, y1)
     deg = torch.diff(g["rowptr"])
+    y4 = prop(graph2, x, _hip.F_HUB_SEGMENTS)
     unsplit = deg <= 300
-    assert torch.equal(y3[unsplit], y1[unsplit])
-    assert float((y3 - y1).abs().max()) < 1e-4
+    assert torch.equal(y4[unsplit], y1[unsplit])
+    assert float((y4 - y1).abs().max()) < 1e-4
+    del y3, y4
     # 5. fused L2: unit rows
     yn = prop(graph, x, _hip.F_L2NORM)
     assert float((yn.double().pow(2).sum(1).sqrt() - 1).abs().max()) < 1e-6
@@ -151,35 +156,23 @@ def test_properties_at_baseline_sizes(config):
     ys = ys_dev.cpu().numpy()
     for r in rows[:400]:
         b, e = int(rp[r]), int(rp[r + 1])
-        if e - b > 1024:
-            continue
         acc = np.zeros(d, np.float32)   # reference order: acc += v * x, separate f32 mul/add
         for k in range(b, e):
             acc += vsh[k] * xh[colh[k]]
         np.testing.assert_array_equal(ys[r], acc)
     # 7. WHOLE-GRAPH parity with the oracle (src/embedding.rs:52-104), left and symmetric, same graph and X:
-    #    one fused SpMM + L2 iteration — every row that is not split must be bit-identical; split (hub) rows are
-    #    summed in segment order on the GPU and carry <= 2e-6 * sum|terms| on the un-normalised product
+    #    one fused SpMM + L2 iteration — EVERY row bit-identical, the hub rows (C3: 1 750, longest 431 465 edges) included
     rp64 = rp.astype(np.uint64)
     edges = np.empty(nnz, dtype=oracle.EDGE_DTYPE)
     edges["col"], edges["left"], edges["sym"] = colh, g["val_left"].cpu().numpy(), vsh
     hub = np.diff(rp.astype(np.int64)) > graph.info().hub_threshold
     threads = oracle.max_threads()
     want = np.empty((n, d), np.float32)
-    for kind, vals in ((0, edges["left"]), (1, edges["sym"])):
+    for kind in (0, 1):
         oracle.spmm_aos_l2_inplace(rp64, edges, kind == 1, xh, want, threads)
         got = prop(graph, x, _hip.F_L2NORM, kind).cpu().numpy()
         same = (got.view(np.uint32) == want.view(np.uint32)).all(axis=1)
-        assert same[~hub].all(), f"{(~same[~hub]).sum()} of {(~hub).sum()} unsplit rows differ from the oracle"
-        raw = y1 if kind == 0 else ys_dev
-        hub_rows = np.flatnonzero(hub)
-        big = hub_rows[np.argsort(-np.diff(rp.astype(np.int64))[hub_rows])[:24]]
-        rnd = np.random.default_rng(7).choice(hub_rows, size=min(150, hub_rows.size), replace=False) if hub_rows.size else hub_rows
-        for r in np.unique(np.concatenate([big, rnd])):
-            b, e = int(rp[r]), int(rp[r + 1])
-            terms = vals[b:e, None].astype(np.float64) * xh[colh[b:e]].astype(np.float64)
-            ref, bound = terms.sum(axis=0), 2e-6 * np.abs(terms).sum(axis=0)
-            assert np.all(np.abs(raw[r].cpu().numpy().astype(np.float64) - ref) <= bound + 1e-12)
+        assert same.all(), f"{(~same).sum()} of {n} rows differ from the oracle ({(~same[hub]).sum()} of them hub rows)"
         del got
     del want, edges
 

@@ -1,5 +1,6 @@
 """GPU fuzz: random shapes / degrees / flags through cleora_propagate_dev against the oracle.
-Rows that are not split are bit-exact (exact-order norm); split rows and FASTNORM carry tolerances."""
+Every row is bit-exact (reference-order sums, hub rows through hub_inorder_kernel, exact-order norm); CLEORA_F_HUB_SEGMENTS (drawn in a
+quarter of the cases with hub rows) and FASTNORM carry tolerances."""
 import numpy as np
 import pytest
 
@@ -54,6 +55,9 @@ def test_random_case(seed):
     want_sq = rng.random() < 0.4
     if want_sq:
         flags |= _hip.F_SQDIFF
+    segmented = bool((deg > eff_thr).any()) and seed % 4 == 3      # the opt-in segment sum of the hub rows
+    if segmented:
+        flags |= _hip.F_HUB_SEGMENTS
     dx, dxs = _hip.DevArray.from_host(x), _hip.DevArray.from_host(np.ascontiguousarray(xs))
     dy = _hip.DevArray((n, d), np.float32)
     L.cleora_memset(dy.ptr, 0xFF, dy.nbytes, None)
@@ -66,7 +70,7 @@ def test_random_case(seed):
     if flags & _hip.F_RESIDUAL:
         y = (np.float32(1.0) - np.float32(rw)) * y + np.float32(rw) * xs
     want = oracle.l2_normalize(y) if flags & _hip.F_L2NORM else y
-    split = deg > eff_thr
+    split = (deg > eff_thr) if segmented else np.zeros(n, bool)
     scale = np.abs(want).max() + 1e-30
     if not fast:
         np.testing.assert_array_equal(got[~split], want[~split])

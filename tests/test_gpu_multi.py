@@ -1,0 +1,121 @@
+"""GPU: ONE process, several devices behind the drop-in surface (csrc/multi.hip).
+
+The reference's user calls `embed(graph, 256, 40)` in one process (pycleora/__init__.py:51-127; SparseMatrix::embed_fast,
+src/lib.rs:320-364).  `cleora_amd.install(devices=[...])` makes that same call run the graph row-partitioned over the listed
+devices.  The GPU box has one device, so the lists here repeat it — P logical shards on device 0, each with its own host thread,
+stream, CSR blocks and replica: the partition, the peer-direct all-gather between the shards (same-process pointers instead of
+hipIpc mappings), the all-reduced whitening statistics and the per-shard host copies all run; only the xGMI hop is missing.
+
+Stated: the propagate and the plain loop are BIT-EQUAL to the one-device calls (and to the oracle); the whitened default loop
+agrees with the one-device result within 1e-4 on pairwise cosines and relative row norms."""
+import numpy as np
+import pytest
+
+import oracle
+import cleora_amd
+from cleora_amd import _hip
+from cleora_amd import embed as dev_embed
+from cleora_amd import pycleora as mod
+from cleora_amd.pycleora import SparseMatrix
+from tests.graphs import random_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _lines(n_nodes, n_lines, seed, hub=None):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, n_nodes, n_lines)
+    b = rng.integers(0, n_nodes, n_lines)
+    if hub is not None:                       # one entity on ~1 500 lines: a hub row for the in-order kernel
+        a[: hub] = 0
+    return [f"u{int(x)} u{int(y)}" for x, y in zip(a, b)]
+
+
+@pytest.fixture(scope="module")
+def graph():
+    g = SparseMatrix.from_iterator(iter(_lines(3000, 30000, 3, hub=1500)), "complex::reflexive::node")
+    deg = np.diff(g._arr["rowptr"].astype(np.int64))
+    assert deg.max() > 1024                    # a hub row is in the mix
+    return g
+
+
+@pytest.fixture(autouse=True)
+def _one_device_after():
+    yield
+    mod.set_devices(None)
+
+
+def _invariants(e):
+    s = e.astype(np.float64)
+    nrm = np.linalg.norm(s, axis=1)
+    s = s / np.maximum(nrm[:, None], 1e-300)
+    return s @ s.T, nrm
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 8])
+def test_drop_in_calls_run_the_partition_and_agree_with_one_device(graph, devices):
+    g = graph
+    a = g._arr
+    mod.set_devices(None)
+    one_fast = g.embed_fast(64, 8)
+    one_conv, one_it = g.embed_fast_convergence(64, 30, residual_weight=0.2, convergence_threshold=1e-3)
+    x = np.random.default_rng(1).standard_normal((g.num_entities, 48)).astype(np.float32)
+    one_left, one_sym = g.left_markov_propagate(x), g.symmetric_markov_propagate(x)
+    one_white = dev_embed.embed(g, 64, 6)
+    one_white_rw = dev_embed.embed(g, 64, 5, residual_weight=0.3, propagation="symmetric")
+
+    cleora_amd.install(devices=devices)
+    m = g._multi()
+    info = m.info()
+    assert info.world == len(devices) and info.n == g.num_entities and sum(info.local_nnz[: info.world]) == g.num_edges
+    # the plain loop: bit-equal to one device and to the oracle
+    np.testing.assert_array_equal(g.embed_fast(64, 8), one_fast)
+    np.testing.assert_array_equal(one_fast, oracle.embed(a["rowptr"], a["col"], a["val_left"], oracle.init(a["hashes"], 64, 0), 8)[0])
+    np.testing.assert_array_equal(dev_embed.embed(g, 64, 8, whiten=False), one_fast)            # pycleora.embed(g, 64, 8, whiten=False)
+    got, it = g.embed_fast_convergence(64, 30, residual_weight=0.2, convergence_threshold=1e-3)
+    assert it == one_it and 1 < it < 30
+    np.testing.assert_array_equal(got, one_conv)
+    # left / symmetric_markov_propagate: host in, host out, every shard its own rows
+    np.testing.assert_array_equal(g.left_markov_propagate(x), one_left)
+    np.testing.assert_array_equal(g.symmetric_markov_propagate(x), one_sym)
+    np.testing.assert_array_equal(one_left, oracle.spmm(a["rowptr"], a["col"], a["val_left"], x))
+    # the whitened default loop (statistics all-reduced over the shards): invariants within the stated 1e-4
+    for got, want in ((dev_embed.embed(g, 64, 6), one_white),
+                      (dev_embed.embed(g, 64, 5, residual_weight=0.3, propagation="symmetric"), one_white_rw)):
+        assert np.isfinite(got).all()
+        (cg, ng), (cw, nw) = _invariants(got), _invariants(want)
+        assert np.abs(cg - cw).max() <= 1e-4
+        assert (np.abs(ng - nw) / nw).max() <= 1e-4
+    # initial_embeddings through the partition
+    x0 = np.random.default_rng(2).standard_normal((g.num_entities, 32)).astype(np.float32)
+    got = dev_embed.embed(g, 32, 4, initial_embeddings=x0)
+    mod.set_devices(None)
+    want = dev_embed.embed(g, 32, 4, initial_embeddings=x0)
+    (cg, ng), (cw, nw) = _invariants(got), _invariants(want)
+    assert np.abs(cg - cw).max() <= 1e-4 and (np.abs(ng - nw) / nw).max() <= 1e-4
+
+
+def test_multi_handle_through_the_c_abi_shapes_and_errors():
+    n = 5003
+    rowptr, col, vl, vs = random_csr(n, 9, seed=5, empty_frac=0.03, hubs=[(17, 2200), (4000, 1300)])
+    hashes = np.random.default_rng(6).integers(0, 2 ** 63, n).astype(np.uint64)
+    g1 = _hip.Graph.from_host(rowptr, col, vl, vs)
+    for devices, steps, d in (([0], 0, 128), ([0, 0], 1, 256), ([0, 0, 0, 0], 3, 64), ([0, 0, 0], 0, 100)):
+        m = _hip.MultiGraph.from_host(devices, rowptr, col, vl, vs, steps=steps)
+        x0 = oracle.init(hashes, d, 3)
+        want, _ = oracle.embed(rowptr, col, vs, x0, 5, residual_weight=0.25)
+        got, ran = m.embed(hashes, None, _hip.SYMMETRIC, d, 5, seed=3, residual_weight=0.25)
+        assert ran == 5
+        np.testing.assert_array_equal(got, want)
+        got, _ = m.embed(None, x0, _hip.SYMMETRIC, d, 5, residual_weight=0.25)
+        np.testing.assert_array_equal(got, want)
+        x = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+        np.testing.assert_array_equal(m.propagate(_hip.LEFT, x), oracle.spmm(rowptr, col, vl, x))
+        m.close()
+    g1.close()
+    m = _hip.MultiGraph.from_host([0, 0], rowptr, col, vl, None)
+    with pytest.raises((ValueError, RuntimeError), match="markov_type"):
+        m.propagate(_hip.SYMMETRIC, np.zeros((n, 8), np.float32))
+    m.close()
+    with pytest.raises((ValueError, RuntimeError), match="device id"):
+        _hip.MultiGraph.from_host([0, 99], rowptr, col, vl, None)

@@ -178,6 +178,51 @@ def golden_loop_check(config, g, hashes, a, b, iterate, n, d, L):
         return {"error": f"{type(ex).__name__}: {ex}"[:300]}
 
 
+class _CsrHost:
+    """What SparseMatrix needs of a host graph when the CSR already exists (the bench's synthetic graphs never were text lines)."""
+
+    def __init__(self, arr):
+        self._arr = arr
+
+    def arrays(self):
+        return self._arr
+
+    def sizes(self):
+        return int(self._arr["rowptr"].shape[0] - 1), int(self._arr["col"].shape[0])
+
+
+def end_to_end(g, hashes, n, d, iterations, L):
+    """SURVEY.md 8(d) "report end-to-end separately": the wall clock of the DROP-IN calls on this workload, host arrays in, host array
+    out — `SparseMatrix.embed_fast(d, 40)` (src/lib.rs:320-364) and `pycleora.embed(graph, d, 40)` with its default whiten=True
+    (pycleora/__init__.py:51-127; cleora_amd.embed.embed is what accelerate() binds there) — and what they are made of: the one-time CSR
+    upload (+ hub schedule), the iteration loop (cleora_last_embed_loop_ms), and everything else of the call (allocation of the iterates,
+    E_0, hot-row marking on the third launch, the placement decision, the 10 GB download through the pinned pipeline)."""
+    from cleora_amd import embed as dev_embed
+    from cleora_amd.pycleora import SparseMatrix
+    arr = {"rowptr": g["rowptr"].cpu().numpy().astype(np.uint64), "col": g["col"].cpu().numpy().view(np.uint32),
+           "val_left": g["val_left"].cpu().numpy(), "val_sym": g["val_sym"].cpu().numpy(),
+           "hashes": hashes.cpu().numpy().view(np.uint64)}
+    sm = SparseMatrix._wrap(_CsrHost(arr))
+    out = {"iterations": iterations, "workload": f"n={n}, nnz={g['nnz']}, d={d}; host CSR and host result (pageable numpy memory)"}
+    t0 = time.perf_counter()
+    sm._graph()
+    out["graph_upload_s"] = round(time.perf_counter() - t0, 3)
+    for name, call in (("embed_fast", lambda: sm.embed_fast(d, iterations)),
+                       ("embed_default_whitened", lambda: dev_embed.embed(sm, d, iterations))):
+        try:
+            t0 = time.perf_counter()
+            res = call()
+            wall = time.perf_counter() - t0
+            loop = L.cleora_last_embed_loop_ms() / 1e3
+            out[name] = {"wall_s": round(wall, 3), "loop_s": round(loop, 3), "outside_the_loop_s": round(wall - loop, 3),
+                         "iterations_per_sec_end_to_end": round(iterations / wall, 2), "finite": bool(np.isfinite(res[:: max(1, n // 4096)]).all())}
+            del res
+        except Exception as ex:                               # noqa: BLE001 - an extra beside the headline
+            out[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    sm._dev_graph.close()
+    return out
+
+
 def cpu_baseline_row_block(g, x_dev, n, d, rows=500_000, budget_s=20.0):
     """cpu_baseline for graphs whose iterate does not fit the host comfortably: the oracle's SpMM + L2 over a contiguous
     block of `rows` OUTPUT rows of the same graph.  The gathered X rows are remapped to a compact array (only the rows the block
@@ -613,7 +658,9 @@ def placed_pair(block, rows, d, dev, args):
     (a, b), ms = _hip.DevArray.iterates(block, rows, d, 2)
     return (torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev),
             {"library_search": True, "untuned_launch_ms": round(ms[0], 3), "chosen_launch_ms": round(ms[1], 3),
-             "note": "one SpMM launch per candidate partner buffer; untuned = the first (plain) allocation pair"})
+             "note": "cleora_alloc_iterates: median of three SpMM launches per candidate partner buffer, the first (plain) pair kept unless another "
+                     "is >= 3 % faster; untuned = the first pair.  The embed loops skip the search when the iterations cannot repay it "
+                     "(cleora_alloc_iterates_for: ~100 iterations at this size)"})
 
 
 def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, backend, L):
@@ -962,6 +1009,7 @@ def main():
                     help="plain allocations for the iterates instead of cleora_alloc_iterates (DESIGN.md §3.1)")
     ap.add_argument("--whiten-iters", type=int, default=8, help="iterations of the whitened default loop (N = 1); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the wall clock of the drop-in calls (embed_fast / embed, 40 iterations, host in / host out)")
     ap.add_argument("--watchdog", type=int, default=1500, help="seconds before every thread's traceback is dumped and the run exits")
     ap.add_argument("--backend", default="rccl", choices=["rccl", "local", "gloo"],
                     help="N > 1: transport of the C-ABI communicator — rccl (RCCL over xGMI, csrc/comm.hip; the peer-direct all-gather is timed "
@@ -1084,7 +1132,7 @@ def main():
     best = "row" if "row" in results else next(iter(results))
     r = results[best]
 
-    whitened = cpu = None
+    whitened = cpu = e2e = None
     if world == 1:
         a, b, iterate, blocks, sg = keep
         if not args.no_cpu_baseline:
@@ -1114,6 +1162,10 @@ def main():
             whitened = run_whitened(args, g, x_w, dev, L, args.whiten_iters)
         elif args.whiten_iters > 0:
             whitened = {"skipped": "the whitened loop keeps three iterates and a workspace resident: does not fit one GPU at this size"}
+        if not args.no_end_to_end and n * d * 4 * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.7 and n * d * 4 < (48 << 30):
+            del x_w
+            torch.cuda.empty_cache()
+            e2e = end_to_end(g, hashes, n, d, 40, L)
 
     if rank == 0:
         # PMC traffic of the dominant kernel: a committed measurement, valid only for the kernel build it was taken on
@@ -1138,7 +1190,7 @@ def main():
         pt = r.get("placement_tuning") or {}
         if pt.get("untuned_launch_ms"):
             r["roofline"]["frac_untuned"] = r["roofline"]["algorithmic_bytes_per_launch"] / (pt["untuned_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
-            r["roofline"]["frac_untuned_note"] = "one launch on the first allocation pair cleora_alloc_iterates drew (what a plain hipMalloc pair runs at)"
+            r["roofline"]["frac_untuned_note"] = "median of three launches on the first allocation pair cleora_alloc_iterates drew (what a plain hipMalloc pair runs at)"
         # end-to-end figures of the GPU suite at config 2's size (tests/test_gpu_parity_at_scale.py), quoted from the committed record;
         # a missing file or key is an error in the line, not an empty object (round 4 shipped one)
         ppath = os.path.join(ROOT, "profiles", "r05_parity_at_scale.json")
@@ -1179,6 +1231,8 @@ def main():
                 out["whitened_sharded"] = whitened_sharded
         if whitened is not None:
             out["whitened"] = whitened
+        if e2e is not None:
+            out["end_to_end"] = e2e
         print(json.dumps(out), flush=True)
     comm.close()
     if world > 1:

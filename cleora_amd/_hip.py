@@ -105,6 +105,7 @@ SIGNATURES = {
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
     "cleora_alloc_iterates": (c_int, [vp, c_u32, c_u32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double * 2)]),
+    "cleora_alloc_iterates_for": (c_int, [vp, c_u32, c_u32, c_u64, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double * 2)]),
     "cleora_propagate_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_propagate_vals_dev": (c_int, [vp, vp, vp, c_u64, c_u32, vp, c_u64, c_u32, c_f32, vp, vp, vp, vp]),
     "cleora_propagate_attention_dev": (c_int, [vp, c_int, vp, c_u64, c_u32, c_f32, vp, c_u64, c_u32, c_f32, vp, vp, vp]),
@@ -376,12 +377,13 @@ class DevArray:
         self.ptr = p
 
     @classmethod
-    def iterates(cls, graph, rows, d, count):
-        """`count` (rows, d) f32 buffers placed for the SpMM of `graph` (cleora_alloc_iterates): every SpMM of the
-        loop should read or write the FIRST one.  Returns (list of DevArray, (first-candidate ms, chosen ms))."""
+    def iterates(cls, graph, rows, d, count, iterations=0):
+        """`count` (rows, d) f32 buffers placed for the SpMM of `graph` (cleora_alloc_iterates_for): every SpMM of the
+        loop should read or write the FIRST one.  iterations: the SpMM launches about to run on them (0 = unknown: always
+        search).  Returns (list of DevArray, (first-candidate ms, chosen ms))."""
         bufs = (vp * count)()
         ms = (ctypes.c_double * 2)()
-        check(lib().cleora_alloc_iterates(graph.handle, int(d), int(count), bufs, ctypes.byref(ms)))
+        check(lib().cleora_alloc_iterates_for(graph.handle, int(d), int(count), int(iterations), bufs, ctypes.byref(ms)))
         return [cls((rows, d), np.float32, _ptr=vp(bufs[i])) for i in range(count)], (ms[0], ms[1])
 
     @classmethod

@@ -192,7 +192,7 @@ def _device_loop(g, n, x0, kind, num_iterations, normalization, callback, residu
     whitener = DeviceWhitener(n, d) if (whiten and n > 1) else None
     # iterate buffers placed for the SpMM (cleora_alloc_iterates): the SpMM always WRITES `nxt` and reads `cur` — which
     # is, in turn, each of the other buffers — so `nxt` is the buffer the partners are tuned against
-    (nxt, cur, *rest), _ = _hip.DevArray.iterates(g, n, d, 3 if whitener is not None else 2)
+    (nxt, cur, *rest), _ = _hip.DevArray.iterates(g, n, d, 3 if whitener is not None else 2, iterations=int(num_iterations))
     wht = rest[0] if rest else None
     _hip.check(L.cleora_memcpy_h2d(cur.ptr, _hip.ptr(x0), cur.nbytes, None))
     check = convergence_threshold > 0

@@ -143,17 +143,20 @@ int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes);
 int cleora_graph_set_timing(cleora_graph *g, int enable);
 int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
 
-/* Iterate buffers placed for the SpMM (no reference counterpart).  The same launch runs up to 12-20 % slower when the
+/* Iterate buffers placed for the SpMM (no reference counterpart).  The same launch has been measured up to 12-20 % slower when the
  * buffer it gathers from and the buffer it writes fall into the same physical placement class of the HBM (DESIGN.md
- * §3.1; not visible in virtual addresses).  Allocates `count` buffers of max(n_rows, n_cols) x d floats: bufs[0] first,
- * then each partner by TIMING the real kernel (one launch per candidate, gathers from bufs[0], writes the candidate)
- * until a candidate is >= 5 % faster than the slowest seen (at most 6, and none once CLEORA_PLACEMENT_BUDGET_MS = 1500 ms
- * of wall clock are spent; rejected candidates are held until the slot is settled, then freed).  Use bufs[0] as the buffer EVERY SpMM of the
- * loop touches: ping-pong = the pair (bufs[0], bufs[1]); the whitened loop = SpMM output in bufs[0], the two whitened
- * iterates in bufs[1] and bufs[2].  Iterates below 256 MiB are allocated without the search.  Contents are
- * unspecified.  ms (optional, double[2]): the first candidate's launch time — what a plain allocation pair would have
- * run at — and the chosen pair's.  Free every buffer with cleora_free. */
+ * §3.1; not visible in virtual addresses; box-dependent).  Allocates `count` buffers of max(n_rows, n_cols) x d floats: bufs[0]
+ * first, then each partner by TIMING the real kernel on candidates (gathers from bufs[0], writes the candidate; a candidate's time
+ * is the median of three launches): the first candidate is kept unless another is >= 3 % faster; at most 3 candidates per slot and
+ * none once CLEORA_PLACEMENT_BUDGET_MS = 1500 ms of wall clock are spent.  cleora_alloc_iterates_for also takes the number of SpMM
+ * launches the caller is about to run (0 = unknown) and stops searching when the most it could win — 15 % of a launch per
+ * iteration — is less than trying another candidate costs (three launches + freeing the loser, ~30 ms per GB): the embed loops
+ * call it that way.  Use bufs[0] as the buffer EVERY SpMM of the loop touches: ping-pong = the pair (bufs[0], bufs[1]); the
+ * whitened loop = SpMM output in bufs[0], the two whitened iterates in bufs[1] and bufs[2].  Iterates below 256 MiB are allocated
+ * without the search.  Contents are unspecified.  ms (optional, double[2]): the first candidate's median launch time — what a
+ * plain allocation pair runs at — and the chosen pair's (never more).  Free every buffer with cleora_free. */
 int cleora_alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, void **bufs, double *ms);
+int cleora_alloc_iterates_for(const cleora_graph *g, uint32_t d, uint32_t count, uint64_t iterations, void **bufs, double *ms);
 
 /* ---- device-pointer hot path ------------------------------------------------------- */
 

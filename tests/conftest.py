@@ -47,3 +47,16 @@ def pytest_sessionstart(session):
     paths += sorted(glob.glob("/opt/rocm/lib/rocblas/library/*gfx950*"))
     if paths:
         threading.Thread(target=_warm_page_cache, args=(paths,), daemon=True).start()
+    # what `import torch` maps (the multi-process tests and bench.py import it in fresh processes: on a box with slow storage the
+    # first of them took 233 s of a 560 s suite, 12 s on a box with fast storage) — a second reader, most needed first
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        tlib = os.path.join(os.path.dirname(spec.origin), "lib") if spec and spec.origin else None
+    except Exception:                               # noqa: BLE001
+        tlib = None
+    if tlib and os.path.isdir(tlib):
+        names = ("libtorch_cpu.so", "libtorch_hip.so", "libamdhip64.so", "libhsa-runtime64.so", "libc10.so", "libtorch_python.so", "librocblas.so",
+                 "libhipblaslt.so", "libamd_comgr.so", "libMIOpen.so", "librocsolver.so", "librocsparse.so", "librocrand.so", "libmagma.so", "librccl.so")
+        tpaths = [os.path.join(tlib, nm) for nm in names if os.path.exists(os.path.join(tlib, nm))]
+        threading.Thread(target=_warm_page_cache, args=(tpaths,), daemon=True).start()

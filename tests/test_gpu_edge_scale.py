@@ -116,8 +116,15 @@ def test_properties_at_baseline_sizes(config):
         return y
 
     # 1. left Markov matrix is row-stochastic: A @ c = c (each row sums to 1 within f32 rounding)
+    #    — as far as the reference's own sum goes: one f32 accumulator over the row's edges in stored order (src/embedding.rs:76-83)
+    #    drifts by up to ~deg * 2^-24 of the sum, which for C3's longest row (431 465 edges) is ~1e-3; rows of ordinary length
+    #    stay within 2e-5.  (The segmented hub sum of rounds 1-4 hid this; the in-order kernel reproduces it bit for bit — check 7.)
     c = torch.full((n, d), 0.375, dtype=torch.float32, device=dev)
-    assert float((prop(graph, c) - 0.375).abs().max()) < 2e-5
+    err = (prop(graph, c) - 0.375).abs().amax(dim=1)
+    deg_all = torch.diff(g["rowptr"])
+    assert float(err[deg_all <= 1024].max()) < 2e-5
+    assert bool((err <= 0.375 * 2.0 ** -24 * (deg_all.double() + 2) + 2e-5).all())
+    del err
     # 2. determinism: two launches are bit-identical
     x = torch.randn((n, d), dtype=torch.float32, device=dev)
     y1, y2 = prop(graph, x), prop(graph, x)

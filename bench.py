@@ -75,8 +75,9 @@ def kernel_source_stamp():
 def rows_bit_equal(dev, host, chunk=1 << 20):
     """Number of rows of the device matrix whose bits equal the host matrix's."""
     same = 0
-    for r0 in range(0, host.shape[0], chunk):
-        got = dev[r0:r0 + chunk].cpu().numpy()
+    n = host.shape[0]                                     # (the device matrix may carry padding rows below)
+    for r0 in range(0, n, chunk):
+        got = dev[r0:min(n, r0 + chunk)].cpu().numpy()
         same += int((got.view(np.uint32) == host[r0:r0 + chunk].view(np.uint32)).all(axis=1).sum())
     return same
 
@@ -511,6 +512,7 @@ def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=
     xr = torch.zeros((sg.n_pad, d), dtype=torch.float32, device=dev)
     xr[:n] = x
     yr = torch.zeros_like(xr)
+    torch.cuda.synchronize()                              # the fills must have RUN before a peer may store into the replicas
     register_replicas(comm, xr, yr)
     out["row_max_abs_diff"], out["row_bit_equal"], algos = 0.0, True, [_hip.ALLGATHER_PEER] if comm.local else [_hip.ALLGATHER_RING, _hip.ALLGATHER_P2P]
     if not comm.local and getattr(comm, "peer_enabled", False):
@@ -518,7 +520,12 @@ def partition_selftest(dev, rank, world, comm, backend, L, nodes=100_000, pairs=
     names = {_hip.ALLGATHER_RING: "rccl_allgather", _hip.ALLGATHER_P2P: "p2p_mesh", _hip.ALLGATHER_PEER: "peer_direct"}
     for algo in algos:                                    # every all-gather algorithm the timed run may pick
         comm.set_allgather(algo)
+        # the zero fill of this rank must have RUN on every rank before any rank's first block is pushed into the peers' copies: a
+        # quicker peer's rows would be wiped by a fill still queued here (seen with 8 ranks sharing one GPU, round 5: three of eight
+        # ranks lost rows; the timed loops never fill a buffer the peers write)
         yr.zero_()
+        torch.cuda.synchronize()
+        dist.barrier()
         sg.propagate(_hip.LEFT, xr, yr)
         torch.cuda.synchronize()
         diff, equal, note = float((yr[:n] - want).abs().max()), bool(torch.equal(yr[:n], want)), ""
@@ -658,8 +665,8 @@ def placed_pair(block, rows, d, dev, args):
     (a, b), ms = _hip.DevArray.iterates(block, rows, d, 2)
     return (torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev),
             {"library_search": True, "untuned_launch_ms": round(ms[0], 3), "chosen_launch_ms": round(ms[1], 3),
-             "note": "cleora_alloc_iterates: median of three SpMM launches per candidate partner buffer, the first (plain) pair kept unless another "
-                     "is >= 3 % faster; untuned = the first pair.  The embed loops skip the search when the iterations cannot repay it "
+             "note": "cleora_alloc_iterates: median of three SpMM launches per candidate partner buffer (at most four), the best taken; "
+                     "untuned = the first (plain) pair.  The embed loops skip the search when the iterations cannot repay it "
                      "(cleora_alloc_iterates_for: ~100 iterations at this size)"})
 
 
@@ -1084,7 +1091,7 @@ def main():
             parts.remove("column")
             parts = parts or ["row"]
 
-    results, keep, whitened_sharded = {}, None, None
+    results, keep, whitened_sharded, cpu = {}, None, None, None
     for part in parts:
         res, a, b, iterate, blocks, sg = run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher,
                                                        backend, L)
@@ -1123,6 +1130,14 @@ def main():
                                         "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
             elif part == "row":
                 unregister_replicas(comm, a, b)
+            if part == "row" and rank == 0 and not args.no_cpu_baseline and cpu is None:
+                # N > 1: the CPU baseline of the (d) rule beside the line — rank 0's host cores on a bounded row block of the same graph
+                # and iterate (the N = 1 protocol for graphs too big for a host-side iteration); the other ranks wait at the barrier below
+                try:
+                    cpu = cpu_baseline_row_block(g, a, n, d, rows=min(500_000, n // 2), budget_s=12.0)
+                    cpu["note"] = "measured by rank 0 while the other ranks wait (N > 1): a row block of the same graph, all host cores"
+                except Exception as ex:                                     # noqa: BLE001
+                    cpu = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             if sg is not None:
                 sg.close()
             del a, b, iterate, blocks, sg
@@ -1132,7 +1147,7 @@ def main():
     best = "row" if "row" in results else next(iter(results))
     r = results[best]
 
-    whitened = cpu = e2e = None
+    whitened = e2e = None
     if world == 1:
         a, b, iterate, blocks, sg = keep
         if not args.no_cpu_baseline:
@@ -1227,6 +1242,9 @@ def main():
                 if k in r:
                     out["config"][k] = r[k]
             out["config"]["ranks"] = world
+            out["expected"] = ("row partition: every rank must RECEIVE (P-1)/P of the n x d iterate per iteration over its xGMI links (config.ceiling), so P = 2 — one link, "
+                               "half the iterate — is expected at or BELOW one GPU's rate at this size, P = 4 about level with it, P = 8 at 2-3.9x (DESIGN.md 6); "
+                               "the column partition beside it (partitions.column) has no such term")
             if whitened_sharded is not None:
                 out["whitened_sharded"] = whitened_sharded
         if whitened is not None:

@@ -162,6 +162,7 @@ int launch_whiten_transform_cholesky(const double *gram, uint64_t n, uint32_t d,
                                      hipStream_t stream, bool approximate_gram = false);
 uint64_t whiten_workspace(uint64_t n, uint32_t d);
 const int *whiten_info(void *workspace, uint64_t n, uint32_t d);
+const int *transform_info(void *eigh_workspace, uint32_t d);
 int whiten_set_timing(bool enable);
 int whiten_get_timing(double ms[4], uint64_t *calls);
 int launch_whiten(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, float *y, uint64_t ldy,

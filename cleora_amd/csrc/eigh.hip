@@ -443,6 +443,9 @@ int whiten_get_timing(double ms[4], uint64_t *calls) {
     return CLEORA_OK;
 }
 
+// the same flag for a caller that owns the d x d step's workspace alone (eigh_workspace(d): sharded.hip)
+const int *transform_info(void *eigh_ws, uint32_t d) { return carve_transform(eigh_ws, d).info; }
+
 // dsyevd's convergence flag of the last launch_whiten on this workspace (0 = converged), on the device
 const int *whiten_info(void *workspace, uint64_t n, uint32_t d) {
     WhitenWs w;

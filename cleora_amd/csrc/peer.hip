@@ -90,6 +90,7 @@ struct PeerLayer {
     // streams of one process share a handful of hardware queues, and one rank's polling kernel in front of the peer's signal on
     // the same queue would wait for its whole budget
     bool inproc = false;
+    bool poisoned = false;                    // a host barrier timed out
     hipEvent_t ev[kChannels][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      // [channel][sequence parity]
     PeerLayer *peer_layer[kMaxWorld] = {nullptr};
     std::vector<Mapping> mappings;
@@ -114,7 +115,14 @@ uint64_t fnv1a(const unsigned char *p, size_t n) {
 
 int barrier_host(cleora_comm *c) {
     PeerLayer *pl = c->peer;
+    // a barrier that timed out leaves its arrival count behind: every later barrier on the segment would pair up wrongly, so the
+    // communicator refuses further collectives instead; destroy it and create a new one
+    if (pl->poisoned) {
+        set_error("peer transport: this communicator lost a rank at an earlier host barrier and cannot be used any more");
+        return CLEORA_E_RCCL;
+    }
     if (shm_barrier_wait(&pl->shm->barrier, (uint32_t)c->world, &pl->local_sense, kHostBarrierSeconds)) return CLEORA_OK;
+    pl->poisoned = true;
     set_error("peer transport: a rank did not reach the host barrier within " + std::to_string((int)kHostBarrierSeconds) + " s");
     return CLEORA_E_RCCL;
 }

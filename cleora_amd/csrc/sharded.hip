@@ -583,10 +583,16 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
     }
     float *result = nullptr;
     uint64_t ran = max_iterations;
+    void *solver_ws = nullptr;                                      // the whitened loops: where the eigensolver leaves its convergence flag
     auto finish = [&]() -> int {
         CL_HIP(hipStreamSynchronize(stream));
         CL_HIP(hipStreamSynchronize(s->comm_stream));
         if (s->comm) { const int rk = cleora_comm_check(s->comm); if (rk != CLEORA_OK) return rk; }
+        if (solver_ws) {                                            // like the one-GPU loops (abi.hip embed_whitened*): non-convergence is an error
+            int info = 0;
+            CL_HIP(hipMemcpy(&info, transform_info(solver_ws, d), sizeof info, hipMemcpyDeviceToHost));
+            if (info != 0) { set_error("the eigensolver did not converge (rocsolver_dsyevd info = " + std::to_string(info) + ")"); return CLEORA_E_HIP; }
+        }
         if (result != x_replica) CL_HIP(hipMemcpy(x_replica, result, replica_bytes, hipMemcpyDeviceToDevice));
         if (iterations_run) *iterations_run = ran;
         return CLEORA_OK;
@@ -625,6 +631,8 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
     uint64_t sr0, srows;
     stat_range(s, &sr0, &srows);
     if ((rc = st.alloc(srows, d)) != CLEORA_OK) return rc;
+    solver_ws = st.eigh.p;
+    CL_HIP(hipMemsetAsync(const_cast<int *>(transform_info(solver_ws, d)), 0, sizeof(int), stream));
     DevMem local;                                                   // this rank's rows only: Z = A Y (reorganised loop) or the normalised rows (reference order)
     if ((rc = local.alloc(std::max<uint64_t>(s->local_rows, 1) * (uint64_t)d * 4)) != CLEORA_OK) return rc;
     const float rw = residual_weight;

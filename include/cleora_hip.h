@@ -147,8 +147,8 @@ int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
  * buffer it gathers from and the buffer it writes fall into the same physical placement class of the HBM (DESIGN.md
  * §3.1; not visible in virtual addresses; box-dependent).  Allocates `count` buffers of max(n_rows, n_cols) x d floats: bufs[0]
  * first, then each partner by TIMING the real kernel on candidates (gathers from bufs[0], writes the candidate; a candidate's time
- * is the median of three launches): the first candidate is kept unless another is >= 3 % faster; at most 3 candidates per slot and
- * none once CLEORA_PLACEMENT_BUDGET_MS = 1500 ms of wall clock are spent.  cleora_alloc_iterates_for also takes the number of SpMM
+ * is the median of three launches) until the best is >= 4 % faster than the slowest seen (at most 4 per slot, none once
+ * CLEORA_PLACEMENT_BUDGET_MS = 1500 ms of wall clock are spent); the best is taken (the first candidate when the best is within 1 % of it).  cleora_alloc_iterates_for also takes the number of SpMM
  * launches the caller is about to run (0 = unknown) and stops searching when the most it could win — 15 % of a launch per
  * iteration — is less than trying another candidate costs (three launches + freeing the loser, ~30 ms per GB): the embed loops
  * call it that way.  Use bufs[0] as the buffer EVERY SpMM of the loop touches: ping-pong = the pair (bufs[0], bufs[1]); the

@@ -119,9 +119,12 @@ import hashlib
 _h = hashlib.sha256()
 for rel in ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/row_epilogue.h", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h"):   # = bench.py KERNEL_SOURCES
     _h.update(open(os.path.join(os.path.dirname(dst), rel), "rb").read())
+# one SpMM = the main launch + the in-order hub launch beside it + the hub rows' epilogue (spmm.hip): their bytes together
+hub = {k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items() if k.startswith("hub_inorder_kernel") or k.startswith("hub_epilogue_kernel")}
 json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"{tag}_pmc.json",
            "kernel_source_sha16": _h.hexdigest()[:16],
-           "bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"]},
+           "main_kernel_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"], "hub_kernels_bytes_per_launch": hub,
+           "bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"] + sum(hub.values())},
           open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 

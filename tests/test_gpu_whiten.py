@@ -312,7 +312,7 @@ def test_intermediate_gram_from_the_bf16_matrix_cores(n, d):
 
 def test_overlapped_loop_recomputes_the_statistics_when_the_guard_refuses_them():
     """The intermediate iterations take their statistics from the bf16 matrix cores (~1e-8 of the f64 Gram) and the Cholesky
-    transform — but only while sum_i (trace(cov) / d) / lambda_i <= 1e5 (csrc/eigh.hip, ADVICE round 3: in a direction of variance
+    transform — but only while sum_i (trace(cov) / d) / lambda_i <= 1e4 (csrc/eigh.hip kMaxRelativeSpread, ADVICE round 3: in a direction of variance
     lambda such a Gram is off by ~2e-8 (trace / d) / lambda).  A start whose last 16 columns are scaled by 1e-3 gives the FIRST
     whitening a covariance with 16 eigenvalues near 1e-6 of the rest: the clamp (1e-10) is inactive, the relative spread is 1.6e7 —
     the loop must take that iteration's statistics again in f64 and the PCA form, and still agree with the reference's order."""

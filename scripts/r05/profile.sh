@@ -8,7 +8,7 @@ root=$(cd "$(dirname "$0")/../.." && pwd)
 out=$root/gpurun_out/prof_r05
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-TLB="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"
+TLB="TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum GRBM_UTCL2_BUSY GRBM_GUI_ACTIVE"
 case $part in
 stats)
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python "$root/bench.py" --no-cpu-baseline --whiten-iters 0 --no-end-to-end > "$out/bench_stats.log" 2>&1

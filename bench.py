@@ -827,7 +827,7 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
                      "algorithmic_bytes_per_launch": avg_bytes, "avg_launch_ms": avg_ms, "launches": calls,
                      "gather_cache_policy_hot_rows": hot_rows,
                      "main_kernel_ms_per_launch": rows_ms / max(calls, 1),
-                     "fork_and_join_of_the_hub_launch_ms_per_launch": other_ms / max(calls, 1),
+                     "fork_and_join_of_the_hub_launch_ms_per_launch": other_ms / max(calls, 1),   # (the sharded loops join the hub launch at the block's gather or the end of the call: csrc/sharded.hip)
                      "timing": "HIP events on the launch stream around [fork | main kernel | join]: the span of the main launch and the in-order hub launch "
                                "(side stream) together; achieved = the gather model's bytes of ALL edges and rows / that span",
                      "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,

@@ -101,7 +101,9 @@ namespace cleora {
 int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                      float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
                      double *row_sqdiff, float *row_sumsq, hipStream_t stream,
-                     const float *val_override = nullptr);   // per-edge values replacing g->val[kind]
+                     const float *val_override = nullptr,    // per-edge values replacing g->val[kind]
+                     hipEvent_t *hub_join_out = nullptr);    // non-NULL: the in-order hub launch is NOT joined into `stream`; *hub_join_out is the
+                                                             // event to wait for before the hub rows of y are read (nullptr: nothing pending)
 int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y, uint64_t ldy,
                   uint32_t flags, float rw, const float *x_self, double *row_sqdiff,
                   float *row_sumsq, hipStream_t stream, uint64_t ldxs = 0);  // ldxs: leading dimension of x_self (0 = ldx)

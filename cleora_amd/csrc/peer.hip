@@ -442,7 +442,18 @@ int peer_register(cleora_comm *c, void *buf, uint64_t bytes) {
     CL_REQUIRE(c->peer != nullptr, "the peer transport is not enabled on this communicator");
     CL_REQUIRE(buf != nullptr && bytes > 0, "buf is NULL / empty");
     PeerLayer *pl = c->peer;
-    if (Registration *r = find_registration(pl, buf, bytes)) { (void)r; return CLEORA_OK; }
+    // Registering is collective, so "already registered" must be a decision every rank takes alike: only the SAME buffer (address and
+    // size) counts — the same call repeated on every rank.  A buffer that merely lies inside, or overlaps, an existing registration
+    // (a freed allocation whose address came back on some ranks, a sub-buffer) would make this rank skip the exchange the others
+    // enter: refused instead.
+    const char *b0 = static_cast<const char *>(buf);
+    for (const Registration &r : pl->regs) {
+        if (r.local == b0 && r.bytes == bytes) return CLEORA_OK;
+        if (b0 < r.local + r.bytes && r.local < b0 + bytes) {
+            set_error("peer transport: the buffer overlaps a registered one without being it; unregister that one first (cleora_comm_unregister)");
+            return CLEORA_E_INVALID;
+        }
+    }
     CL_HIP(hipSetDevice(c->device));
     Registration reg;
     if (c->world > 1) {
@@ -486,7 +497,9 @@ int peer_allgatherv_f32(cleora_comm *c, float *buf, const uint64_t *offsets, hip
         const uint64_t byte_off = (uint64_t)(reinterpret_cast<char *>(buf + offsets[me]) - reg->local);
         PeerPtrs dst{};
         for (int k = 1; k < P; ++k) dst.p[k - 1] = reg->peer[(me + k) % P] + byte_off;       // staggered: rank r starts with r + 1
-        const bool vec4 = (byte_off & 15u) == 0 && (reinterpret_cast<uintptr_t>(reg->local) & 15u) == 0;
+        bool vec4 = (byte_off & 15u) == 0 && (reinterpret_cast<uintptr_t>(reg->local) & 15u) == 0;
+        for (int p = 0; p < P; ++p)                                                          // the peers' mapped copies need not be aligned like ours
+            if (p != me && (reinterpret_cast<uintptr_t>(reg->peer[p]) & 15u) != 0) vec4 = false;
         const uint64_t units = vec4 ? (mine + 3) / 4 : mine;
         uint64_t bx = (units + 255) / 256;
         if (bx > 160) bx = 160;                                                              // bandwidth-bound on the links: a few blocks per CU in total

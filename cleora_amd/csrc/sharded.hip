@@ -154,13 +154,17 @@ hipEvent_t timing_event(cleora_sharded *s) {
 
 // the exchange of step k: rows [bounds[kP], bounds[(k+1)P]) of `buf` (a replica, ld = d), on the communication stream,
 // after everything enqueued on `stream` so far
-int gather_step(cleora_sharded *s, float *buf, uint32_t d, uint32_t k, hipStream_t stream) {
-    if (s->world == 1) return CLEORA_OK;
+int gather_step(cleora_sharded *s, float *buf, uint32_t d, uint32_t k, hipStream_t stream, hipEvent_t hub_join = nullptr) {
+    if (s->world == 1) {
+        if (hub_join) CL_HIP(hipStreamWaitEvent(stream, hub_join, 0));
+        return CLEORA_OK;
+    }
     const int P = s->world;
     s->offsets.resize((size_t)P + 1);
     for (int r = 0; r <= P; ++r) s->offsets[r] = s->bounds[(size_t)k * P + r] * (uint64_t)d;
     CL_HIP(hipEventRecord(s->ev_fork, stream));
     CL_HIP(hipStreamWaitEvent(s->comm_stream, s->ev_fork, 0));
+    if (hub_join) CL_HIP(hipStreamWaitEvent(s->comm_stream, hub_join, 0));   // the block's hub rows (in-order launch on its side stream)
     hipEvent_t t0 = s->timing ? timing_event(s) : nullptr;
     if (t0) CL_HIP(hipEventRecord(t0, s->comm_stream));
     const int rc = cleora_allgatherv_f32_dev(s->comm, buf, s->offsets.data(), s->comm_stream);
@@ -184,17 +188,25 @@ int join(cleora_sharded *s, hipStream_t stream) {
 // one iteration (see cleora_sharded_propagate_dev); y_local != nullptr: block k's rows go to y_local + first_local * d instead of x_next
 int propagate_blocks(cleora_sharded *s, int kind, const float *x, float *x_next, float *y_local, uint32_t d, uint32_t flags, float rw,
                      double *row_sqdiff, bool gather, hipStream_t stream) {
+    // A block's in-order hub launch (its longest row is a chain of dependent adds: milliseconds) is joined where its rows are
+    // needed — the block's gather, or the end of the call — not before the NEXT block's launch: with P ranks a block's main kernel is
+    // 1/P-th of an iteration, and waiting for every block's longest chain in turn would put the chains on the critical path.
+    std::vector<hipEvent_t> open_joins;
     for (uint32_t k = 0; k < s->steps; ++k) {
         const auto &b = s->blocks[k];
         float *out = y_local ? y_local + b.first_local * d : x_next + b.b0 * (uint64_t)d;
+        hipEvent_t hub_join = nullptr;
         const int rc = launch_propagate(b.g, kind, x, d, d, out, d, flags, rw, x + b.b0 * (uint64_t)d, row_sqdiff ? row_sqdiff + b.first_local : nullptr,
-                                        nullptr, stream);
+                                        nullptr, stream, nullptr, &hub_join);
         if (rc != CLEORA_OK) return rc;
-        if (gather && !y_local) {
-            const int rg = gather_step(s, x_next, d, k, stream);
+        if (gather && !y_local && s->world > 1) {
+            const int rg = gather_step(s, x_next, d, k, stream, hub_join);
             if (rg != CLEORA_OK) return rg;
+        } else if (hub_join) {
+            open_joins.push_back(hub_join);
         }
     }
+    for (hipEvent_t e : open_joins) CL_HIP(hipStreamWaitEvent(stream, e, 0));
     return join(s, stream);
 }
 

@@ -617,7 +617,7 @@ int ensure_hub_stream(const cleora_graph *g) {
 }
 
 // One SpMM over a column panel that fits the register-resident shapes.
-int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, hipStream_t stream) {
+int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, hipStream_t stream, hipEvent_t *hub_join_out = nullptr) {
     const uint32_t d = a.r.d;
     bool ok = true;
     const bool inorder = g->n_hub_rows && !segmented;
@@ -666,7 +666,10 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, 
     }
     mark(g, stream);
     if (inorder) {
-        CL_HIP(hipStreamWaitEvent(stream, g->hub_join, 0));
+        // the caller may take the join itself (sharded.hip: only the gather of this block — and the next iteration — need the hub
+        // rows, so the next block's launch need not wait for this block's longest chain)
+        if (hub_join_out) *hub_join_out = g->hub_join;
+        else CL_HIP(hipStreamWaitEvent(stream, g->hub_join, 0));
     } else if (ok && g->n_hub_rows) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
             hipLaunchKernelGGL((hub_finish_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
@@ -686,8 +689,9 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, 
 
 int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t ldx, uint32_t d,
                      float *y, uint64_t ldy, uint32_t flags, float rw, const float *x_self,
-                     double *row_sqdiff, float *row_sumsq, hipStream_t stream, const float *val_override) {
+                     double *row_sqdiff, float *row_sumsq, hipStream_t stream, const float *val_override, hipEvent_t *hub_join_out) {
     CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    if (hub_join_out) *hub_join_out = nullptr;
     if (!val_override) {
         CL_REQUIRE(kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC, "unknown markov_type");
         CL_REQUIRE(g->val[kind] != nullptr, "graph has no values for this markov_type");
@@ -743,7 +747,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
 
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
                     (!x_self || aligned16(x_self));
-    if (d <= (w4 ? kMaxD4 : kMaxD1)) return propagate_panel(g, a, w4, segmented, stream);
+    if (d <= (w4 ? kMaxD4 : kMaxD1)) return propagate_panel(g, a, w4, segmented, stream, hub_join_out);
 
     // Wider rows: SpMM column panel by column panel without the epilogue, then the wide row pass.
     const uint32_t panel = w4 ? kMaxD4 : kMaxD1;

@@ -127,27 +127,32 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
         return graph.embed_fast(feature_dim, num_iterations, propagation=propagation, seed=seed,
                                 residual_weight=residual_weight)
 
+    x0 = None
     if initial_embeddings is not None:                    # :100-105
         x0 = np.ascontiguousarray(np.asarray(initial_embeddings).astype(np.float32))
         if x0.shape[0] != n:
             raise ValueError(f"initial_embeddings has {x0.shape[0]} rows but graph has {n} entities")
-    else:
+    one_call = whiten and callback is None and normalization in ("l2", "l1")
+    if x0 is None and not (one_call and n > 0 and int(feature_dim) > 0 and num_iterations > 0):
         x0 = graph.initialize_deterministically(feature_dim, seed)
-    d = x0.shape[1]
+    d = x0.shape[1] if x0 is not None else int(feature_dim)
     if n == 0 or d == 0 or num_iterations <= 0:
         return x0
 
-    if whiten and callback is None and normalization in ("l2", "l1"):
+    if one_call:
         # the default loop as ONE C-ABI call (cleora_embed + CLEORA_F_WHITEN): nobody looks at the intermediate
-        # iterates, so the library may run the SpMM of iteration t+1 beside the Gram / eigensolver of iteration t
+        # iterates, so the library may run the SpMM of iteration t+1 beside the Gram / eigensolver of iteration t.
+        # Without initial_embeddings E_0 is made ON the device from the entity hashes (init_value, src/lib.rs:478-488: bit-equal to
+        # initialize_deterministically) — it does not travel to the host and back (10 GB each way at |V| = 10M, d = 256).
         out = np.empty((n, d), np.float32)
         ran = ctypes.c_uint64(0)
         flags = _hip.F_WHITEN | (_hip.F_L1NORM if normalization == "l1" else 0)
+        hashes = graph._arr["hashes"] if x0 is None else None
         with graph._lock:
             m = graph._multi()
             if m is not None:                        # several devices configured (cleora_amd.install(devices=...)): the row partition
-                return m.embed(None, x0, kind, d, int(num_iterations), 0, float(residual_weight), float(max(convergence_threshold, 0.0)), flags)[0]
-            _hip.check(L.cleora_embed(graph._graph().handle, None, _hip.ptr(x0), kind, d, int(num_iterations), 0,
+                return m.embed(hashes, x0, kind, d, int(num_iterations), int(seed), float(residual_weight), float(max(convergence_threshold, 0.0)), flags)[0]
+            _hip.check(L.cleora_embed(graph._graph().handle, _hip.ptr(hashes), _hip.ptr(x0), kind, d, int(num_iterations), int(seed),
                                       float(residual_weight), float(max(convergence_threshold, 0.0)), flags,
                                       _hip.ptr(out), ctypes.byref(ran)))
         return out

@@ -53,7 +53,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s meas
 F32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = the f32 vector rate
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16 measured 2495 TF)
 F64_MFMA_PEAK_TF = 78.6     # AMD's MI355X datasheet figure for FP64 matrix (the guide lists none); the measured
-                            # ceiling of v_mfma_f64_16x16x4_f64 on this chip is in DESIGN.md §3.5 (scripts/mfma_peak.hip)
+                            # ceiling of v_mfma_f64_16x16x4_f64 on this chip is in docs/history.md §3.5 (scripts/mfma_peak.hip)
 KERNEL_SOURCES = ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/row_epilogue.h", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h")
 
 
@@ -1013,7 +1013,7 @@ def main():
     ap.add_argument("--balance", default="auto", choices=["auto", "rows", "nnz"],
                     help="row partition: equal row counts, or balanced on the rowptr prefix sum")
     ap.add_argument("--no-placement", action="store_true",
-                    help="plain allocations for the iterates instead of cleora_alloc_iterates (DESIGN.md §3.1)")
+                    help="plain allocations for the iterates instead of cleora_alloc_iterates (DESIGN.md §2.1)")
     ap.add_argument("--whiten-iters", type=int, default=8, help="iterations of the whitened default loop (N = 1); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the wall clock of the drop-in calls (embed_fast / embed, 40 iterations, host in / host out)")

@@ -576,7 +576,7 @@ int alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, uint64_t i
         return CLEORA_OK;
     }
     // The same SpMM launch has been measured up to 12-20 % slower when the buffer it reads and the buffer it writes fall into
-    // the same (physical) placement class (DESIGN.md 3.1) — on some boxes; on others every pair runs alike.  bufs[0] is fixed;
+    // the same (physical) placement class (DESIGN.md §2.1) — on some boxes; on others every pair runs alike.  bufs[0] is fixed;
     // a partner is searched by timing the real kernel.  What round 4's driver run showed (VERDICT weak #5): ONE launch per
     // candidate cannot resolve a 1 % difference from launch noise, and the search itself costs (freeing a rejected 10 GB
     // candidate is ~0.3 s on this driver).  So:
@@ -803,7 +803,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     } st;
     // Stream a: SpMM and projection; stream b (higher priority: its few hundred resident blocks are dispatched at once, the
     // SpMM's millions of short blocks fill what is left): statistics and the d x d step.
-    // What round 3's measurements settled (the switches they were taken with are gone from the library):
+    // What round 3's measurements settled (docs/history.md §3.8; the switches they were taken with are gone from the library):
     //   * the loop is the SUM of its kernels — a SIMD that holds a busy matrix-core wave gives the SpMM waves beside it next
     //     to nothing, and whatever shares the chip with the SpMM waits 10-16 us per memory request;
     //   * so when the statistics take the split-bf16 form (8 waves per CU, every matrix pipe busy) they run strictly BEFORE
@@ -1013,7 +1013,7 @@ static int embed_impl(const cleora_graph *g, const uint64_t *entity_hash_host, c
             return rc;
     }
     // Placement tuning on the job's own iterations (large iterates only): the SpMM runs up to 12 %
-    // slower when the two ping-pong allocations fall into the same placement class (DESIGN.md §3.1).
+    // slower when the two ping-pong allocations fall into the same placement class (DESIGN.md §2.1).
     // Buffer `a` stays; the partner buffer is re-drawn every two iterations (a -> c, c -> a, timed
     // with events) until a pair is >= 5 % faster than the slowest pair seen, 4 partners were tried, or the remaining
     // iterations could no longer repay a rejected candidate; the best partner is kept.  Every trial iteration is a real

@@ -13,7 +13,7 @@
 //   cleora_sharded_propagate_dev   one iteration: x_next <- epilogue(A x), replicated (block k's gather beside block k+1's SpMM)
 //   cleora_embed_sharded      the loops: embed_full / embed_full_with_convergence (src/embedding.rs:106-188) and — with
 //                             CLEORA_F_WHITEN — the default embed() loop (pycleora/__init__.py:109-117) in the reorganised form
-//                             of the single-GPU loop (abi.hip embed_whitened_overlapped) or in the reference's order
+//                             of the single-GPU loop (abi.hip embed_whitened_overlapped; docs/history.md §3.7-3.8) or in the reference's order
 //
 // Layout.  With P ranks and K steps per iteration the row space is cut into P*K contiguous blocks (equal row counts, or
 // balanced on the rowptr prefix sum for graphs whose ids are ordered by degree); rank r owns blocks {k*P + r}.  Step k
@@ -689,7 +689,7 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
         const uint64_t Pw = (uint64_t)s->world;
         const bool split_stats = n >= 2 * Pw && gram32_applies(y, d, (n + Pw - 1) / Pw, d);
         for (uint64_t it = 0; it + 1 < max_iterations; ++it) {
-            // the statistics first (alone on the chip: DESIGN 3.8), then Z = A Y on a second stream beside the all-reduces and the
+            // the statistics first (alone on the chip: docs/history.md §3.8), then Z = A Y on a second stream beside the all-reduces and the
             // d x d step (the host blocks there), the projection when both are through
             if ((rc = replicated_stats(s, y, d, st, true, stream)) != CLEORA_OK) return rc;
             CL_HIP(hipEventRecord(s->ev_side, stream));

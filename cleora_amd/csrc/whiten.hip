@@ -14,7 +14,7 @@
 //     shared through LDS; optional row normalisation in the epilogue (the reorganised loop of abi.hip / sharded.hip).
 //     project_kernel: v_mfma_f32_32x32x2_f32, LDS-tiled, any shape (d not a multiple of 32).
 //
-// All are matrix-core work (2 n d^2 flops against 1-3 passes over X), unlike the SpMM; DESIGN.md 3.5 / 3.6 have what bounds each.
+// All are matrix-core work (2 n d^2 flops against 1-3 passes over X), unlike the SpMM; docs/history.md §3.5 / 3.6 have what bounds each.
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>

@@ -20,7 +20,7 @@
  *   - matrices are row-major f32 with a leading dimension in ELEMENTS (ld >= d).
  *   - threads: every entry point may be called from any thread; calls on one graph handle are
  *     serialised by a mutex inside the handle while they enqueue.  A handle owns device scratch
- *     (hub-row partial sums, timing events), so launches on the SAME handle must be ordered on the
+ *     (the hub rows' sums, its side stream, timing events), so launches on the SAME handle must be ordered on the
  *     device too — use one stream per handle (or the default stream); different handles are independent.
  *   - there is no CPU fallback: without a gfx950 device every compute entry point
  *     fails with CLEORA_E_NODEVICE / CLEORA_E_HIP.
@@ -75,8 +75,8 @@ typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct S
 
 typedef struct cleora_graph_info {
     uint64_t n_rows, n_cols, nnz;
-    uint64_t n_hub_rows;      /* rows longer than hub_threshold: split across waves */
-    uint64_t n_hub_segments;
+    uint64_t n_hub_rows;      /* rows longer than hub_threshold: summed by the in-order hub launch (spmm.hip hub_inorder_kernel) */
+    uint64_t n_hub_segments;  /* their hub_segment-edge segments (the CLEORA_F_HUB_SEGMENTS form) */
     uint64_t device_bytes;    /* HBM held by the handle */
     uint64_t hot_rows;        /* rows the gather cache policy currently keeps cacheable; 0 = policy inactive */
     uint32_t hub_threshold, hub_segment;
@@ -111,8 +111,9 @@ int cleora_stream_wait_stream(void *waiter, void *signaller);
  * col u32[nnz], one f32[nnz] stream per MarkovType (val_sym may be NULL).
  * Rows are the OUTPUT rows of this shard (all rows on one GPU; a row block when the graph
  * is row-partitioned); col indexes the n_cols rows of the full embedding matrix.
- * hub_threshold: rows with more edges are split into hub_segment-edge segments that run
- * on separate wavefronts (0 = defaults 1024 / 256).  Copies the arrays; the caller keeps
+ * hub_threshold: rows with more edges are hub rows — summed in the reference's order by a launch of their own beside the main one
+ * (one wavefront per 64-column slab), or, with CLEORA_F_HUB_SEGMENTS, as hub_segment-edge segments on separate wavefronts
+ * (0 = defaults 1024 / 256).  Copies the arrays; the caller keeps
  * ownership of its buffers. */
 int cleora_graph_create(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
                         const uint64_t *rowptr, const uint32_t *col, const float *val_left,
@@ -138,8 +139,9 @@ int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes);
 /* Per-kernel timing for roofline reporting (no reference counterpart).  While enabled, every
  * cleora_propagate_dev call on this graph brackets its three kernels with HIP events on the
  * launch stream.  cleora_graph_get_timing waits for the recorded events, returns the summed
- * durations in milliseconds — ms[0] hub_partial, ms[1] spmm_rows (the dominant kernel),
- * ms[2] hub_finish — and the number of calls they cover, then resets the record. */
+ * durations in milliseconds — ms[0] the fork of the in-order hub launch onto its side stream, ms[1] spmm_rows (the dominant kernel,
+ * with the hub launch beside it), ms[2] the join (with CLEORA_F_HUB_SEGMENTS: hub_finish_kernel) — and the number of calls they
+ * cover, then resets the record.  ms[0] + ms[1] + ms[2] = the span of one SpMM on the launch stream. */
 int cleora_graph_set_timing(cleora_graph *g, int enable);
 int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
 
@@ -429,7 +431,7 @@ int cleora_sharded_set_timing(cleora_sharded *s, int enable);
 int cleora_sharded_get_timing(cleora_sharded *s, double ms[2], uint64_t *calls);
 /* The loops over the partition, x_replica (n_pad x d): E_0 in, result out, replicated; synchronous.
  *   flags without CLEORA_F_WHITEN: embed_full / embed_full_with_convergence (src/embedding.rs:106-188) — bit-equal to the one-GPU
- *     loop on rows that are not split;
+ *     loop (every row, hub rows included);
  *   with CLEORA_F_WHITEN: the default loop of pycleora.embed() (pycleora/__init__.py:109-117).  L2 norm and no convergence test: the
  *     reorganised form of cleora_embed (SpMM before the projection, Cholesky whitening in the intermediate iterations behind the clamp
  *     guard, normalisation in the projection's epilogue): Z = A Y on the rank's rows beside the statistics of Y (every rank one
@@ -527,7 +529,7 @@ int cleora_whiten(const float *x_host, uint64_t n, uint32_t d, uint32_t n_compon
  * ANY rw > 0 (:111-115 — unlike the Rust loop's 0 < rw < 1), L2 normalise (L1 with CLEORA_F_L1NORM), THEN
  * whiten_embeddings; the RMSE of the early stop is taken between whitened iterates in f64 (:122-125, :974-976).
  * Without a convergence test nobody sees the intermediate whitened iterates, and the loop is reorganised without changing
- * what it computes: (1) the SpMM is linear, so A ((Y - 1 mu^T) T) is taken as (A Y - (A 1) mu^T) T — the
+ * what it computes (docs/history.md §3.7-3.8): (1) the SpMM is linear, so A ((Y - 1 mu^T) T) is taken as (A Y - (A 1) mu^T) T — the
  * SpMM of the next iteration is enqueued beside the Gram matrix / d x d step of this one, and the projection normalises its
  * output rows in its own epilogue; (2) with the L2 norm, intermediate iterations may use ANY whitening transform (two differ by
  * an orthogonal factor that the linear steps, the rotation-invariant norm and the final PCA whitening remove): Cholesky

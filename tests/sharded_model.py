@@ -177,7 +177,7 @@ class ShardedGraph:
 
 def embed_whitened_sharded(sg, kind, x0, iterations, residual_weight=0.0):
     """The default embed() loop (pycleora/__init__.py:109-117, L2 normalisation, no convergence test) over a ShardedGraph in
-    the reorganised form of the single-GPU library loop (csrc/abi.hip embed_whitened_overlapped):
+    the reorganised form of the single-GPU library loop (csrc/abi.hip embed_whitened_overlapped, docs/history.md §3.7-3.8):
 
         Y_0 = normalise(A E_0 [+ blend]);   per iteration:  Z = A Y (row blocks, no epilogue) | statistics of Y
         -> all-reduce (d + d*d doubles) -> replicated transform: Cholesky form while the reference's eigenvalue clamp is

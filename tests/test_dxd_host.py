@@ -1,6 +1,6 @@
 """The d x d step of the intermediate whitened iterations on the HOST (csrc/dxd_host.cpp, cleora_cholesky_whiten_host): plain host
 math inside the HIP library, so it is checked here without a GPU.  Reference operation: the transform of whiten_embeddings
-(pycleora/__init__.py:145-156); inside the loop any W with W^T C W = I serves, and this one is W = L^-T."""
+(pycleora/__init__.py:145-156); inside the loop any W with W^T C W = I serves (docs/history.md §3.7), and this one is W = L^-T."""
 import ctypes
 
 import numpy as np
@@ -39,7 +39,7 @@ def test_host_cholesky_whitens_like_lapack(d):
 
 
 def test_host_cholesky_verdicts():
-    """The guard of DESIGN 3.7 on the host: lambda_min = 1e-9 is accepted, 5e-11 is not (trace(cov^-1) > 0.999e10 although
+    """The guard of docs/history.md §3.7 on the host: lambda_min = 1e-9 is accepted, 5e-11 is not (trace(cov^-1) > 0.999e10 although
     every squared pivot is >= 1e-8), an indefinite and a NaN matrix are not, bad arguments are refused."""
     d, n = 64, 1000
     q, _ = np.linalg.qr(np.random.default_rng(1).standard_normal((d, d)))

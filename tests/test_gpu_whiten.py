@@ -274,7 +274,7 @@ def test_intermediate_gram_from_the_bf16_matrix_cores(n, d):
       from 2^20 rows:       THREE — (1,1) (1,2) (2,1) of a two-way split — plus the systematic r1^2 term of the diagonal accumulated on
                             the vector unit; what they drop is random-signed per row and falls as sqrt(d) 2^-18 / sqrt(n) — stated <= 1e-7.
     Both: every diagonal entry to the same tolerance of the largest, and NO systematic bias of the variances: |mean relative diagonal
-    error| <= 2e-8 (dropping the r1^2 term would show as -6e-7; a long f32 accumulation chain on the bf16 MFMA as -1.3e-6: DESIGN 3.5).
+    error| <= 2e-8 (dropping the r1^2 term would show as -6e-7; a long f32 accumulation chain on the bf16 MFMA as -1.3e-6: docs/history.md §3.5).
     Mean: 1e-12 for the f64 form; the split forms centre in f32 (y = x - c32, one rounding of 3e-8 |y|): <= 1e-8."""
     L = _hip.lib()                                             # n: not a multiple of the 32-row stage or of the slice count
     rng = np.random.default_rng(8)

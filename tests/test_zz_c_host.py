@@ -87,7 +87,7 @@ def test_c_host_whitened_loop(tmp_path):
     the solver's, so columns are sign-aligned; 1e-4 relative.
     Slow on a freshly provisioned box (200 s measured): the first dsyevd of the process pages in the 931 MB system
     librocsolver.so.  The intermediate iterations take the in-house Cholesky kernel here (no rocBLAS in this process);
-    with rocSOLVER's potrf/trtri the same test took 556 s."""
+    with rocSOLVER's potrf/trtri the same test took 556 s (docs/history.md §3.7)."""
     from cleora_amd import embed as dev_embed
     from cleora_amd.pycleora import SparseMatrix
     build_example()

@@ -257,43 +257,50 @@ def cpu_baseline_row_block(g, x_dev, n, d, rows=500_000, budget_s=20.0):
                       f"(reference AoS edge layout, SpMM + L2), {el:.1f} s; the whole graph is {g['nnz']} edges"}
 
 
-def sampled_row_check(g, x_dev, y_dev, n, d, hub_threshold, rows=4096, seed=11):
+def sampled_row_check(g, x_dev, y_dev, n, d, hub_threshold, rows=4096, seed=11, hub_rows=24):
     """Parity check that scales to graphs whose iterate does not fit a host-side oracle run (config 4's size: X is 114 GB):
-    `rows` random unsplit rows of the GPU's iteration y = l2_normalise(A x) recomputed on the host in the reference's order —
-    acc += v * x[c] edge by edge in stored order with separate f32 multiply and add (src/embedding.rs:80-82), the sum of squares
-    in index order, v * (1 / max(sqrt(s), 1e-10)) (src/embedding.rs:94-102) — from exactly the X rows those edges touch
-    (gathered on the device, copied once).  Every compared row must be bit-equal."""
+    `rows` random rows AND the `hub_rows` longest rows (hub rows: the in-order hub launch) of the GPU's iteration
+    y = l2_normalise(A x), recomputed by the oracle (oracle.spmm_aos_l2_inplace: acc += v * x[c] edge by edge in stored order with
+    separate f32 multiply and add, the sum of squares in index order, v * (1 / max(sqrt(s), 1e-10)): src/embedding.rs:76-102) on a
+    compact sub-problem — exactly the X rows those edges touch, gathered on the device and copied once.  Every compared row must be
+    bit-equal."""
+    import oracle
     gen = torch.Generator(device="cpu")
     gen.manual_seed(seed)
-    cand = torch.randint(0, n, (rows * 2,), generator=gen).unique()
     rp = g["rowptr"]
-    cand_d = cand.to(rp.device)
-    deg = (rp[cand_d + 1] - rp[cand_d]).cpu()
-    pick = cand[(deg <= hub_threshold) & (deg > 0)][:rows]
+    deg_all = torch.diff(rp)
+    longest = torch.topk(deg_all, min(hub_rows, n)).indices.cpu()
+    cand = torch.cat([torch.randint(0, n, (rows * 2,), generator=gen), longest]).unique()
+    deg = deg_all[cand.to(rp.device)].cpu()
+    is_long = torch.isin(cand, longest)
+    keep = (deg > 0) & (is_long | (torch.cumsum((~is_long).long(), 0) <= rows))
+    pick = cand[keep]
     pick_d = pick.to(rp.device)
-    beg, end = rp[pick_d].cpu().numpy(), rp[pick_d + 1].cpu().numpy()
-    idx = torch.cat([torch.arange(int(b), int(e)) for b, e in zip(beg, end)]).to(rp.device)
+    beg, end = rp[pick_d], rp[pick_d + 1]
+    cnt = (end - beg)
+    sub_rp = torch.zeros(len(pick) + 1, dtype=torch.int64, device=rp.device)
+    sub_rp[1:] = torch.cumsum(cnt, 0)
+    # edge indices of the picked rows, in order
+    total = int(sub_rp[-1])
+    row_of = torch.repeat_interleave(torch.arange(len(pick), device=rp.device), cnt)
+    idx = beg[row_of] + (torch.arange(total, device=rp.device) - sub_rp[row_of])
     cols = g["col"][idx].long()
-    vals = g["val_left"][idx].cpu().numpy()
     ucols, inv = torch.unique(cols, return_inverse=True)
     xs = x_dev[ucols].cpu().numpy()                       # only the rows these edges gather
-    inv = inv.cpu().numpy()
+    edges = np.empty(total, dtype=oracle.EDGE_DTYPE)
+    edges["col"] = inv.cpu().numpy().astype(np.uint32)
+    edges["left"] = g["val_left"][idx].cpu().numpy()
+    edges["sym"] = 0.0
+    want = np.empty((len(pick), d), np.float32)
+    oracle.spmm_aos_l2_inplace(sub_rp.cpu().numpy().astype(np.uint64), edges, False, xs, want, oracle.max_threads())
     got = y_dev[pick_d].cpu().numpy()
-    equal, pos = 0, 0
-    for k in range(len(pick)):
-        cnt = int(end[k] - beg[k])
-        acc = np.zeros(d, np.float32)
-        for j in range(pos, pos + cnt):
-            acc += np.float32(vals[j]) * xs[inv[j]]       # numpy f32: one rounding for the product, one for the sum
-        pos += cnt
-        ssq = np.float32(0.0)
-        for v in acc * acc:
-            ssq = np.float32(ssq + v)
-        inv_norm = np.float32(1.0) / max(np.float32(np.sqrt(ssq)), np.float32(1e-10))
-        equal += int(np.array_equal((acc * inv_norm).view(np.uint32), got[k].view(np.uint32)))
-    return {"sampled_unsplit_rows_compared": int(len(pick)), "sampled_rows_bit_equal": equal,
-            "sampled_rows_edges": int(len(vals)), "note": "host recomputation in the reference's order of randomly chosen rows (the full oracle "
-                                                           "iteration is run when the iterate fits the host: see oracle_rows_compared)"}
+    same = (got.view(np.uint32) == want.view(np.uint32)).all(axis=1)
+    hub = (cnt.cpu().numpy() > hub_threshold)
+    return {"sampled_rows_compared": int(len(pick)), "sampled_rows_bit_equal": int(same.sum()),
+            "sampled_hub_rows_compared": int(hub.sum()), "sampled_hub_rows_bit_equal": int(same[hub].sum()),
+            "longest_row_edges": int(cnt.max()), "sampled_rows_edges": total,
+            "note": "the oracle's iteration (reference order) on a compact sub-problem of randomly chosen rows plus the longest rows (the full "
+                    "oracle iteration is run when the iterate fits the host: see oracle_rows_compared)"}
 
 
 def c_abi_communicator(local_rank, dev, rank, world, transport="rccl"):

@@ -30,6 +30,10 @@ struct cleora_multi {
     std::vector<cleora_sharded *> shards;
     std::vector<hipStream_t> streams;
     std::vector<uint64_t> bounds;          // world * steps + 1 row boundaries (padded row space)
+    // per shard: device staging of the host-pointer calls, kept between calls and grow-only like cleora_propagate's (what the
+    // reference's unmodified embed() loop calls 40 times; freeing 10 GB costs ~0.3 s on this driver)
+    std::vector<void *> io[2];
+    std::vector<uint64_t> io_bytes[2];
     std::mutex mu;                         // one call at a time
     // the threads of a call meet here before they enter a collective: a rank that failed on its own (allocation, upload) must not
     // leave the others waiting inside one
@@ -51,6 +55,24 @@ struct DevMem {
     }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
+
+struct Borrowed {      // a staging buffer that stays with the handle
+    void *p = nullptr;
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+// shard p's staging buffer k of at least `bytes` (thread p only)
+int staging(cleora_multi *m, uint32_t p, int k, uint64_t bytes, void **out) {
+    if (m->io_bytes[k][p] < bytes || !m->io[k][p]) {
+        if (m->io[k][p]) CL_HIP(hipFree(m->io[k][p]));
+        m->io[k][p] = nullptr;
+        m->io_bytes[k][p] = 0;
+        CL_HIP(hipMalloc(&m->io[k][p], bytes ? bytes : 1));
+        m->io_bytes[k][p] = bytes;
+    }
+    *out = m->io[k][p];
+    return CLEORA_OK;
+}
 
 // true when every rank of the call arrived with ok = true
 bool gate(cleora_multi *m, bool ok) {
@@ -106,6 +128,8 @@ void free_multi(cleora_multi *m) {
     (void)run_all(m, [&](uint32_t p) {
         if (p < m->shards.size() && m->shards[p]) (void)cleora_sharded_destroy(m->shards[p]);
         if (p < m->streams.size() && m->streams[p]) { (void)hipStreamSynchronize(m->streams[p]); (void)hipStreamDestroy(m->streams[p]); }
+        for (int k = 0; k < 2; ++k)
+            if (p < m->io[k].size() && m->io[k][p]) (void)hipFree(m->io[k][p]);
         if (p < m->comms.size() && m->comms[p]) (void)cleora_comm_destroy(m->comms[p]);
         return CLEORA_OK;
     });
@@ -154,6 +178,7 @@ int cleora_multi_create(const int *device_ids, uint32_t n_devices, uint64_t n, u
     m->comms.assign(n_devices, nullptr);
     m->shards.assign(n_devices, nullptr);
     m->streams.assign(n_devices, nullptr);
+    for (int k = 0; k < 2; ++k) { m->io[k].assign(n_devices, nullptr); m->io_bytes[k].assign(n_devices, 0); }
     unsigned char id[CLEORA_COMM_ID_BYTES];
     int rc = cleora_comm_local_id(id);
     if (rc == CLEORA_OK)
@@ -234,9 +259,10 @@ int cleora_multi_embed(cleora_multi *m, const uint64_t *entity_hash_host, const 
     const uint64_t n = m->n, row_bytes = (uint64_t)d * 4;
     std::vector<uint64_t> ran(m->world, 0);
     const int rc = run_all(m, [&](uint32_t p) {
-        DevMem x, hashes;
+        DevMem hashes;
+        Borrowed x;
         hipStream_t st = m->streams[p];
-        int r = x.alloc(m->n_pad * row_bytes);
+        int r = staging(m, p, 0, m->n_pad * row_bytes, &x.p);
         if (r == CLEORA_OK && m->n_pad > n && hipMemsetAsync(x.as<char>() + n * row_bytes, 0, (m->n_pad - n) * row_bytes, st) != hipSuccess) {
             (void)hipGetLastError();
             set_error("hipMemsetAsync failed");
@@ -276,10 +302,10 @@ int cleora_multi_propagate(cleora_multi *m, int markov_type, const float *x_host
     std::lock_guard<std::mutex> lock(m->mu);
     const uint64_t n = m->n, row_bytes = (uint64_t)d * 4;
     return run_all(m, [&](uint32_t p) {
-        DevMem x, y;
+        Borrowed x, y;
         hipStream_t st = m->streams[p];
-        int r = x.alloc(m->n_pad * row_bytes);
-        if (r == CLEORA_OK) r = y.alloc(m->n_pad * row_bytes);
+        int r = staging(m, p, 0, m->n_pad * row_bytes, &x.p);
+        if (r == CLEORA_OK) r = staging(m, p, 1, m->n_pad * row_bytes, &y.p);
         if (r == CLEORA_OK && m->n_pad > n && hipMemsetAsync(x.as<char>() + n * row_bytes, 0, (m->n_pad - n) * row_bytes, st) != hipSuccess) {
             (void)hipGetLastError();
             set_error("hipMemsetAsync failed");

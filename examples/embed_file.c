@@ -6,7 +6,10 @@
  * device-resident embed loop (embed_fast, src/lib.rs:320-364; with --whiten the default path of
  * pycleora.embed(), pycleora/__init__.py:97-127) and write `entity_id<TAB>v0 v1 ...` lines.
  *
- *   embed_file [--whiten] [--symmetric] <columns> <dim> <iterations> <out.tsv> <edges.tsv> [more files]
+ *   embed_file [--whiten] [--symmetric] [--devices 0,1,...] <columns> <dim> <iterations> <out.tsv> <edges.tsv> [more files]
+ *
+ * --devices: the same loop with the graph row-partitioned over the listed devices INSIDE this process (cleora_multi_*,
+ * csrc/multi.hip: a host thread per device, peer-direct all-gather of the iterate between iterations); ids may repeat.
  *
  * Exit codes: 0 ok, 1 usage, 2 graph construction failed, 3 device library failed (e.g. no GPU: there is
  * no CPU fallback), 4 I/O.
@@ -25,14 +28,20 @@ static int fail_dev(const char *what) {
 
 int main(int argc, char **argv) {
     int whiten = 0, kind = CLEORA_LEFT, a = 1;
+    int devices[64];
+    uint32_t n_devices = 0;
     while (a < argc && strncmp(argv[a], "--", 2) == 0) {
         if (strcmp(argv[a], "--whiten") == 0) whiten = 1;
         else if (strcmp(argv[a], "--symmetric") == 0) kind = CLEORA_SYMMETRIC;
+        else if (strcmp(argv[a], "--devices") == 0 && a + 1 < argc) {
+            for (char *tok = strtok(argv[++a], ","); tok && n_devices < 64; tok = strtok(NULL, ",")) devices[n_devices++] = atoi(tok);
+            if (n_devices == 0) { fprintf(stderr, "embed_file: --devices needs a list like 0,1,2\n"); return 1; }
+        }
         else { fprintf(stderr, "embed_file: unknown option %s\n", argv[a]); return 1; }
         ++a;
     }
     if (argc - a < 5) {
-        fprintf(stderr, "usage: embed_file [--whiten] [--symmetric] <columns> <dim> <iterations> <out.tsv> <edges> [...]\n");
+        fprintf(stderr, "usage: embed_file [--whiten] [--symmetric] [--devices 0,1,...] <columns> <dim> <iterations> <out.tsv> <edges> [...]\n");
         return 1;
     }
     const char *columns = argv[a];
@@ -72,14 +81,24 @@ int main(int argc, char **argv) {
         fprintf(stderr, "embed_file: no HIP device visible; libcleora_hip has no CPU fallback\n");
         return 3;
     }
-    cleora_graph *g = NULL;
-    if (cleora_graph_create(0, n, n, nnz, rowptr, col, val_left, val_sym, 0, 0, &g) != CLEORA_OK)
-        return fail_dev("cleora_graph_create");
     uint64_t ran = 0;
-    if (n > 0 && cleora_embed(g, hashes, NULL, kind, dim, iterations, 0, 0.0f, 0.0f, whiten ? CLEORA_F_WHITEN : 0u,
-                              emb, &ran) != CLEORA_OK)
-        return fail_dev("cleora_embed");
-    cleora_graph_destroy(g);
+    if (n_devices > 0) {
+        /* one process, several devices: the row partition behind one handle (SURVEY 8b B2's graph handle with device_ids) */
+        cleora_multi *m = NULL;
+        if (cleora_multi_create(devices, n_devices, n, nnz, rowptr, col, val_left, val_sym, 0, CLEORA_BALANCE_AUTO, &m) != CLEORA_OK)
+            return fail_dev("cleora_multi_create");
+        if (n > 0 && cleora_multi_embed(m, hashes, NULL, kind, dim, iterations, 0, 0.0f, 0.0f, whiten ? CLEORA_F_WHITEN : 0u, emb, &ran) != CLEORA_OK)
+            return fail_dev("cleora_multi_embed");
+        cleora_multi_destroy(m);
+    } else {
+        cleora_graph *g = NULL;
+        if (cleora_graph_create(0, n, n, nnz, rowptr, col, val_left, val_sym, 0, 0, &g) != CLEORA_OK)
+            return fail_dev("cleora_graph_create");
+        if (n > 0 && cleora_embed(g, hashes, NULL, kind, dim, iterations, 0, 0.0f, 0.0f, whiten ? CLEORA_F_WHITEN : 0u,
+                                  emb, &ran) != CLEORA_OK)
+            return fail_dev("cleora_embed");
+        cleora_graph_destroy(g);
+    }
 
     /* 3. output */
     FILE *f = fopen(out_path, "w");

@@ -78,6 +78,11 @@ def test_c_host_matches_the_drop_in(tmp_path):
     np.testing.assert_array_equal(got, g.embed_fast(32, 5))
     run_example(["--symmetric", "complex::reflexive::n", "16", "3", str(out), str(edges)], env)
     np.testing.assert_array_equal(read_tsv(out)[1], g.embed_fast(16, 3, propagation="symmetric"))
+    # one process, several devices (cleora_multi_*, csrc/multi.hip) from plain C: three shards on the one GPU, same bits
+    run_example(["--devices", "0,0,0", "complex::reflexive::n", "32", "5", str(out), str(edges)], env)
+    ids, got = read_tsv(out)
+    assert ids == g.entity_ids
+    np.testing.assert_array_equal(got, g.embed_fast(32, 5))
 
 
 @pytest.mark.gpu

@@ -30,5 +30,6 @@ int peer_allreduce(cleora_comm *c, void *buf, uint64_t n, bool f64, hipStream_t 
 int peer_broadcast(cleora_comm *c, void *buf, uint64_t bytes, int root, hipStream_t stream);
 int peer_check(cleora_comm *c);                                    // CLEORA_E_RCCL if a wait ever timed out on this rank (reads the mailbox)
 int peer_host_barrier(cleora_comm *c);                             // the ranks' host threads meet (shared memory; bounded wait)
+void peer_abandon(cleora_comm *c);                                 // its host barriers stop waiting (teardown of a group that never became complete)
 
 }  // namespace cleora

@@ -124,7 +124,11 @@ int run_all(cleora_multi *m, const std::function<int(uint32_t)> &fn) {
 
 void free_multi(cleora_multi *m) {
     if (!m) return;
-    // (the communicators' teardown is collective: every rank on its own thread)
+    // (the communicators' teardown is collective: every rank on its own thread — unless the group never became complete)
+    bool complete = true;
+    for (cleora_comm *c : m->comms) complete = complete && (c != nullptr || m->world == 1);
+    if (!complete)
+        for (cleora_comm *c : m->comms) peer_abandon(c);
     (void)run_all(m, [&](uint32_t p) {
         if (p < m->shards.size() && m->shards[p]) (void)cleora_sharded_destroy(m->shards[p]);
         if (p < m->streams.size() && m->streams[p]) { (void)hipStreamSynchronize(m->streams[p]); (void)hipStreamDestroy(m->streams[p]); }

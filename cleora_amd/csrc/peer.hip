@@ -353,6 +353,12 @@ Registration *find_registration(PeerLayer *pl, const void *ptr, uint64_t bytes) 
 
 }  // namespace
 
+// the communicator will never see all of its ranks again (a partly built multi-device handle is being torn down): its host
+// barriers return at once instead of waiting out their budget for ranks that do not exist
+void peer_abandon(cleora_comm *c) {
+    if (c && c->peer) c->peer->poisoned = true;
+}
+
 int peer_host_barrier(cleora_comm *c) {
     if (!c->peer || c->world == 1) return CLEORA_OK;
     return barrier_host(c);

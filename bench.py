@@ -822,10 +822,12 @@ def run_partition(part, args, g, hashes, deg, dev, rank, world, comm, launcher, 
     norm_err = float((sumsq.sqrt() - 1).abs().max())
     hot_rows = int(blocks[0].info().hot_rows)      # gather cache policy (cleora_graph_set_hot_cache), 0 = inactive
     g_lanes = max(8, min(64, 1 << (max(dl // 4, 1) - 1).bit_length()))
-    n_hub_rows = sum(int(blk.info().n_hub_rows) for blk in blocks)
+    n_long = sum(int(blk.info().n_hub_rows) for blk in blocks)
+    n_io = sum(int(blk.info().n_inorder_rows) for blk in blocks)
     kernel_name = (f"spmm_rows_kernel<{g_lanes},{max(1, dl // 256)},4,true,{'true' if hot_rows else 'false'}>"
-                   f"  (G lanes per row, float4 chunks per lane, W, FULL, gather cache policy)"
-                   + (f" + hub_inorder_kernel<48,true> beside it on a side stream ({n_hub_rows} hub rows x {(dl + 63) // 64} column slabs, reference order)" if n_hub_rows else ""))
+                   f"  (G lanes per row, float4 chunks per lane, W, FULL, gather cache policy; its first work items: the {n_long - n_io} rows of "
+                   f"{blocks[0].info().hub_threshold} < edges <= {blocks[0].info().hub_inorder_min}, longest first)"
+                   + (f" + hub_inorder_kernel<48,L> beside it on a side stream ({n_io} longer rows cut into column slabs, reference order)" if n_io else ""))
     res = {
         "value": nnz * d * args.steps / elapsed, "iterations_per_sec": args.steps / elapsed,
         "ms_per_step": elapsed / args.steps * 1e3, "parallelism": par,

@@ -29,7 +29,8 @@ vp = ctypes.c_void_p
 class GraphInfo(ctypes.Structure):
     _fields_ = [("n_rows", c_u64), ("n_cols", c_u64), ("nnz", c_u64), ("n_hub_rows", c_u64),
                 ("n_hub_segments", c_u64), ("device_bytes", c_u64), ("hot_rows", c_u64), ("hub_threshold", c_u32),
-                ("hub_segment", c_u32), ("device", ctypes.c_int32), ("has_symmetric", ctypes.c_int32)]
+                ("hub_segment", c_u32), ("device", ctypes.c_int32), ("has_symmetric", ctypes.c_int32),
+                ("n_inorder_rows", c_u64), ("hub_inorder_min", c_u64)]
 
 
 class ShardedInfo(ctypes.Structure):
@@ -102,6 +103,8 @@ SIGNATURES = {
     "cleora_graph_destroy": (c_int, [vp]),
     "cleora_graph_get_info": (c_int, [vp, ctypes.POINTER(GraphInfo)]),
     "cleora_graph_set_hot_cache": (c_int, [vp, c_i64]),
+    "cleora_graph_set_hub_lanes": (c_int, [vp, c_int]),
+    "cleora_graph_set_hub_inorder_min": (c_int, [vp, c_u64]),
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
     "cleora_alloc_iterates": (c_int, [vp, c_u32, c_u32, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_double * 2)]),
@@ -278,6 +281,14 @@ class Graph:
     def set_hot_cache(self, hot_bytes):
         """-1 automatic, 0 off, > 0 forced byte budget (include/cleora_hip.h)."""
         check(lib().cleora_graph_set_hot_cache(self.handle, int(hot_bytes)))
+
+    def set_hub_inorder_min(self, min_edges):
+        """Long rows with more than min_edges edges run on the in-order hub launch, the others first in the main launch (same bits)."""
+        check(lib().cleora_graph_set_hub_inorder_min(self.handle, int(min_edges)))
+
+    def set_hub_lanes(self, lanes):
+        """Lanes per edge of the in-order hub launch: 0 automatic, 4 / 2 forced (same bits either way)."""
+        check(lib().cleora_graph_set_hub_lanes(self.handle, int(lanes)))
 
     def set_timing(self, enable):
         check(lib().cleora_graph_set_timing(self.handle, 1 if enable else 0))

@@ -56,6 +56,40 @@ int require_device() {
     return CLEORA_OK;
 }
 
+// The reference-order schedule of the long rows (common.h): mid rows -> first items of the main launch, longest first; rows beyond
+// inorder_min -> the in-order hub launch, longest first.  Rebuilt by cleora_graph_set_hub_inorder_min (host lists, no rowptr needed).
+int build_inorder_tables(cleora_graph *g) {
+    std::vector<uint32_t> mid, io;
+    std::vector<uint64_t> mid_len, io_len;
+    for (size_t i = 0; i < g->long_rows.size(); ++i) {
+        if (g->long_len[i] > g->inorder_min) { io.push_back(g->long_rows[i]); io_len.push_back(g->long_len[i]); }
+        else { mid.push_back(g->long_rows[i]); mid_len.push_back(g->long_len[i]); }
+    }
+    // longest first (ties by row id: deterministic)
+    std::vector<uint32_t> mid_order(mid.size()), io_order(io.size());
+    for (size_t i = 0; i < mid_order.size(); ++i) mid_order[i] = (uint32_t)i;
+    for (size_t i = 0; i < io_order.size(); ++i) io_order[i] = (uint32_t)i;
+    std::sort(mid_order.begin(), mid_order.end(), [&](uint32_t x, uint32_t y) { return mid_len[x] != mid_len[y] ? mid_len[x] > mid_len[y] : x < y; });
+    std::sort(io_order.begin(), io_order.end(), [&](uint32_t x, uint32_t y) { return io_len[x] != io_len[y] ? io_len[x] > io_len[y] : x < y; });
+    std::vector<uint32_t> mid_sorted(mid.size());
+    for (size_t i = 0; i < mid.size(); ++i) mid_sorted[i] = mid[mid_order[i]];
+    (void)hipFree(g->mid_rows);
+    (void)hipFree(g->io_rows);
+    (void)hipFree(g->hub_by_len);
+    g->mid_rows = g->io_rows = g->hub_by_len = nullptr;
+    g->n_mid_rows = mid.size();
+    g->n_io_rows = io.size();
+    auto up = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
+        if (v.empty()) return CLEORA_OK;
+        CL_HIP(hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(uint32_t)));
+        CL_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return CLEORA_OK;
+    };
+    int rc;
+    if ((rc = up(&g->mid_rows, mid_sorted)) != CLEORA_OK || (rc = up(&g->io_rows, io)) != CLEORA_OK || (rc = up(&g->hub_by_len, io_order)) != CLEORA_OK) return rc;
+    return CLEORA_OK;
+}
+
 // Finds hub rows from a host copy of rowptr and uploads the split schedule.
 int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
     std::vector<uint32_t> hub_rows, seg_row;
@@ -72,15 +106,25 @@ int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
         }
     }
     hub_seg_first.push_back(seg_row.size());
-    // longest row first for the in-order launch (ties by row id: deterministic)
-    std::vector<uint32_t> hub_by_len(hub_rows.size());
-    for (size_t i = 0; i < hub_by_len.size(); ++i) hub_by_len[i] = (uint32_t)i;
-    auto len_of = [&](uint32_t h) { return rowptr_host[hub_rows[h] + 1] - rowptr_host[hub_rows[h]]; };
-    std::sort(hub_by_len.begin(), hub_by_len.end(), [&](uint32_t x, uint32_t y) {
-        const uint64_t lx = len_of(x), ly = len_of(y);
-        return lx != ly ? lx > ly : x < y;
-    });
-    g->hub_inorder_ok = hub_by_len.empty() || len_of(hub_by_len[0]) < (1ull << 30) - 4096;
+    g->long_rows = hub_rows;
+    g->long_len.resize(hub_rows.size());
+    uint64_t longest = 0;
+    for (size_t i = 0; i < hub_rows.size(); ++i) {
+        g->long_len[i] = rowptr_host[hub_rows[i] + 1] - rowptr_host[hub_rows[i]];
+        longest = std::max(longest, g->long_len[i]);
+    }
+    g->hub_inorder_ok = longest < (1ull << 30) - 4096;
+    g->hub_longest = longest;
+    if (g->inorder_min == 0) {
+        // A long row that stays in the main launch is ONE wavefront's work: ~3.3 GB/s of gathers beside a saturated memory system, so
+        // len * d * 4 B / 3.3 GB/s of time, against ~nnz * d * 4 B / 6.4 TB/s for the whole launch.  Started first it is harmless up to a
+        // quarter of that: len <= nnz / 8192 (config 3: 24 k edges, config 5: capped; config 2: 2.4 k; a 6 M-edge block of an 8-way
+        // partition: none — every long row goes to the hub launch).  Capped at 32 x hub_threshold: beyond it the hub launch's column
+        // slabs are the better shape.  Measured on one box (scripts/r05/hub_lanes_probe.py): C5 193.3 ms with every long row on the
+        // hub launch, 187.5 at 8 k, 186.6 at 32 k, segments 187.2; C3 32.71 / 32.68 / 32.68 / 32.55.
+        const uint64_t by_size = g->nnz / 8192, cap = (uint64_t)g->hub_threshold * kInorderMinCap;
+        g->inorder_min = std::max<uint64_t>(g->hub_threshold, std::min(by_size, cap));
+    }
     g->n_hub_rows = hub_rows.size();
     g->n_hub_segments = seg_row.size();
     if (g->n_hub_rows == 0) return CLEORA_OK;
@@ -93,7 +137,7 @@ int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
     };
     int rc;
     if ((rc = up(&g->hub_rows, hub_rows)) != CLEORA_OK) return rc;
-    if ((rc = up(&g->hub_by_len, hub_by_len)) != CLEORA_OK) return rc;
+    if ((rc = build_inorder_tables(g)) != CLEORA_OK) return rc;
     if ((rc = up(&g->hub_seg_first, hub_seg_first)) != CLEORA_OK) return rc;
     if ((rc = up(&g->seg_row, seg_row)) != CLEORA_OK) return rc;
     if ((rc = up(&g->seg_begin, seg_begin)) != CLEORA_OK) return rc;
@@ -152,6 +196,8 @@ void free_graph(cleora_graph *g) {
     }
     (void)hipFree(g->hub_rows);
     (void)hipFree(g->hub_by_len);
+    (void)hipFree(g->mid_rows);
+    (void)hipFree(g->io_rows);
     if (g->hub_stream) {
         (void)hipStreamSynchronize(g->hub_stream);
         (void)hipStreamDestroy(g->hub_stream);
@@ -353,8 +399,27 @@ int cleora_graph_get_info(const cleora_graph *g, cleora_graph_info *info) {
     }
     info->hub_threshold = g->hub_threshold;
     info->hub_segment = g->hub_segment;
+    info->n_inorder_rows = g->n_io_rows;
+    info->hub_inorder_min = g->inorder_min;
     info->device = g->device;
     info->has_symmetric = g->val[1] != nullptr;
+    return CLEORA_OK;
+}
+
+int cleora_graph_set_hub_inorder_min(cleora_graph *g, uint64_t min_edges) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    std::lock_guard<std::mutex> lock(g->mu);
+    CL_HIP(hipSetDevice(g->device));
+    CL_HIP(hipDeviceSynchronize());                       // launches that still read the tables being replaced
+    g->inorder_min = min_edges > g->hub_threshold ? min_edges : g->hub_threshold;
+    return build_inorder_tables(g);
+}
+
+int cleora_graph_set_hub_lanes(cleora_graph *g, int lanes) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    CL_REQUIRE(lanes == 0 || lanes == 2 || lanes == 4, "lanes per edge: 0 (automatic), 4 or 2");
+    std::lock_guard<std::mutex> lock(g->mu);
+    g->hub_lanes = lanes;
     return CLEORA_OK;
 }
 

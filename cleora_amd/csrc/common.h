@@ -42,6 +42,7 @@ inline dim3 grid_1d_as_2d(uint64_t blocks) {
 
 constexpr uint32_t kDefaultHubThreshold = 1024;  // edges; longer rows are split
 constexpr uint32_t kDefaultHubSegment = 256;     // edges per split segment
+constexpr uint32_t kInorderMinCap = 32;          // the in-order hub launch takes every row beyond hub_threshold * this many edges (abi.hip build_hub_schedule)
 
 }  // namespace cleora
 
@@ -62,9 +63,20 @@ struct cleora_graph {
     uint64_t *hub_seg_first = nullptr;  // [n_hub_rows + 1]   first segment of each hub row
     uint32_t *seg_row = nullptr;        // [n_hub_segments]   row id of the segment
     uint64_t *seg_begin = nullptr;      // [n_hub_segments]   first edge of the segment
-    // the in-order hub launch (spmm.hip hub_inorder_kernel): hub indices longest row first, side stream + fork / join events
-    uint32_t *hub_by_len = nullptr;     // [n_hub_rows]
+    // Reference-order schedule of the long rows (the default; spmm.hip).  Rows of hub_threshold < edges <= inorder_min are the
+    // FIRST work items of the main launch, longest first, one wavefront each like any row ("mid" rows: long enough to be a tail if
+    // they started last, short enough for one wavefront); rows beyond inorder_min run on the in-order hub launch
+    // (hub_inorder_kernel: one wavefront per 64-column slab) on the side stream, whose rows / order / scratch these are:
+    std::vector<uint32_t> long_rows;    // host: every row longer than hub_threshold (ascending row id) ...
+    std::vector<uint64_t> long_len;     // ... and its edge count: what cleora_graph_set_hub_inorder_min re-partitions
+    uint64_t inorder_min = 0;           // rows with MORE edges go to the in-order hub launch
+    uint64_t n_mid_rows = 0, n_io_rows = 0;
+    uint32_t *mid_rows = nullptr;       // [n_mid_rows]  row ids, longest first
+    uint32_t *io_rows = nullptr;        // [n_io_rows]   row ids (ascending): scratch row h belongs to io_rows[h]
+    uint32_t *hub_by_len = nullptr;     // [n_io_rows]   indices into io_rows, longest row first
     bool hub_inorder_ok = true;         // false: some row is too long for the kernel's 32-bit (col, val) offsets
+    uint64_t hub_longest = 0;           // edges of the longest row
+    mutable int hub_lanes = 0;          // lanes per edge of the in-order hub launch: 0 = automatic (spmm.hip hub_lanes), else 4 / 2 / 1
     mutable hipStream_t hub_stream = nullptr;
     mutable hipEvent_t hub_fork = nullptr, hub_join = nullptr;
     uint64_t device_bytes = 0;

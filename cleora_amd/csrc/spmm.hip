@@ -54,6 +54,7 @@ struct SpmmArgs {
     const uint32_t *hub_rows;
     const uint64_t *hub_seg_first;
     float *partial;
+    const uint32_t *mid_rows;     // reference-order schedule: the first n_segments items are these rows (longest first), not segments
     // in-order hub kernel
     const uint32_t *hub_by_len;   // hub indices, longest row first
     uint64_t nnz;
@@ -176,10 +177,15 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs a) {
         if (!active) return;
         item = uniform_u64(item);
     }
-    const bool is_seg = item < a.n_segments;
+    const bool is_mid = a.mid_rows != nullptr && item < a.n_segments;      // a long row scheduled first: a whole row like any other
+    const bool is_seg = a.mid_rows == nullptr && item < a.n_segments;
     uint64_t row = 0, beg = 0, end = 0;
     if (active) {
-        if (is_seg) {
+        if (is_mid) {
+            row = a.mid_rows[item];
+            beg = a.rowptr[row];
+            end = a.rowptr[row + 1];
+        } else if (is_seg) {
             row = a.seg_row[item];
             beg = a.seg_begin[item];
             const uint64_t rend = a.rowptr[row + 1];
@@ -280,23 +286,34 @@ __global__ __launch_bounds__(256) void hub_finish_kernel(const SpmmArgs a) {
 //     buffer loads (ordinary loads would sit in the same in-order vmcnt queue as the ring and drain it), read back with
 //     one ds_read per step at a compile-time offset.
 // The last step of a row runs only its valid rounds (the padding lanes hold the next row's edges).
-template <int R, bool QUAD>
+// L = lanes per edge (each lane 16 bytes = 4 columns): 4 -> 4 edges per load, a 64-column slab per wavefront (the form described
+// above); 2 -> 8 edges per load, 32-column slabs (1 -> 16 edges per load compiles too, but its unrolled body spills and outgrows the
+// instruction cache: not instantiated).  Fewer lanes per edge = more edges in
+// flight per wavefront (the vmcnt counter caps the LOADS at 63) and more wavefronts per row: a shorter chain for the longest row
+// — which, beside a main kernel that saturates HBM, advances one step per (load latency / R) — at the price of proportionally more
+// vector instructions in total (every lane still adds 4 floats per edge).  The launcher picks L per launch (hub_lanes()).
+// L = 0: the LANE form (one column per lane, one edge per step; any alignment).
+template <int R, int L>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hub_inorder_kernel(const SpmmArgs a) {
-    constexpr int EPS = QUAD ? 4 : 1;             // edges per step
+    constexpr bool QUAD = L != 0;
+    constexpr int EPS = QUAD ? 16 / L : 1;        // edges per step
+    constexpr int COLS = QUAD ? 16 * L : 64;      // columns per wavefront
     constexpr int CH = R * EPS;                   // edges per chunk
-    constexpr int FE = CH > 64 ? 4 : 1;           // (col, val) entries fetched per lane and chunk: one dword or one dwordx4
-    static_assert(64 * FE >= CH, "a chunk is one fetch instruction per stream");
-    __shared__ __attribute__((aligned(16))) uint32_t s_col[2][64 * FE];
-    __shared__ __attribute__((aligned(16))) uint32_t s_val[2][64 * FE];
+    constexpr int NF = CH > 64 ? (CH + 255) / 256 : 0;    // dwordx4 fetches per lane, stream and chunk (0: one dword)
+    constexpr int SLOT = NF ? 256 * NF : 64;      // entries of an LDS slot
+    static_assert(SLOT >= CH, "a chunk fits its LDS slot");
+    __shared__ __attribute__((aligned(16))) uint32_t s_col[2][SLOT];
+    __shared__ __attribute__((aligned(16))) uint32_t s_val[2][SLOT];
     const int lane = threadIdx.x;
-    const int q = QUAD ? (lane >> 2) & 3 : 0;
+    const int q = QUAD ? (lane & 15) / (QUAD ? L : 1) : 0;                        // which edge of the step this lane loads
     const uint64_t item = CLEORA_LINEAR_BLOCK();
     const uint32_t k = (uint32_t)(item / a.n_slabs), slab = (uint32_t)(item - (uint64_t)k * a.n_slabs);
     const uint32_t h = a.hub_by_len[k];
     const uint64_t row = a.hub_rows[h];
     const uint64_t beg = a.rowptr[row], n = a.rowptr[row + 1] - beg;
     const uint32_t d = a.r.d;
-    const uint32_t coff = QUAD ? slab * 64u + (uint32_t)(lane >> 4) * 16u + (uint32_t)(lane & 3) * 4u : slab * 64u + (uint32_t)lane;
+    const uint32_t coff = QUAD ? slab * (uint32_t)COLS + (uint32_t)(lane >> 4) * (4u * (QUAD ? L : 1)) + (uint32_t)((lane & 15) % (QUAD ? L : 1)) * 4u
+                               : slab * 64u + (uint32_t)lane;
     const bool in_range = coff < d;
     const float *xb = a.x + (in_range ? coff : 0u);
 
@@ -305,24 +322,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hu
     const auto rs_col = __builtin_amdgcn_make_buffer_rsrc((void *)(a.col + beg), 0, records, 0x00020000);
     const auto rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)(a.val + beg), 0, records, 0x00020000);
     // entries past the row's end are the next rows' (valid gather addresses, never consumed) or, past the array, zero
-    u32x4 pc, pv;
+    u32x4 pc[NF ? NF : 1], pv[NF ? NF : 1];
     auto fetch = [&](uint64_t chunk) {
-        const int off = (int)(uint32_t)((chunk * CH + (uint64_t)lane * FE) * 4u);
-        if constexpr (FE == 4) {
-            pc = __builtin_amdgcn_raw_buffer_load_b128(rs_col, off, 0, 0);
-            pv = __builtin_amdgcn_raw_buffer_load_b128(rs_val, off, 0, 0);
+        if constexpr (NF != 0) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int off = (int)(uint32_t)((chunk * CH + (uint64_t)(256 * f + 4 * lane)) * 4u);
+                pc[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_col, off, 0, 0);
+                pv[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_val, off, 0, 0);
+            }
         } else {
-            pc.x = __builtin_amdgcn_raw_buffer_load_b32(rs_col, off, 0, 0);
-            pv.x = __builtin_amdgcn_raw_buffer_load_b32(rs_val, off, 0, 0);
+            const int off = (int)(uint32_t)((chunk * CH + (uint64_t)lane) * 4u);
+            pc[0].x = __builtin_amdgcn_raw_buffer_load_b32(rs_col, off, 0, 0);
+            pv[0].x = __builtin_amdgcn_raw_buffer_load_b32(rs_val, off, 0, 0);
         }
     };
     auto stash = [&](int slot) {
-        if constexpr (FE == 4) {
-            *reinterpret_cast<u32x4 *>(&s_col[slot][4 * lane]) = pc;
-            *reinterpret_cast<u32x4 *>(&s_val[slot][4 * lane]) = pv;
+        if constexpr (NF != 0) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                *reinterpret_cast<u32x4 *>(&s_col[slot][256 * f + 4 * lane]) = pc[f];
+                *reinterpret_cast<u32x4 *>(&s_val[slot][256 * f + 4 * lane]) = pv[f];
+            }
         } else {
-            s_col[slot][lane] = pc.x;
-            s_val[slot][lane] = pv.x;
+            s_col[slot][lane] = pc[0].x;
+            s_val[slot][lane] = pv[0].x;
         }
     };
     using Vec = std::conditional_t<QUAD, float4, float>;
@@ -336,9 +360,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hu
 #pragma unroll
     for (int s = 0; s < R; ++s) ring[s] = gather(s_col[0][EPS * s + q]);
 
-    float acc[EPS];
+    float acc[QUAD ? 4 : 1];
 #pragma unroll
-    for (int e = 0; e < EPS; ++e) acc[e] = 0.f;
+    for (int e = 0; e < (QUAD ? 4 : 1); ++e) acc[e] = 0.f;
     // One chunk: R steps.  WHOLE: all CH edges belong to the row (no tests); else `left` < CH of them do.
     auto chunk_body = [&](auto whole, int cur, uint32_t left) {
         constexpr bool WHOLE = decltype(whole)::value;
@@ -353,28 +377,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hu
                 // which would wait for the loads)
                 float t0 = fmul(w, ring[s].x), t1 = fmul(w, ring[s].y), t2 = fmul(w, ring[s].z), t3 = fmul(w, ring[s].w);
                 if constexpr (WHOLE) ring[s] = gather(cn);
-                // one round: acc = row_ror:4(acc) + t in every lane.  Written as asm so that all rounds are the 1-instruction
+                // one round: acc = row_ror:L(acc) + t in every lane.  Written as asm so that all rounds are the 1-instruction
                 // DPP add (the compiler turns the last round of a step into v_mov_dpp x4 + v_pk_add x2).  A DPP read needs 2 wait
                 // states after a VALU write of its source: inside a round the four chains interleave; the s_nop covers a copy
                 // or product the compiler schedules right in front of the block (it does not look for hazards inside asm —
                 // without it the first chain read stale sums in the tail chunk).
-#define CLEORA_HUB_ROUND                                                                                              \
+#define CLEORA_HUB_ROUND_(ROR)                                                                                        \
     asm volatile("s_nop 1\n\t"                                                                                      \
-                 "v_add_f32_dpp %0, %0, %4 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
-                 "v_add_f32_dpp %1, %1, %5 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
-                 "v_add_f32_dpp %2, %2, %6 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                                 \
-                 "v_add_f32_dpp %3, %3, %7 row_ror:4 row_mask:0xf bank_mask:0xf"                                      \
+                 "v_add_f32_dpp %0, %0, %4 row_ror:" ROR " row_mask:0xf bank_mask:0xf\n\t"                           \
+                 "v_add_f32_dpp %1, %1, %5 row_ror:" ROR " row_mask:0xf bank_mask:0xf\n\t"                           \
+                 "v_add_f32_dpp %2, %2, %6 row_ror:" ROR " row_mask:0xf bank_mask:0xf\n\t"                           \
+                 "v_add_f32_dpp %3, %3, %7 row_ror:" ROR " row_mask:0xf bank_mask:0xf"                                \
                  : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                            \
                  : "v"(t0), "v"(t1), "v"(t2), "v"(t3))
-                if (WHOLE || left >= (uint32_t)(4 * s + 4)) {
-                    CLEORA_HUB_ROUND; CLEORA_HUB_ROUND; CLEORA_HUB_ROUND; CLEORA_HUB_ROUND;
-                } else if (left > (uint32_t)(4 * s)) {
-                    const uint32_t m = left - 4 * s;   // 1..3 edges in the row's last step
+#define CLEORA_HUB_ROUND                                            \
+    do {                                                            \
+        if constexpr (L == 4) { CLEORA_HUB_ROUND_("4"); }           \
+        else if constexpr (L == 2) { CLEORA_HUB_ROUND_("2"); }      \
+        else { CLEORA_HUB_ROUND_("1"); }                            \
+    } while (0)
+                if (WHOLE || left >= (uint32_t)(EPS * s + EPS)) {
+#pragma unroll
+                    for (int g = 0; g < EPS; ++g) CLEORA_HUB_ROUND;
+                } else if (left > (uint32_t)(EPS * s)) {
+                    const uint32_t m = left - EPS * s;   // 1 .. EPS - 1 edges in the row's last step
                     CLEORA_HUB_ROUND;
-                    if (m > 1) { CLEORA_HUB_ROUND; }
-                    if (m > 2) { CLEORA_HUB_ROUND; }
+#pragma unroll
+                    for (int g = 1; g < EPS - 1; ++g)
+                        if (m > (uint32_t)g) CLEORA_HUB_ROUND;
                 }
 #undef CLEORA_HUB_ROUND
+#undef CLEORA_HUB_ROUND_
             } else {
                 const float t = fmul(w, ring[s]);
                 if constexpr (WHOLE) ring[s] = gather(cn);
@@ -393,7 +426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hu
     if (tail) chunk_body(std::false_type{}, (int)(whole_chunks & 1), tail);
     float *p = a.partial + (uint64_t)h * d + coff;
     if constexpr (QUAD) {
-        if (in_range && (uint32_t)q == (uint32_t)((n - 1) & 3)) *reinterpret_cast<float4 *>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (in_range && (uint32_t)q == (uint32_t)((n - 1) % EPS)) *reinterpret_cast<float4 *>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     } else {
         if (in_range) *p = acc[0];
     }
@@ -578,7 +611,7 @@ inline dim3 grid_for(uint64_t items, int per_block) {
 // Scratch for the hub-segment partial sums, grown when a wider d arrives: stream-ordered (the old block is released
 // behind the launches that still use it), so a `*_dev` call stays enqueue-only.
 int ensure_partial(const cleora_graph *g, uint32_t d, bool segmented, hipStream_t stream) {
-    const uint64_t need = (segmented ? g->n_hub_segments : g->n_hub_rows) * (uint64_t)d;
+    const uint64_t need = (segmented ? g->n_hub_segments : g->n_io_rows) * (uint64_t)d;
     if (need <= g->hub_partial_elems) return CLEORA_OK;
     if (g->hub_partial) CL_HIP(hipFreeAsync(g->hub_partial, stream));
     g->hub_partial = nullptr;
@@ -605,6 +638,19 @@ inline void mark(const cleora_graph *g, hipStream_t stream) {
     if (hipEvent_t e = take_event(g)) (void)hipEventRecord(e, stream);
 }
 
+// Lanes per edge of the in-order hub launch (hub_inorder_kernel<R, L>).  The longest row is one in-order chain; beside a main kernel
+// that saturates HBM a wavefront advances one step per (load latency / 48) — measured 10 us per request at C3, i.e. ~52 ns per edge at
+// 4 edges per step.  The launch should end well before the main kernel does (~nnz * d * 4 bytes at ~6.4 TB/s): the narrowest form whose
+// estimated chain stays under HALF the main kernel's estimated time, else the 2-lane form.  Narrower forms cost proportionally more
+// vector instructions in total, so the wide form stays wherever the chain is hidden anyway (C5: 1.13 M edges beside 190 ms).
+// g->hub_lanes != 0 forces a form (cleora_graph_set_hub_lanes: tests, A/B runs).
+int hub_lanes(const cleora_graph *g, uint32_t d) {
+    if (g->hub_lanes == 4 || g->hub_lanes == 2) return g->hub_lanes;
+    const double main_ns = (double)g->nnz * (double)d * 4.0 / 6.4e3;          // bytes / (6.4e12 B/s) in ns
+    const double chain4_ns = (double)g->hub_longest * 52.0;
+    return chain4_ns <= 0.5 * main_ns ? 4 : 2;
+}
+
 // Side stream (highest priority) and the fork / join events of the in-order hub launch, created on first use.
 int ensure_hub_stream(const cleora_graph *g) {
     if (g->hub_stream) return CLEORA_OK;
@@ -620,29 +666,36 @@ int ensure_hub_stream(const cleora_graph *g) {
 int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, hipStream_t stream, hipEvent_t *hub_join_out = nullptr) {
     const uint32_t d = a.r.d;
     bool ok = true;
-    const bool inorder = g->n_hub_rows && !segmented;
+    const bool inorder = g->n_hub_rows && !segmented;      // the reference-order schedule of the long rows
+    const bool hub_launch = inorder && g->n_io_rows;       // ... of which some run on the in-order hub launch
     mark(g, stream);
-    if (inorder) {
+    if (hub_launch) {
         // the hub rows, longest first, on the side stream beside the main launch (src/embedding.rs:76-83's order)
         const int rc = ensure_hub_stream(g);
         if (rc != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(g->hub_fork, stream));
         CL_HIP(hipStreamWaitEvent(g->hub_stream, g->hub_fork, 0));
         a.hub_by_len = g->hub_by_len;
+        a.hub_rows = g->io_rows;
         a.nnz = g->nnz;
-        a.n_slabs = (d + 63) / 64;
-        const dim3 grid = grid_1d_as_2d(g->n_hub_rows * (uint64_t)a.n_slabs);
-        if (w4) hipLaunchKernelGGL((hub_inorder_kernel<48, true>), grid, dim3(64), 0, g->hub_stream, a);
-        else hipLaunchKernelGGL((hub_inorder_kernel<64, false>), grid, dim3(64), 0, g->hub_stream, a);
+        const int lanes = w4 ? hub_lanes(g, d) : 0;
+        a.n_slabs = lanes ? (d + 16 * lanes - 1) / (16 * lanes) : (d + 63) / 64;
+        const dim3 grid = grid_1d_as_2d(g->n_io_rows * (uint64_t)a.n_slabs);
+        if (lanes == 4) hipLaunchKernelGGL((hub_inorder_kernel<48, 4>), grid, dim3(64), 0, g->hub_stream, a);
+        else if (lanes == 2) hipLaunchKernelGGL((hub_inorder_kernel<48, 2>), grid, dim3(64), 0, g->hub_stream, a);
+        else hipLaunchKernelGGL((hub_inorder_kernel<64, 0>), grid, dim3(64), 0, g->hub_stream, a);
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
             constexpr int kG = decltype(G)::value;
             hipLaunchKernelGGL((hub_epilogue_kernel<kG, decltype(V)::value, decltype(W)::value>),
-                               grid_for(g->n_hub_rows, 256 / kG), dim3(256), 0, g->hub_stream, a, g->n_hub_rows);
+                               grid_for(g->n_io_rows, 256 / kG), dim3(256), 0, g->hub_stream, a, g->n_io_rows);
         });
         CL_HIP(hipEventRecord(g->hub_join, g->hub_stream));
     }
     mark(g, stream);
-    a.n_segments = inorder ? 0 : g->n_hub_segments;
+    a.hub_rows = g->hub_rows;
+    a.mid_rows = inorder ? g->mid_rows : nullptr;
+    a.n_segments = inorder ? g->n_mid_rows : g->n_hub_segments;
+    if (inorder && !g->n_mid_rows) a.mid_rows = nullptr;
     a.n_items = a.n_segments + g->n_rows;
     if (ok && a.n_items) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto FULL) {
@@ -665,12 +718,12 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, 
         });
     }
     mark(g, stream);
-    if (inorder) {
+    if (hub_launch) {
         // the caller may take the join itself (sharded.hip: only the gather of this block — and the next iteration — need the hub
         // rows, so the next block's launch need not wait for this block's longest chain)
         if (hub_join_out) *hub_join_out = g->hub_join;
         else CL_HIP(hipStreamWaitEvent(stream, g->hub_join, 0));
-    } else if (ok && g->n_hub_rows) {
+    } else if (ok && g->n_hub_rows && !inorder) {
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
             hipLaunchKernelGGL((hub_finish_kernel<decltype(G)::value, decltype(V)::value, decltype(W)::value>),
                                dim3((unsigned)g->n_hub_rows), dim3(256), 0, stream, a);

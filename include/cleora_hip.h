@@ -75,13 +75,16 @@ typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct S
 
 typedef struct cleora_graph_info {
     uint64_t n_rows, n_cols, nnz;
-    uint64_t n_hub_rows;      /* rows longer than hub_threshold: summed by the in-order hub launch (spmm.hip hub_inorder_kernel) */
+    uint64_t n_hub_rows;      /* rows longer than hub_threshold ("long" rows) */
     uint64_t n_hub_segments;  /* their hub_segment-edge segments (the CLEORA_F_HUB_SEGMENTS form) */
     uint64_t device_bytes;    /* HBM held by the handle */
     uint64_t hot_rows;        /* rows the gather cache policy currently keeps cacheable; 0 = policy inactive */
     uint32_t hub_threshold, hub_segment;
     int32_t device;
     int32_t has_symmetric;
+    uint64_t n_inorder_rows;  /* long rows beyond hub_inorder_min edges: summed by the in-order hub launch (spmm.hip hub_inorder_kernel);
+                                 the other long rows are the first work items of the main launch, longest first */
+    uint64_t hub_inorder_min;
 } cleora_graph_info;
 
 /* ---- library / device ------------------------------------------------------------ */
@@ -111,9 +114,10 @@ int cleora_stream_wait_stream(void *waiter, void *signaller);
  * col u32[nnz], one f32[nnz] stream per MarkovType (val_sym may be NULL).
  * Rows are the OUTPUT rows of this shard (all rows on one GPU; a row block when the graph
  * is row-partitioned); col indexes the n_cols rows of the full embedding matrix.
- * hub_threshold: rows with more edges are hub rows — summed in the reference's order by a launch of their own beside the main one
- * (one wavefront per 64-column slab), or, with CLEORA_F_HUB_SEGMENTS, as hub_segment-edge segments on separate wavefronts
- * (0 = defaults 1024 / 256).  Copies the arrays; the caller keeps
+ * hub_threshold: rows with more edges are "long" rows — scheduled first (longest first) in the main launch or, beyond a length
+ * that grows with the graph (cleora_graph_set_hub_inorder_min), summed by a launch of their own beside the main one, one wavefront per
+ * 64-column slab: the reference's order either way.  With CLEORA_F_HUB_SEGMENTS they are summed as hub_segment-edge segments on
+ * separate wavefronts instead (0 = defaults 1024 / 256).  Copies the arrays; the caller keeps
  * ownership of its buffers. */
 int cleora_graph_create(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
                         const uint64_t *rowptr, const uint32_t *col, const float *val_left,
@@ -142,6 +146,17 @@ int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes);
  * durations in milliseconds — ms[0] the fork of the in-order hub launch onto its side stream, ms[1] spmm_rows (the dominant kernel,
  * with the hub launch beside it), ms[2] the join (with CLEORA_F_HUB_SEGMENTS: hub_finish_kernel) — and the number of calls they
  * cover, then resets the record.  ms[0] + ms[1] + ms[2] = the span of one SpMM on the launch stream. */
+/* Which long rows take the in-order hub launch: those with MORE than min_edges edges (default: nnz / 8192 — what one wavefront can
+ * gather in a quarter of the launch — clamped to [hub_threshold, 32 x hub_threshold]; values below hub_threshold mean hub_threshold).  Long rows up to min_edges are the FIRST work items of the main launch, longest first, one
+ * wavefront each like any row — long enough to be a tail if they started last, short enough for one wavefront; rows beyond it are
+ * cut by column over many wavefronts (hub_inorder_kernel).  Either way every row is summed in the reference's order: the setting
+ * moves work between two kernels, never a bit of the result.  Waits for the device (the tables are replaced). */
+int cleora_graph_set_hub_inorder_min(cleora_graph *g, uint64_t min_edges);
+/* The in-order hub launch's shape: lanes per edge — 4 (four edges per 16-byte load instruction, 64-column slabs per wavefront) or
+ * 2 (eight edges, 32-column slabs: twice the edges in flight per wavefront, twice the wavefronts per row — a shorter chain for the
+ * longest row at twice the vector instructions); 0 = automatic (default): 4 while the estimated chain of the graph's longest row
+ * stays under half the main kernel's estimated time, else 2.  Results are bit-identical for either choice. */
+int cleora_graph_set_hub_lanes(cleora_graph *g, int lanes);
 int cleora_graph_set_timing(cleora_graph *g, int enable);
 int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
 

@@ -40,6 +40,10 @@ def test_random_case(seed):
     L = _hip.lib()
     g = _hip.Graph.from_host(rowptr, col, val, None, n_cols=n_cols, hub_threshold=thr, hub_segment=seg)
     eff_thr = g.info().hub_threshold
+    if seed % 3 == 0:
+        g.set_hub_inorder_min(0)               # every long row on the in-order hub launch instead of first in the main launch
+    if seed % 5 == 0:
+        g.set_hub_lanes(2)
     square = n == n_cols
     flags = 0
     if rng.random() < 0.7:

@@ -109,6 +109,16 @@ def test_hub_rows_in_reference_order(d):
     want = oracle.spmm(rowptr, col, vl, x)
     got = run_dev(g, _hip.LEFT, x)
     np.testing.assert_array_equal(got, want)
+    # which long rows take the in-order hub launch and which are the first work items of the main launch is a scheduling choice
+    # (default: by graph size, nnz / 8192 edges): any split gives the same bits
+    assert info.hub_inorder_min == 1024 and info.n_inorder_rows == len(hubs) - 1        # a small graph: every long row on the hub launch
+    for min_edges in (0, 1100, 8192):
+        g.set_hub_inorder_min(min_edges)
+        assert g.info().n_inorder_rows == sum(1 for _, deg in hubs if deg > max(min_edges, 1024))
+        for lanes in (2, 4, 0):                  # both shapes of the hub launch (8 / 4 edges per load): the same bits
+            g.set_hub_lanes(lanes)
+            np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x), want)
+    g.set_hub_inorder_min(0)
     # with the epilogue (exact-order L2 norm over the whole row, residual blend, squared difference)
     got = run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM)
     np.testing.assert_array_equal(got, oracle.l2_normalize(want))
@@ -118,6 +128,13 @@ def test_hub_rows_in_reference_order(d):
     # every row a hub row, chunk tails of every length
     g2 = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=4, hub_segment=16)
     np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
+    g2.set_hub_lanes(2)
+    np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
+    np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x, flags=_hip.F_L2NORM), oracle.l2_normalize(want))
+    g2.set_hub_inorder_min(0)                    # every row of more than 4 edges on the hub launch
+    for lanes in (4, 2):
+        g2.set_hub_lanes(lanes)
+        np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
 
 
 def test_hub_rows_signed_zero_and_specials():
@@ -139,8 +156,13 @@ def test_hub_rows_signed_zero_and_specials():
     x[3, 2] = np.inf
     x[4, 3] = np.nan
     g = _hip.Graph.from_host(rowptr, col, vl_pos, hub_threshold=4, hub_segment=16)
+    g.set_hub_inorder_min(0)                     # all nine rows on the hub launch (the default would keep the four short ones in the main launch)
     want = oracle.spmm(rowptr, col, vl_pos, x)
+    g.set_hub_lanes(2)
+    got2 = run_dev(g, _hip.LEFT, x)
+    g.set_hub_lanes(4)
     got = run_dev(g, _hip.LEFT, x)
+    np.testing.assert_array_equal(got.view(np.uint32), got2.view(np.uint32))
     np.testing.assert_array_equal(got.view(np.uint32)[:, :3], want.view(np.uint32)[:, :3])     # bit patterns: signs of zero, denormals, inf
     np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     np.testing.assert_array_equal(got[~np.isnan(want)], want[~np.isnan(want)])

@@ -119,7 +119,7 @@ int build_hub_schedule(cleora_graph *g, const uint64_t *rowptr_host) {
         // A long row that stays in the main launch is ONE wavefront's work: ~3.3 GB/s of gathers beside a saturated memory system, so
         // len * d * 4 B / 3.3 GB/s of time, against ~nnz * d * 4 B / 6.4 TB/s for the whole launch.  Started first it is harmless up to a
         // quarter of that: len <= nnz / 8192 (config 3: 24 k edges, config 5: capped; config 2: 2.4 k; a 6 M-edge block of an 8-way
-        // partition: none — every long row goes to the hub launch).  Capped at 32 x hub_threshold: beyond it the hub launch's column
+        // partition: none — every long row goes to the hub launch).  Capped at 128 x hub_threshold = 32 768: beyond it the hub launch's column
         // slabs are the better shape.  Measured on one box (scripts/r05/hub_lanes_probe.py): C5 193.3 ms with every long row on the
         // hub launch, 187.5 at 8 k, 186.6 at 32 k, segments 187.2; C3 32.71 / 32.68 / 32.68 / 32.55.
         const uint64_t by_size = g->nnz / 8192, cap = (uint64_t)g->hub_threshold * kInorderMinCap;

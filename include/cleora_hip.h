@@ -117,7 +117,7 @@ int cleora_stream_wait_stream(void *waiter, void *signaller);
  * hub_threshold: rows with more edges are "long" rows — scheduled first (longest first) in the main launch or, beyond a length
  * that grows with the graph (cleora_graph_set_hub_inorder_min), summed by a launch of their own beside the main one, one wavefront per
  * 64-column slab: the reference's order either way.  With CLEORA_F_HUB_SEGMENTS they are summed as hub_segment-edge segments on
- * separate wavefronts instead (0 = defaults 1024 / 256).  Copies the arrays; the caller keeps
+ * separate wavefronts instead (0 = defaults 256 / 256).  Copies the arrays; the caller keeps
  * ownership of its buffers. */
 int cleora_graph_create(int device, uint64_t n_rows, uint64_t n_cols, uint64_t nnz,
                         const uint64_t *rowptr, const uint32_t *col, const float *val_left,
@@ -147,7 +147,7 @@ int cleora_graph_set_hot_cache(cleora_graph *g, int64_t hot_bytes);
  * with the hub launch beside it), ms[2] the join (with CLEORA_F_HUB_SEGMENTS: hub_finish_kernel) — and the number of calls they
  * cover, then resets the record.  ms[0] + ms[1] + ms[2] = the span of one SpMM on the launch stream. */
 /* Which long rows take the in-order hub launch: those with MORE than min_edges edges (default: nnz / 8192 — what one wavefront can
- * gather in a quarter of the launch — clamped to [hub_threshold, 32 x hub_threshold]; values below hub_threshold mean hub_threshold).  Long rows up to min_edges are the FIRST work items of the main launch, longest first, one
+ * gather in a quarter of the launch — clamped to [hub_threshold, 128 x hub_threshold]; values below hub_threshold mean hub_threshold).  Long rows up to min_edges are the FIRST work items of the main launch, longest first, one
  * wavefront each like any row — long enough to be a tail if they started last, short enough for one wavefront; rows beyond it are
  * cut by column over many wavefronts (hub_inorder_kernel).  Either way every row is summed in the reference's order: the setting
  * moves work between two kernels, never a bit of the result.  Waits for the device (the tables are replaced). */

@@ -140,7 +140,7 @@ def test_properties_at_baseline_sizes(config):
     graph.set_hot_cache(-1)
     # 3. linearity: A(2x) = 2 A x exactly (power-of-two scaling commutes with every rounding)
     assert torch.equal(prop(graph, x * 2.0), y1 * 2.0)
-    # 4. the hub threshold decides which KERNEL adds a row, never the result: rows of 301..1024 edges go through
+    # 4. the hub threshold decides which KERNEL adds a row, never the result: rows of 257..300 edges are scheduled first on graph2 and in row order on graph, the longest go through
     #    hub_inorder_kernel on graph2 and through the main kernel on graph — same bits; the segmented form
     #    (CLEORA_F_HUB_SEGMENTS) changes only the split rows, within summation-order tolerance
     y3 = prop(graph2, x)

@@ -35,7 +35,7 @@ def _lines(n_nodes, n_lines, seed, hub=None):
 def graph():
     g = SparseMatrix.from_iterator(iter(_lines(3000, 30000, 3, hub=1500)), "complex::reflexive::node")
     deg = np.diff(g._arr["rowptr"].astype(np.int64))
-    assert deg.max() > 1024                    # a hub row is in the mix
+    assert deg.max() > 1024                    # a long row is in the mix
     return g
 
 

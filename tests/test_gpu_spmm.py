@@ -103,7 +103,8 @@ def test_hub_rows_in_reference_order(d):
             (5, 1026), (6, 1027), (7, 1028), (8, 1152), (9, 1153), (10, 1151), (11, 1343), (12, 1344), (13, 1345), (14, 1088)]
     rowptr, col, vl, _ = random_csr(n, 8, seed=11, hubs=hubs)
     x = np.random.default_rng(12).standard_normal((n, d)).astype(np.float32)
-    g = _hip.Graph.from_host(rowptr, col, vl)
+    assert _hip.Graph.from_host(rowptr, col, vl).info().hub_threshold == 256           # the default
+    g = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=1024)
     info = g.info()
     assert info.n_hub_rows == len(hubs) - 1 and info.hub_threshold == 1024
     want = oracle.spmm(rowptr, col, vl, x)
@@ -175,7 +176,7 @@ def test_hub_rows_segmented(d):
     hubs = [(17, 5000), (1234, 1025), (3999, 20000), (2000, 1024)]  # 1024 = threshold: not split
     rowptr, col, vl, _ = random_csr(n, 8, seed=11, hubs=hubs)
     x = np.random.default_rng(12).standard_normal((n, d)).astype(np.float32)
-    g = _hip.Graph.from_host(rowptr, col, vl)
+    g = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=1024)
     want = oracle.spmm(rowptr, col, vl, x)
     got = run_dev(g, _hip.LEFT, x, flags=_hip.F_HUB_SEGMENTS)
     hub_rows = np.array([17, 1234, 3999])

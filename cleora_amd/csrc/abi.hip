@@ -664,9 +664,14 @@ int alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, uint64_t i
     CL_HIP(hipEventCreate(&e0));
     hipError_t ee = hipEventCreate(&e1);
     if (ee != hipSuccess) { (void)hipEventDestroy(e0); fail(0); CL_HIP(ee); }
+    // Three or more buffers = the whitened loop's use: the SpMM WRITES bufs[0] and gathers from the partners in turn, so that is the
+    // direction a candidate is timed in (a pair is not symmetric: this round's bench showed a triple chosen at 32.5 ms in the other
+    // direction run its loop's SpMM at 33.8).  Two buffers ping-pong: both directions occur, the forward one is timed.
+    const bool reverse = count >= 3;
     auto launch = [&](void *partner) {
-        return launch_propagate(g, CLEORA_LEFT, static_cast<const float *>(bufs[0]), d, d, static_cast<float *>(partner), d,
-                                CLEORA_F_L2NORM, 0.f, nullptr, nullptr, nullptr, nullptr);
+        const float *src = static_cast<const float *>(reverse ? partner : bufs[0]);
+        float *dst = static_cast<float *>(reverse ? bufs[0] : partner);
+        return launch_propagate(g, CLEORA_LEFT, src, d, d, dst, d, CLEORA_F_L2NORM, 0.f, nullptr, nullptr, nullptr, nullptr);
     };
     auto median3 = [&](void *partner, float *out_ms) -> int {
         float t[3] = {0.f, 0.f, 0.f};
@@ -700,6 +705,7 @@ int alloc_iterates(const cleora_graph *g, uint32_t d, uint32_t count, uint64_t i
             void *cand = nullptr;
             if (hipMalloc(&cand, bytes) != hipSuccess) { (void)hipGetLastError(); break; }   // no room for another candidate: keep the best so far
             held.push_back(cand);
+            if (reverse) hipLaunchKernelGGL(fill_pattern_kernel, dim3(8192), dim3(256), 0, nullptr, static_cast<float *>(cand), rows * (uint64_t)d);
             if (!warmed) {                                                  // hub scratch, hot marks, caches: not part of any timing
                 rc = launch(cand);
                 warmed = true;

@@ -163,7 +163,8 @@ int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
 /* Iterate buffers placed for the SpMM (no reference counterpart).  The same launch has been measured up to 12-20 % slower when the
  * buffer it gathers from and the buffer it writes fall into the same physical placement class of the HBM (DESIGN.md
  * §3.1; not visible in virtual addresses; box-dependent).  Allocates `count` buffers of max(n_rows, n_cols) x d floats: bufs[0]
- * first, then each partner by TIMING the real kernel on candidates (gathers from bufs[0], writes the candidate; a candidate's time
+ * first, then each partner by TIMING the real kernel on candidates (count = 2: gathers from bufs[0], writes the candidate; count >= 3,
+ * the whitened loop's use: gathers from the candidate, writes bufs[0]; a candidate's time
  * is the median of three launches) until the best is >= 4 % faster than the slowest seen (at most 4 per slot, none once
  * CLEORA_PLACEMENT_BUDGET_MS = 1500 ms of wall clock are spent); the best is taken (the first candidate when the best is within 1 % of it).  cleora_alloc_iterates_for also takes the number of SpMM
  * launches the caller is about to run (0 = unknown) and stops searching when the most it could win — 15 % of a launch per

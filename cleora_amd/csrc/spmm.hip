@@ -651,12 +651,15 @@ int hub_lanes(const cleora_graph *g, uint32_t d) {
     return chain4_ns <= 0.5 * main_ns ? 4 : 2;
 }
 
-// Side stream (highest priority) and the fork / join events of the in-order hub launch, created on first use.
+// Side stream and the fork / join events of the in-order hub launch, created on first use.  DEFAULT priority on purpose: with a
+// highest- (or lowest-) priority stream, the hub launch of the third and fifth handle of a process did not overlap the main kernel
+// at all — 37.4 ms per SpMM instead of 33.1 at C3, the hub launch's 4 ms in front of the main kernel (the runtime keeps few hardware
+// queues per non-default priority) — while default-priority streams overlapped for every handle (32.7-32.9 ms;
+// profiles/r05_hub_schedule_ab.jsonl, scripts/r05/threshold_probe.py).  hipExtAnyOrderLaunch, which would let the two kernels share
+// ONE stream, is not honoured on gfx9 parts (scripts/r05/anyorder_probe.hip: 10.0 ms for two 5 ms kernels).
 int ensure_hub_stream(const cleora_graph *g) {
     if (g->hub_stream) return CLEORA_OK;
-    int lo = 0, hi = 0;
-    CL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    CL_HIP(hipStreamCreateWithPriority(&g->hub_stream, hipStreamNonBlocking, hi));
+    CL_HIP(hipStreamCreateWithFlags(&g->hub_stream, hipStreamNonBlocking));
     CL_HIP(hipEventCreateWithFlags(&g->hub_fork, hipEventDisableTiming));
     CL_HIP(hipEventCreateWithFlags(&g->hub_join, hipEventDisableTiming));
     return CLEORA_OK;

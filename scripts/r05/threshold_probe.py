@@ -43,7 +43,12 @@ out = {"config": cfg, "placement_ms": ms, "ms_per_iteration": {}, "long_rows": {
 for t, gr in graphs.items():
     run(gr, 4)
     out["long_rows"][str(t)] = [int(gr.info().n_hub_rows), int(gr.info().n_inorder_rows), int(gr.info().hub_inorder_min)]
+out["span_parts_ms"] = {}                     # [fork of the hub launch | main kernel | wait for the hub launch] per SpMM, HIP events
 for rep in range(3):
     for t, gr in graphs.items():
+        gr.set_timing(True)
         out["ms_per_iteration"].setdefault(str(t), []).append(round(run(gr, 10), 3))
+        ms3, calls = gr.get_timing()
+        gr.set_timing(False)
+        out["span_parts_ms"].setdefault(str(t), []).append([round(v / max(calls, 1), 3) for v in ms3])
 print(json.dumps(out))

@@ -881,7 +881,36 @@ def project_roofline(n, d, ms, split):
     return out
 
 
-def run_whitened(args, g, x, dev, L, iters):
+def whitened_record_check(config, g, hashes, n, d, graph, L, dev):
+    """The DEFAULT loop (cleora_embed_dev + CLEORA_F_WHITEN, what pycleora.embed() runs) at this workload's FULL size against the
+    ORACLE's loop (oracle.spmm + oracle/whiten.py: pycleora/__init__.py:109-117,130-164) pinned as tests/golden/whitened_loop_<config>.npz
+    — written by tests/golden/make_whitened_loop_record.py from the oracle on the GPU box (4 iterations at config 3, 3 at config 5).
+    Invariants of PCA whitening: pairwise cosines and norms of fixed rows, the spectrum of the covariance the last iteration whitened,
+    and |cov - I| over all rows.  The GPU side is measured live in this run, in the product's order and in the reference's order."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_whitened_loop_record as wrec
+        rec = wrec.load_record(config)
+        if rec is None:
+            return {"error": f"no golden record tests/golden/whitened_loop_{config}.npz for this config"}
+        m = rec["meta"]
+        if (m["n"], m["nnz"], m["d"]) != (n, g["nnz"], d) or m["graph"] != wrec.graph_hash(g):
+            return {"error": "the golden record describes another graph (generator output differs): re-run tests/golden/make_whitened_loop_record.py"}
+        x0 = torch.empty((n, d), dtype=torch.float32, device=dev)
+        _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x0.data_ptr(), d, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        if wrec.hash_array(x0) != m["x0"]:
+            return {"error": "E_0 differs from the golden record's"}
+        out = {"source": f"tests/golden/whitened_loop_{config}.npz (oracle loop: {m['oracle_threads']} host threads, {m['oracle_seconds']} s); the GPU side measured in this run",
+               "default_loop": wrec.gpu_invariants(L, graph, x0, n, d, rec),
+               "reference_order_loop": wrec.gpu_invariants(L, graph, x0, n, d, rec, threshold=1e-30)}
+        out["within_tolerance"] = bool(out["default_loop"]["within_tolerance"] and out["reference_order_loop"]["within_tolerance"])
+        return out
+    except Exception as ex:                                   # noqa: BLE001
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
+
+
+def run_whitened(args, g, x, dev, L, iters, hashes):
     """The default pycleora.embed() loop on one GPU (pycleora/__init__.py:109-117): SpMM + fused L2 norm, then
     whiten_embeddings (cleora_whiten_dev: statistics, f64-MFMA Gram, eigensolver, f32-MFMA projection)."""
     n, nnz, d = g["n"], g["nnz"], args.dim
@@ -969,7 +998,15 @@ def run_whitened(args, g, x, dev, L, iters):
     _hip.check(L.cleora_embed_dev(gr.handle, xo.data_ptr(), _hip.LEFT, d, 2 * iters, 0.0, 0.0, _hip.F_WHITEN, None))
     marginal_ms = (L.cleora_last_embed_loop_ms() - loops["overlapped"] * iters) / iters
     prev = xo
-    cov = torch.cov(prev[: min(n, 2_000_000)].double().T)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_whitened_loop_record as wrec
+    # ALL rows, f64, chunked torch matmuls (rocBLAS dgemm: not a kernel under test) — a 2M-row sample of config 3 read 3e-3 of pure
+    # sampling noise
+    cov_err = float((wrec.covariance_all_rows(prev, n) - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())
+    finite = finite_and_row_sumsq(prev, prev.shape[0])[0]
+    del prev, xo
+    torch.cuda.empty_cache()
+    vs_record = whitened_record_check(args.config, g, hashes, n, d, gr, L, dev)
     out = {
         "ms_per_iter": loops["overlapped"], "iterations": iters, "iterations_per_sec": 1e3 / loops["overlapped"],
         "marginal_ms_per_iter": marginal_ms,
@@ -990,8 +1027,9 @@ def run_whitened(args, g, x, dev, L, iters):
                           "frac": gram_flops / (gram_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TF if gram_ms else 0.0,
                           "executed_flops": gram_flops, "full_flops_2nd2": 2.0 * n * d * d},
         "project_roofline": project_roofline(n, d, proj_ms, split_proj),
-        "checks": {"finite": finite_and_row_sumsq(prev, prev.shape[0])[0],
-                   "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())},
+        "checks": {"finite": finite, "max_abs_cov_minus_identity_all_rows": cov_err,
+                   "cov_note": f"covariance of all {n} rows of the loop's result in f64 (chunked torch matmul), stated bound {'2e-3' if d > 256 else '1e-3'}",
+                   "vs_oracle_record": vs_record},
     }
     gr.close()
     return out
@@ -1129,14 +1167,16 @@ def main():
                 if launcher.max(1.0 if err else 0.0) > 0:
                     whitened_sharded = {"error": err or "another rank failed"}
                 else:
-                    cov = torch.cov(a[: min(n, 2_000_000)].double().T)
+                    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+                    import make_whitened_loop_record as wrec
+                    cov = wrec.covariance_all_rows(a, n)
                     whitened_sharded = {"ms_per_iter": el / args.whiten_iters * 1e3, "iterations": args.whiten_iters,
                                         "loop": "cleora_embed_sharded + CLEORA_F_WHITEN (csrc/sharded.hip: two replicas + the rank's own rows; statistics "
                                                 "all-reduced, one all-gather of the iterate per iteration); wall clock of the call incl. its allocations, "
                                                 "the registration of the replicas and the final PCA whitening; its schedule (statistics, then Z = A Y beside the d x d step, "
                                                 "projection and gather block by block) was never tuned on multi-GPU hardware",
                                         "device_bytes_beside_the_callers_replica": sg.embed_bytes(d, _hip.F_WHITEN),
-                                        "max_abs_cov_minus_identity_2M_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
+                                        "max_abs_cov_minus_identity_all_rows": float((cov - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())}
             elif part == "row":
                 unregister_replicas(comm, a, b)
             if part == "row" and rank == 0 and not args.no_cpu_baseline and cpu is None:
@@ -1183,7 +1223,7 @@ def main():
         del b, iterate, blocks, keep, sg
         torch.cuda.empty_cache()
         if args.whiten_iters > 0 and n * d * 4 * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.8:
-            whitened = run_whitened(args, g, x_w, dev, L, args.whiten_iters)
+            whitened = run_whitened(args, g, x_w, dev, L, args.whiten_iters, hashes)
         elif args.whiten_iters > 0:
             whitened = {"skipped": "the whitened loop keeps three iterates and a workspace resident: does not fit one GPU at this size"}
         if not args.no_end_to_end and n * d * 4 * 4 < torch.cuda.get_device_properties(dev).total_memory * 0.7 and n * d * 4 < (48 << 30):
@@ -1217,12 +1257,12 @@ def main():
             r["roofline"]["frac_untuned_note"] = "median of three launches on the first allocation pair cleora_alloc_iterates drew (what a plain hipMalloc pair runs at)"
         # end-to-end figures of the GPU suite at config 2's size (tests/test_gpu_parity_at_scale.py), quoted from the committed record;
         # a missing file or key is an error in the line, not an empty object (round 4 shipped one)
-        ppath = os.path.join(ROOT, "profiles", "r05_parity_at_scale.json")
+        ppath = os.path.join(ROOT, "profiles", "r06_parity_at_scale.json")
         try:
             pj = json.load(open(ppath))
             plain, dl = pj["plain_loop_c2"], pj["default_loop_40_iterations_c2"]
             r["checks"]["drift_at_scale"] = {
-                "source": "profiles/r05_parity_at_scale.json (tests/test_gpu_parity_at_scale.py at BASELINE config 2's size; NOT measured in this run — "
+                "source": "profiles/r06_parity_at_scale.json (tests/test_gpu_parity_at_scale.py at BASELINE config 2's size; NOT measured in this run — "
                           "this run's own multi-iteration checks are rows_bit_equal_after_those_iterations and plain_loop_vs_oracle_record)",
                 "plain_loop_bit_equal_to_oracle_through_iteration": plain["bit_equal_through_iteration"],
                 "plain_loop_with_CLEORA_F_HUB_SEGMENTS_max_abs_diff_after_10": plain["hub_segments_flag_max_abs_diff_after_10"],
@@ -1230,7 +1270,7 @@ def main():
                 "default_loop_max_abs_cosine_diff_vs_oracle_loop": {"iterations": dl["vs_oracle_loop"]["iterations"], "value": dl["vs_oracle_loop"]["max_abs_cosine_diff_2000_rows"]},
                 "default_loop_stated_tolerance": 1e-4}
         except Exception as ex:                               # noqa: BLE001
-            r["checks"]["drift_at_scale"] = {"error": f"profiles/r05_parity_at_scale.json missing or incomplete: {type(ex).__name__}: {ex}"}
+            r["checks"]["drift_at_scale"] = {"error": f"profiles/r06_parity_at_scale.json missing or incomplete: {type(ex).__name__}: {ex}"}
         out = {
             "metric": METRIC if args.config == "C3" else f"propagate iterations/sec & edges·dim/sec, BASELINE config {args.config}", "value": r["value"], "unit": "edge*dim/s",
             "iterations_per_sec": r["iterations_per_sec"],

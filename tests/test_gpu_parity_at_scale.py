@@ -14,8 +14,8 @@ d = 256) against the CPU oracle's loops on the same graph and the same E_0 — t
     iterations (array_equal) and compares the GPU's hashes with the record at 1, 2, 3, 5, 10, 20 and 40.  Only with
     CLEORA_F_HUB_SEGMENTS does the loop drift (hub rows summed in segments): held to 5e-5, as before.
 
-Tolerances (stated; the measured values of the last GPU run are merged into gpurun_out/r05_parity_at_scale.json — started from
-the committed profiles/r05_parity_at_scale.json, so a partial run never drops a key — and quoted in DESIGN.md §4):
+Tolerances (stated; the measured values of the last GPU run are merged into gpurun_out/r06_parity_at_scale.json — started from
+the committed profiles/r06_parity_at_scale.json, so a partial run never drops a key — and quoted in DESIGN.md §4):
   whitened loop, 4 iterations:  max |cos_gpu - cos_oracle| <= 1e-4, relative row-norm difference <= 1e-4,
                                 max |cov(E_gpu) - I| <= 1e-3 over all rows      (measured round 3: 1.3e-6, 6.1e-7)
   plain loop, 40 iterations:    E_gpu == E_oracle bit for bit; with CLEORA_F_HUB_SEGMENTS max |E_gpu - E_oracle| <= 5e-5 on
@@ -37,7 +37,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-RECORD = "r05_parity_at_scale.json"
+RECORD = "r06_parity_at_scale.json"
 
 
 def _record(key, values):
@@ -139,6 +139,46 @@ def test_whitened_loop_at_c2_size_against_the_oracle_loop(c2, oracle_whitened):
     assert cos_err <= 1e-4, cos_err
     assert norm_err <= 1e-4, norm_err
     assert cov_err <= 1e-3, cov_err
+
+
+def test_whitened_loop_record_at_c2_size_is_what_the_live_oracle_computes_and_the_gpu_matches_it(c2, oracle_whitened):
+    """the default loop at BASELINE's FULL sizes (config 3: 10M x 256, config 5: 2M x 1024) is pinned by
+    records of the oracle's loop (tests/golden/whitened_loop_{C3,C5}.npz, written by tests/golden/make_whitened_loop_record.py on the
+    GPU box; bench.py compares the GPU with them in every run: `whitened.checks.vs_oracle_record`).  Here the same machinery at
+    config 2's size, where the oracle also runs LIVE: (1) the record equals what the live oracle loop computes (invariants to 1e-5:
+    the oracle itself is only reproducible to the order of its BLAS's summation), (2) the GPU's default loop and its
+    reference-order loop match the record within the stated tolerances — cosines and row norms 1e-4, spectrum 1e-4 of the largest
+    eigenvalue, |cov - I| over all rows 1e-3."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_whitened_loop_record as wrec
+    from tests.golden.make_plain_loop_hashes import hash_array
+    n, nnz, graph, host, hashes = c2
+    d = 256
+    rec = wrec.load_record("C2")
+    assert rec is not None, "tests/golden/whitened_loop_C2.npz is missing"
+    m = rec["meta"]
+    here = "-".join(hash_array(np.ascontiguousarray(host[k]).reshape(-1, 1)) for k in ("rowptr", "col", "val"))
+    x0 = oracle.init(hashes, d, 0)
+    if (m["n"], m["nnz"], m["d"]) != (n, nnz, d) or m["graph"] != here or m["x0"] != hash_array(x0):
+        pytest.skip("the golden record describes another graph (generator output differs on this torch build)")
+    iters = int(m["iterations"])
+    # (1) the live oracle (the module's shared loop: iterations 1-4 are also what the test above uses)
+    oracle_whitened.advance_to(iters, keep=(iters,))
+    want = oracle_whitened.snap[iters]
+    live = wrec.compare(rec, want[rec["rows"]], np.linalg.norm(want[rec["norm_rows"]].astype(np.float64), axis=1))
+    assert live["max_abs_cosine_diff"] <= 1e-5 and live["max_rel_row_norm_diff"] <= 1e-5, live
+    # (2) the GPU against the record
+    L = _hip.lib()
+    x0_dev = torch.from_numpy(x0).to("cuda:0")
+    res = {"default_loop": wrec.gpu_invariants(L, graph, x0_dev, n, d, rec),
+           "reference_order_loop": wrec.gpu_invariants(L, graph, x0_dev, n, d, rec, threshold=1e-30)}
+    _record("whitened_loop_record_c2", {"record_vs_live_oracle": {k: live[k] for k in ("max_abs_cosine_diff", "max_rel_row_norm_diff")},
+                                        "gpu_vs_record": {k: {a: b for a, b in v.items() if a != "tolerances"} for k, v in res.items()}})
+    for name, r in res.items():
+        assert r["finite"] and r["within_tolerance"], (name, r)
+        assert r["max_abs_cov_minus_identity_all_rows"] <= 1e-3, (name, r)
 
 
 def test_default_loop_with_a_residual_blend_at_c2_size(c2):

@@ -16,7 +16,7 @@ OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE, E_RCCL = 0, -1, -2, -3, -4, -5
 LEFT, SYMMETRIC = 0, 1
 F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
 F_L1NORM, F_BLEND_ANY, F_SQDIFF64, F_HUB_SEGMENTS = 128, 256, 512, 1024
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 ALLGATHER_RING, ALLGATHER_P2P, ALLGATHER_PEER = 0, 1, 2
 BALANCE_AUTO, BALANCE_ROWS, BALANCE_NNZ = 0, 1, 2
@@ -125,6 +125,9 @@ SIGNATURES = {
     "cleora_project_general_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp, vp, c_u64, c_f32, c_f32, c_int,
                                            ctypes.POINTER(c_int), vp]),
     "cleora_csr_rowsum_dev": (c_int, [vp, c_int, vp, vp]),
+    "cleora_csr_rowsums_dev": (c_int, [vp, c_int, vp, vp, vp]),
+    "cleora_project_bounded_dev": (c_int, [vp, c_u64, c_u64, c_u32, vp, vp, c_u32, vp, c_u64, vp, vp, c_int, ctypes.POINTER(c_int),
+                                           ctypes.POINTER(c_int), vp]),
     "cleora_mean_dev": (c_int, [vp, c_u64, c_u32, vp, vp, vp]),
     "cleora_eigh_workspace": (c_u64, [c_u32]),
     "cleora_whiten_transform_dev": (c_int, [vp, c_u64, c_u32, c_u32, vp, vp, vp, vp]),

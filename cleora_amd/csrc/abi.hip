@@ -576,6 +576,33 @@ int cleora_project_general_dev(const float *x, uint64_t ldx, uint64_t n, uint32_
     return rc;
 }
 
+int cleora_csr_rowsums_dev(const cleora_graph *g, int markov_type, float *rowsum_dev, float *rowabs_dev, void *stream) {
+    CL_REQUIRE(g != nullptr && rowsum_dev != nullptr, "graph / rowsum is NULL");
+    CL_REQUIRE(markov_type == CLEORA_LEFT || markov_type == CLEORA_SYMMETRIC, "unknown markov_type");
+    CL_REQUIRE(g->val[markov_type] != nullptr, "graph has no values for this markov_type");
+    return launch_csr_rowsum(g, markov_type, rowsum_dev, S(stream), rowabs_dev);
+}
+
+int cleora_project_bounded_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean_f32_dev,
+                               const float *transform_dev, uint32_t k, float *out, uint64_t ldo, const float *rowscale_dev,
+                               const float *rowbound_dev, int norm, int *norm_done, int *form, void *stream) {
+    CL_REQUIRE(norm >= 0 && norm <= 2, "norm must be 0, 1 or 2");
+    CL_REQUIRE(d > 0 && k > 0 && ldx >= d && ldo >= k, "bad d / k / leading dimension");
+    CL_REQUIRE(x != nullptr && mean_f32_dev != nullptr && transform_dev != nullptr && out != nullptr, "x / mean / transform / out is NULL");
+    CL_REQUIRE((const void *)x != (const void *)out, "x and out must not alias");
+    if (form) *form = 0;
+    if (n > 0 && project_f16_applies(x, ldx, n, d, k, out, ldo, nullptr)) {
+        if (form) *form = 1;
+        if (norm_done) *norm_done = norm != 0;
+        return launch_project_f16(x, ldx, n, mean_f32_dev, transform_dev, out, ldo, S(stream), rowscale_dev, rowbound_dev, norm);
+    }
+    bool done = false;
+    const int rc = launch_project(x, ldx, n, d, mean_f32_dev, transform_dev, k, out, ldo, S(stream), rowscale_dev, nullptr, 0, 1.0f, 0.0f,
+                                  norm, &done);
+    if (norm_done) *norm_done = done ? 1 : 0;
+    return rc;
+}
+
 int cleora_csr_rowsum_dev(const cleora_graph *g, int markov_type, float *rowsum_dev, void *stream) {
     CL_REQUIRE(g != nullptr && rowsum_dev != nullptr, "graph / rowsum is NULL");
     CL_REQUIRE(markov_type == CLEORA_LEFT || markov_type == CLEORA_SYMMETRIC, "unknown markov_type");
@@ -901,9 +928,13 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     const bool any_whitening = norm == CLEORA_F_L2NORM;                   // rotation invariance needs the L2 norm
     int rc;
     if (iterations == 0) { *result = b0; return CLEORA_OK; }
-    DevBuf ws, rowsum;
+    DevBuf ws, rowsum, rowabs;
     if ((rc = ws.alloc(whiten_workspace(n, d))) != CLEORA_OK) return rc;
     if ((rc = rowsum.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
+    // intermediate projections at d = 256 without a blend: the f16 form (project_f16.hip) — its operand Z = A Y is bounded row by
+    // row by the sum of |values| because Y's rows are normalised (L2 or L1: |Y| <= 1 either way)
+    const bool f16_project = !blend && n > 1 && project_f16_applies(b0, d, n, d, d, b1, d, nullptr);
+    if (f16_project && (rc = rowabs.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
     struct Streams {
         hipStream_t a = nullptr, b = nullptr;
         hipEvent_t ya = nullptr, fb = nullptr, gs = nullptr;
@@ -936,7 +967,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     CL_HIP(hipEventCreateWithFlags(&st.gs, hipEventDisableTiming));
     CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
     const auto t_loop = std::chrono::steady_clock::now();
-    if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a)) != CLEORA_OK) return rc;
+    if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a, f16_project ? rowabs.as<float>() : nullptr)) != CLEORA_OK) return rc;
     // Y_0 = normalise(A E_0 [+ blend]): the ordinary fused launch
     if ((rc = launch_propagate(g, markov_type, b0, d, d, b1, d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, b0,
                                nullptr, nullptr, st.a)) != CLEORA_OK)
@@ -973,8 +1004,14 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
         if (n > 1) {
             // P = (alpha (Z - s mu^T) + rw (Y - mu)) T, then the row normalisation: Y of the next iteration
             bool normed = false;
-            rc = launch_project(b0, d, n, d, mean32, transform, d, ynext, d, st.a, rowsum.as<float>(), blend ? y : nullptr, d,
-                                1.0f - rw, rw, norm == CLEORA_F_L1NORM ? 2 : 1, &normed);
+            if (f16_project) {
+                rc = launch_project_f16(b0, d, n, mean32, transform, ynext, d, st.a, rowsum.as<float>(), rowabs.as<float>(),
+                                        norm == CLEORA_F_L1NORM ? 2 : 1);
+                normed = true;
+            } else {
+                rc = launch_project(b0, d, n, d, mean32, transform, d, ynext, d, st.a, rowsum.as<float>(), blend ? y : nullptr, d,
+                                    1.0f - rw, rw, norm == CLEORA_F_L1NORM ? 2 : 1, &normed);
+            }
             if (rc != CLEORA_OK) return rc;
             if (!normed && (rc = launch_rowops(ynext, d, n, d, ynext, d, norm | fast, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
         } else {

@@ -130,7 +130,7 @@ int launch_reduce_sum(const double *v, uint64_t n, double *ws, double *out, hipS
 uint64_t colsum_workspace(uint64_t n, uint32_t d);
 int launch_colsum(const float *x, uint64_t ldx, uint64_t n, uint32_t d, double *ws, double *out,
                   hipStream_t stream);
-int launch_csr_rowsum(const cleora_graph *g, int kind, float *out, hipStream_t stream);
+int launch_csr_rowsum(const cleora_graph *g, int kind, float *out, hipStream_t stream, float *abs_out = nullptr);   // abs_out: sum of |values| per row
 int launch_cosine(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *q, float *scores,
                   hipStream_t stream);
 // whiten.hip
@@ -149,6 +149,12 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
                    const float *rowscale = nullptr, const float *x2 = nullptr, uint64_t ldx2 = 0, float alpha = 1.0f,
                    float beta = 0.0f, int norm = 0,           // norm: 1 = L2-, 2 = L1-normalise the output rows in the epilogue ...
                    bool *norm_done = nullptr);                // ... if the shape allows (reported here); else the caller runs rowops
+
+// project_f16.hip: the projection for BOUNDED operands (|x[r][j]| <= rowbound[r], |mean[j]| <= 1) at d = k = 256 — three f16 MFMAs per
+// product, the transform resident in registers; the whitened loop's intermediate iterations
+bool project_f16_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, const float *out, uint64_t ldo, const float *x2);
+int launch_project_f16(const float *x, uint64_t ldx, uint64_t n, const float *mean, const float *t, float *out, uint64_t ldo,
+                       hipStream_t stream, const float *rowscale, const float *rowbound, int norm);
 
 // similarity.hip
 uint64_t topk_workspace_bytes(uint64_t n, uint32_t k, uint32_t n_queries);

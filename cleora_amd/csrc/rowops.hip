@@ -173,25 +173,36 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // s[r] = sum of the stored values of row r = (A 1)[r]: what the propagate-before-project form of the whitened loop
 // needs to move the mean through the SpMM, A (Y - 1 mu^T) = A Y - s mu^T.  One wavefront per row, f64 partials.
 __global__ __launch_bounds__(256) void csr_rowsum_kernel(const uint64_t *__restrict__ rowptr, const float *__restrict__ val,
-                                                         uint64_t n_rows, float *__restrict__ out) {
+                                                         uint64_t n_rows, float *__restrict__ out, float *__restrict__ abs_out) {
     const int lane = threadIdx.x & 63;
     const uint64_t row = CLEORA_LINEAR_BLOCK() * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
-    double s = 0.0;
-    for (uint64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) s += (double)val[e];
+    double s = 0.0, sa = 0.0;
+    for (uint64_t e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) {
+        const double v = (double)val[e];
+        s += v;
+        sa += fabs(v);
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) out[row] = (float)s;
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        sa += __shfl_xor(sa, o, 64);
+    }
+    if (lane == 0) {
+        out[row] = (float)s;
+        // rounded UP: this is a bound on |(A y)[r][j]| for |y| <= 1 (project_f16.hip scales a row by it)
+        if (abs_out) abs_out[row] = __double2float_ru(sa);
+    }
 }
 
 }  // namespace
 
-int launch_csr_rowsum(const cleora_graph *g, int kind, float *out, hipStream_t stream) {
+int launch_csr_rowsum(const cleora_graph *g, int kind, float *out, hipStream_t stream, float *abs_out) {
     CL_REQUIRE(g != nullptr && out != nullptr, "graph / out is NULL");
     CL_REQUIRE((kind == CLEORA_LEFT || kind == CLEORA_SYMMETRIC) && g->val[kind] != nullptr, "no values for this markov_type");
     if (g->n_rows == 0) return CLEORA_OK;
     hipLaunchKernelGGL(csr_rowsum_kernel, grid_1d_as_2d((g->n_rows + 3) / 4), dim3(256), 0, stream, g->rowptr, g->val[kind],
-                       g->n_rows, out);
+                       g->n_rows, out, abs_out);
     CL_HIP(hipGetLastError());
     return CLEORA_OK;
 }

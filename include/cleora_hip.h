@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define CLEORA_ABI_VERSION 4
+#define CLEORA_ABI_VERSION 5
 
 #define CLEORA_OK 0
 #define CLEORA_E_INVALID (-1)   /* bad argument (shape, null pointer, unknown enum) */
@@ -269,6 +269,20 @@ int cleora_project_general_dev(const float *x, uint64_t ldx, uint64_t n, uint32_
 /* rowsum[r] = sum of the stored values of row r (f32, stored order): s = A 1 of the identity above; 1 for every row of a
  * row-stochastic left Markov matrix up to rounding, anything for symmetric values or trimmed hyperedges. */
 int cleora_csr_rowsum_dev(const cleora_graph *g, int markov_type, float *rowsum_dev, void *stream);
+/* The same plus rowabs[r] = sum of |values| of row r, rounded up: a bound on |(A Y)[r][j]| for |Y| <= 1 (may be NULL). */
+int cleora_csr_rowsums_dev(const cleora_graph *g, int markov_type, float *rowsum_dev, float *rowabs_dev, void *stream);
+
+/* The same projection for BOUNDED operands — what the loop's intermediate iterations have: x = A Y with unit rows Y, so
+ * |x[r][j]| <= rowbound[r] (cleora_csr_rowsums_dev's rowabs; NULL: 1) and |mean[j]| <= 1 —
+ *     out[r,:] = normalise( (x[r,:] - rowscale[r] * mean) @ transform )
+ * At d = k = 256 this takes the f16 matrix cores with the transform resident in registers (csrc/project_f16.hip: operands scaled
+ * into the f16 range by per-row / per-column powers of two, each f32 product from three f16 MFMAs of two-way split operands:
+ * 2^-22 per product, the error class of the f32 GEMM of pycleora/__init__.py:163); *form (host, may be NULL) reports 1 when it
+ * did, 0 when the call fell back to cleora_project_general_dev's kernel (any other shape).  An operand that violates its bound
+ * overflows f16: the result is then inf / NaN, never silently wrong.  norm as above, always applied when *form == 1. */
+int cleora_project_bounded_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean_f32_dev,
+                               const float *transform_dev, uint32_t k, float *out, uint64_t ldo, const float *rowscale_dev,
+                               const float *rowbound_dev, int norm, int *norm_done, int *form, void *stream);
 
 /* mean64[c] = colsum[c] / n (f64, :136) and mean32[c] = (float)mean64[c] (:159), on the device. */
 int cleora_mean_dev(const double *colsum_dev, uint64_t n, uint32_t d, double *mean64_dev,

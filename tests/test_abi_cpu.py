@@ -30,7 +30,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_abi_version_and_error_channel():
     L = _hip.lib()
-    assert L.cleora_abi_version() == _hip.ABI_VERSION == 4
+    assert L.cleora_abi_version() == _hip.ABI_VERSION == 5
     # argument validation happens before any device work
     n = ctypes.c_int(-1)
     assert L.cleora_device_count(ctypes.byref(n)) == _hip.OK and n.value >= 0

@@ -364,3 +364,65 @@ def test_projection_error_against_an_f64_product(n, d, k):
     erms = float(np.sqrt(((got - ref) ** 2).mean()) / np.abs(ref).max())
     grow = max(1.0, (d / 1024) ** 0.5)                    # f32 rounding of a d-term sum grows like sqrt(d): measured 2.07e-6 / 2.07e-7 at d = 4096
     assert emax <= 2e-6 * grow and erms <= 3e-7 * grow, (emax, erms)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 5003, 70_001])
+@pytest.mark.parametrize("norm,scaled", [(1, True), (0, False), (2, True), (1, False)])
+def test_bounded_projection_on_the_f16_matrix_cores(n, norm, scaled):
+    """cleora_project_bounded_dev at d = k = 256 (csrc/project_f16.hip: the intermediate projections of the whitened loop — operands
+    bounded row by row, every f32 product from three f16 MFMAs of two-way split operands scaled by powers of two, the transform
+    resident in registers) against an f64 product of the same f32 inputs: row bounds over five decades (what symmetric Markov values or
+    trimmed hyperedges give), transform columns over five decades (1 / sqrt(eigenvalue)), all norms, with and without row scales,
+    ragged last tiles.  Stated: every row within 2e-6 of its own norm (measured 5e-7; the six-product bf16 form reads 7e-7 on the
+    same data, scripts/r06/project_probe.py) — the error class of the f32 GEMM of pycleora/__init__.py:163."""
+    import ctypes
+    L = _hip.lib()
+    d = 256
+    rng = np.random.default_rng(n + 7 * norm + scaled)
+    bound = np.where(rng.random(n) < 0.8, 1.0, 10 ** (rng.random(n) * 4 - 1)).astype(np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x *= (bound * (0.2 + 0.8 * rng.random(n)))[:, None].astype(np.float32)
+    x = np.minimum(np.maximum(x, -bound[:, None]), bound[:, None]).astype(np.float32)
+    rowscale = (bound * (2 * rng.random(n) - 1)).astype(np.float32)
+    mean = np.clip(rng.standard_normal(d) * 0.05, -1, 1).astype(np.float32)
+    t = (rng.standard_normal((d, d)) * 10 ** (rng.random(d) * 5 - 2)[None, :]).astype(np.float32)
+    dx, dm, dt, ds, db = (_hip.DevArray.from_host(a) for a in (x, mean, t, rowscale, bound))
+    do = _hip.DevArray((n, d), np.float32)
+    nd, form = ctypes.c_int(0), ctypes.c_int(-1)
+    _hip.check(L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, do.ptr, d, ds.ptr if scaled else None, db.ptr, norm,
+                                            ctypes.byref(nd), ctypes.byref(form), None))
+    _hip.check(L.cleora_stream_sync(None))
+    assert form.value == 1 and nd.value == (1 if norm else 0)
+    got = do.to_host().astype(np.float64)
+    ref = (x.astype(np.float64) - (rowscale.astype(np.float64)[:, None] if scaled else 1.0) * mean.astype(np.float64)[None, :]) @ t.astype(np.float64)
+    if norm == 1:
+        ref /= np.maximum(np.linalg.norm(ref, axis=1, keepdims=True), 1e-10)
+    elif norm == 2:
+        ref /= np.maximum(np.abs(ref).sum(axis=1, keepdims=True), 1e-10)
+    assert np.isfinite(got).all()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)
+    assert err.max() <= 2e-6, float(err.max())
+
+
+def test_bounded_projection_falls_back_for_other_shapes_and_checks_its_arguments():
+    """Any shape but d = k = 256 takes cleora_project_general_dev's kernel (*form == 0) with the same result contract."""
+    import ctypes
+    L = _hip.lib()
+    n, d = 3000, 128
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    mean = x.mean(axis=0).astype(np.float32)
+    t = rng.standard_normal((d, d)).astype(np.float32)
+    dx, dm, dt = (_hip.DevArray.from_host(a) for a in (x, mean, t))
+    do = _hip.DevArray((n, d), np.float32)
+    nd, form = ctypes.c_int(0), ctypes.c_int(-1)
+    _hip.check(L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, do.ptr, d, None, None, 1, ctypes.byref(nd), ctypes.byref(form), None))
+    _hip.check(L.cleora_stream_sync(None))
+    assert form.value == 0 and nd.value == 1
+    ref = (x - mean).astype(np.float64) @ t.astype(np.float64)
+    ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    assert np.abs(do.to_host() - ref).max() <= 2e-6
+    assert L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, do.ptr, d, None, None, 3, None, None, None) == _hip.E_INVALID
+    assert L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, dx.ptr, d, None, None, 1, None, None, None) == _hip.E_INVALID

@@ -39,7 +39,7 @@ def read_tsv(path):
 def test_headers_are_plain_c(tmp_path):
     src = tmp_path / "t.c"
     src.write_text('#include "cleora_hip.h"\n#include "cleora_host.h"\n'
-                   "int main(void) { cleora_graph_info i; (void)i; return CLEORA_ABI_VERSION == 4 ? 0 : 1; }\n")
+                   "int main(void) { cleora_graph_info i; (void)i; return CLEORA_ABI_VERSION == 5 ? 0 : 1; }\n")
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src),
                            "-o", str(tmp_path / "t.o")])

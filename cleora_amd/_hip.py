@@ -104,6 +104,7 @@ SIGNATURES = {
     "cleora_graph_get_info": (c_int, [vp, ctypes.POINTER(GraphInfo)]),
     "cleora_graph_set_hot_cache": (c_int, [vp, c_i64]),
     "cleora_graph_set_hub_lanes": (c_int, [vp, c_int]),
+    "cleora_graph_set_hub_chain_min": (c_int, [vp, c_u64]),
     "cleora_graph_set_hub_inorder_min": (c_int, [vp, c_u64]),
     "cleora_graph_set_timing": (c_int, [vp, c_int]),
     "cleora_graph_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 3), ctypes.POINTER(c_u64)]),
@@ -288,6 +289,10 @@ class Graph:
     def set_hub_inorder_min(self, min_edges):
         """Long rows with more than min_edges edges run on the in-order hub launch, the others first in the main launch (same bits)."""
         check(lib().cleora_graph_set_hub_inorder_min(self.handle, int(min_edges)))
+
+    def set_hub_chain_min(self, min_edges):
+        """cleora_graph_set_hub_chain_min: rows of the hub launch with at least this many edges take the chain kernel (0 = automatic)."""
+        check(lib().cleora_graph_set_hub_chain_min(self.handle, int(min_edges)))
 
     def set_hub_lanes(self, lanes):
         """Lanes per edge of the in-order hub launch: 0 automatic, 4 / 2 forced (same bits either way)."""

@@ -79,6 +79,8 @@ int build_inorder_tables(cleora_graph *g) {
     g->mid_rows = g->io_rows = g->hub_by_len = nullptr;
     g->n_mid_rows = mid.size();
     g->n_io_rows = io.size();
+    g->io_len_desc.resize(io.size());
+    for (size_t i = 0; i < io.size(); ++i) g->io_len_desc[i] = io_len[io_order[i]];
     auto up = [&](uint32_t **dst, const std::vector<uint32_t> &v) -> int {
         if (v.empty()) return CLEORA_OK;
         CL_HIP(hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(uint32_t)));
@@ -420,6 +422,13 @@ int cleora_graph_set_hub_lanes(cleora_graph *g, int lanes) {
     CL_REQUIRE(lanes == 0 || lanes == 2 || lanes == 4, "lanes per edge: 0 (automatic), 4 or 2");
     std::lock_guard<std::mutex> lock(g->mu);
     g->hub_lanes = lanes;
+    return CLEORA_OK;
+}
+
+int cleora_graph_set_hub_chain_min(cleora_graph *g, uint64_t min_edges) {
+    CL_REQUIRE(g != nullptr, "graph handle is NULL");
+    std::lock_guard<std::mutex> lock(g->mu);
+    g->hub_chain_min = min_edges;
     return CLEORA_OK;
 }
 

@@ -74,6 +74,8 @@ struct cleora_graph {
     uint32_t *mid_rows = nullptr;       // [n_mid_rows]  row ids, longest first
     uint32_t *io_rows = nullptr;        // [n_io_rows]   row ids (ascending): scratch row h belongs to io_rows[h]
     uint32_t *hub_by_len = nullptr;     // [n_io_rows]   indices into io_rows, longest row first
+    std::vector<uint64_t> io_len_desc;  // host: the edge counts in hub_by_len's order (what hub_chain_rows() decides on)
+    mutable uint64_t hub_chain_min = 0; // rows of the hub launch with at least this many edges take hub_chain_kernel: 0 = automatic
     bool hub_inorder_ok = true;         // false: some row is too long for the kernel's 32-bit (col, val) offsets
     uint64_t hub_longest = 0;           // edges of the longest row
     mutable int hub_lanes = 0;          // lanes per edge of the in-order hub launch: 0 = automatic (spmm.hip hub_lanes), else 4 / 2 / 1

@@ -59,6 +59,7 @@ struct SpmmArgs {
     const uint32_t *hub_by_len;   // hub indices, longest row first
     uint64_t nnz;
     uint32_t n_slabs;             // 64-column slabs per row
+    uint32_t hub_first;           // hub_inorder_kernel: its first row in hub_by_len (the rows before it take hub_chain_kernel)
     RowArgs r;
 };
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hu
     const int q = QUAD ? (lane & 15) / (QUAD ? L : 1) : 0;                        // which edge of the step this lane loads
     const uint64_t item = CLEORA_LINEAR_BLOCK();
     const uint32_t k = (uint32_t)(item / a.n_slabs), slab = (uint32_t)(item - (uint64_t)k * a.n_slabs);
-    const uint32_t h = a.hub_by_len[k];
+    const uint32_t h = a.hub_by_len[k + a.hub_first];
     const uint64_t row = a.hub_rows[h];
     const uint64_t beg = a.rowptr[row], n = a.rowptr[row + 1] - beg;
     const uint32_t d = a.r.d;
@@ -429,6 +430,140 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void hu
         if (in_range && (uint32_t)q == (uint32_t)((n - 1) % EPS)) *reinterpret_cast<float4 *>(p) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     } else {
         if (in_range) *p = acc[0];
+    }
+}
+
+// ---- the LONGEST rows: products by producer waves, the in-order chain by a wave that only adds -------------------------------
+// hub_inorder_kernel's wavefront does everything for its (row, slab): (col, val) staging, address arithmetic, gathers, products and
+// the chain of adds — ~30 instructions per 4 edges in ONE in-order instruction stream.  Alone beside a 33 ms main kernel that is
+// hidden; for one rank of an 8-way partition it is the critical path (profiles/r06_plan_c3.json: the rank that owns C3's longest
+// row, 431 465 edges, needs 11.3 ms for its blocks against 4.2 ms with the segmented sum: 26 ns per edge), and a 10^7-edge hub
+// costs 0.3 s per SpMM.  Here the chain wave does NOTHING but add: a block is 8 waves for one (row, 64-column slab) —
+//   * seven PRODUCER waves gather (one 16-byte load per lane covers four edges x 64 columns, like the QUAD form), multiply by the
+//     edge values (fmul: the reference's `v * src`, src/embedding.rs:80-82) and write the PRODUCTS to an LDS ring, [edge][column];
+//     each keeps D chunks of loads in flight.  Vector-memory operations retire in order, so every load of the loop has the same
+//     lead: the gathers and values of chunk c + D and the columns of chunk c + 2 D are issued during chunk c (6 operations per
+//     chunk, 48 in flight at D = 8; the counter reaches 63): 7 x 8 x 16 = 896 edges in flight per block;
+//   * the CONSUMER wave owns one column per lane and adds the products in stored order, two edges per LDS instruction
+//     (ds_read2st64_b32) + two dependent adds (fadd: `acc += ...`), the reads of the next group in flight under the adds;
+//   * chunks of 112 edges alternate between two ring halves, one barrier per chunk: producers fill chunk c while the consumer adds
+//     chunk c - 1.
+// Same products, same order of additions: the bits of hub_inorder_kernel and of the reference.  Measured (rocprofv3, one rank's
+// blocks of C3 / 8 alone on the GPU): 3.0 ms for the 431 465-edge row = 6.9 ns per edge — the consumer's ~2 instructions per edge
+// in one wave's issue slots; a form that computed the products in a separate launch on every CU and streamed them in ran the same
+// 3.0 ms (the gathers are not what bounds it) plus the products' 1.6 ms, and is not kept.  Taken for the few longest rows only
+// (hub_chain_rows()): a block holds a whole CU's registers.
+constexpr int HC_NP = 7, HC_U = 4, HC_CH = HC_NP * HC_U * 4;     // producers, loads per producer and chunk, edges per chunk (112)
+// the block's barrier as an LDS-only hand-off (the producers' global loads are consumed by the producers themselves)
+__device__ __forceinline__ void hc_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void hub_chain_kernel(const SpmmArgs a) {
+    static_assert(D % 2 == 0, "ring halves are compile-time functions of the unrolled interval");
+    __shared__ __attribute__((aligned(16))) float ring[2][HC_CH][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t item = CLEORA_LINEAR_BLOCK();
+    const uint32_t k = (uint32_t)(item / a.n_slabs), slab = (uint32_t)(item - (uint64_t)k * a.n_slabs);
+    const uint32_t h = a.hub_by_len[k];
+    const uint64_t row = a.hub_rows[h];
+    const uint64_t beg = a.rowptr[row], n = a.rowptr[row + 1] - beg;
+    const uint32_t d = a.r.d;
+    const uint64_t nchunks = (n + HC_CH - 1) / HC_CH;
+    // interval j: producers make chunk j, the consumer adds chunk j - 1; whole trips of D intervals (the surplus ones are idle)
+    const uint64_t trips = (nchunks + 1 + D - 1) / D;
+    if (w == 0) {
+        // ---- consumer: lane = column ----------------------------------------------------------------------------------
+        float acc = 0.f;
+        for (uint64_t j = 0; j < trips * D; ++j) {
+            if (j >= 1 && j <= nchunks) {
+                const float *r = &ring[(j - 1) & 1][0][lane];
+                const uint64_t done = (j - 1) * HC_CH;
+                if (n - done >= (uint64_t)HC_CH) {
+                    // eight groups of 14 products through two register sets: the reads of group g + 1 are in flight under the adds of
+                    // group g (7 ds_read2st64 per group: the LDS counter tracks 15 operations, two groups fit), ONE wait per group
+                    // (LDS reads return in order: "at most 7 outstanding" = the current group has landed).  Left to itself the compiler
+                    // read eight products, waited for all of them, added, and paid the LDS latency fourteen times per chunk
+                    constexpr int NG = 8, GR = HC_CH / NG;
+                    float v[2][GR];
+#pragma unroll
+                    for (int e = 0; e < GR; ++e) v[0][e] = r[e * 64];
+#pragma unroll
+                    for (int grp = 0; grp < NG; ++grp) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (grp + 1 < NG) {
+#pragma unroll
+                            for (int e = 0; e < GR; ++e) v[(grp + 1) & 1][e] = r[((grp + 1) * GR + e) * 64];
+                            __builtin_amdgcn_s_waitcnt(0xC77F);                   // lgkmcnt(7)
+                        } else {
+                            __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0)
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < GR; ++e) acc = fadd(acc, v[grp & 1][e]);
+                    }
+                } else {
+                    const uint32_t left = (uint32_t)(n - done);
+                    for (uint32_t e = 0; e < left; ++e) acc = fadd(acc, r[e * 64]);
+                }
+            }
+            hc_barrier();
+        }
+        const uint32_t c = slab * 64u + (uint32_t)lane;
+        if (c < d) a.partial[(uint64_t)h * d + c] = acc;
+        return;
+    }
+    // ---- producers: lane = (edge quad qr | four columns) -------------------------------------------------------------
+    const int p = w - 1, qr = lane >> 4, i4 = lane & 15;
+    const uint32_t coff = slab * 64u + 4u * (uint32_t)i4;
+    const float *xb = a.x + (coff < d ? coff : 0u);                               // (columns past d: a valid address; the consumer never stores them)
+    const uint64_t left_bytes = (a.nnz - beg) * 4u;
+    const int records = (int)(left_bytes > 0xfffffffcull ? 0xfffffffcu : (uint32_t)left_bytes);
+    const auto rs_col = __builtin_amdgcn_make_buffer_rsrc((void *)(a.col + beg), 0, records, 0x00020000);
+    const auto rs_val = __builtin_amdgcn_make_buffer_rsrc((void *)(a.val + beg), 0, records, 0x00020000);
+    // this lane's four edges of chunk c: c * 112 + 16 p + 4 qr + u; entries past the row's end are the next rows' (valid gather
+    // addresses, products never added) or, past the array, zero
+    const uint32_t lane_edge = (uint32_t)(16 * p + 4 * qr);
+    auto stream_off = [&](uint64_t chunk) { return (int)(uint32_t)((chunk * HC_CH + lane_edge) * 4u); };
+    const uint32_t ldx32 = (uint32_t)a.ldx;                                       // < 2^32 (checked by the launcher)
+    auto gather = [&](uint32_t c) { return *reinterpret_cast<const float4 *>(xb + (uint64_t)c * ldx32); };
+    float4 g[D][HC_U];
+    u32x4 pc[D], pv[D];
+#pragma unroll
+    for (int s = 0; s < D; ++s) pc[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_col, stream_off(s), 0, 0);
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+#pragma unroll
+        for (int u = 0; u < HC_U; ++u) g[s][u] = gather(pc[s][u]);
+        pv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_val, stream_off(s), 0, 0);
+        pc[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_col, stream_off(D + s), 0, 0);
+        // (in this order: a prologue the scheduler rearranges — it issued chunk 0's values LAST — makes the loop's first wait a full
+        // drain, on the entry path and therefore, merged, on every trip)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (uint64_t c0 = 0; c0 < trips * D; c0 += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const uint64_t c = c0 + s;
+            float4 *const dst = reinterpret_cast<float4 *>(&ring[s & 1][lane_edge][4 * i4]);      // (c & 1 == s & 1: D is even)
+            // the products of chunk c, THEN the refill of the same registers (chunk c + D): no copies at the loop's back edge
+#pragma unroll
+            for (int u = 0; u < HC_U; ++u) {
+                const float wv = __uint_as_float(pv[s][u]);
+                dst[16 * u] = make_float4(fmul(wv, g[s][u].x), fmul(wv, g[s][u].y), fmul(wv, g[s][u].z), fmul(wv, g[s][u].w));
+            }
+            // (the scheduler must not lift a refill above a product that still reads the old value: it would keep the old value in a
+            // copy made at the loop's back edge, behind a wait for nearly everything in flight)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < HC_U; ++u) g[s][u] = gather(pc[s][u]);
+            pv[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_val, stream_off(c + D), 0, 0);
+            pc[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_col, stream_off(c + 2 * D), 0, 0);
+            hc_barrier();
+        }
     }
 }
 
@@ -644,10 +779,32 @@ inline void mark(const cleora_graph *g, hipStream_t stream) {
 // estimated chain stays under HALF the main kernel's estimated time, else the 2-lane form.  Narrower forms cost proportionally more
 // vector instructions in total, so the wide form stays wherever the chain is hidden anyway (C5: 1.13 M edges beside 190 ms).
 // g->hub_lanes != 0 forces a form (cleora_graph_set_hub_lanes: tests, A/B runs).
+// Rows of the in-order hub launch (longest first) that take hub_chain_kernel.  Automatic: the rows whose chain in hub_inorder_kernel
+// (26 ns per edge measured with an idle memory system, 52 under a saturating main kernel) would outlast a quarter of the main kernel's
+// estimated time — config 3 on one GPU: the one row of 431 465 edges; a 6 M-edge block of an 8-way partition: every row beyond ~10 k
+// edges — at least 4 096 edges, at most 128 blocks (a block holds a CU's whole register file).  g->hub_chain_min forces a threshold
+// (cleora_graph_set_hub_chain_min: 1 = every row of the hub launch, UINT64_MAX = none).
+uint64_t hub_chain_rows(const cleora_graph *g, uint32_t d) {
+    if (g->io_len_desc.empty()) return 0;
+    uint64_t min_edges = g->hub_chain_min, cap_blocks = ~0ull;
+    if (min_edges == 0) {
+        const double main_ns = (double)g->nnz * (double)d * 4.0 / 6.4e3;      // bytes / (6.4e12 B/s) in ns
+        min_edges = (uint64_t)(0.25 * main_ns / 26.0);
+        if (min_edges < 4096) min_edges = 4096;
+        cap_blocks = 128;
+    }
+    const uint64_t slabs = (d + 63) / 64;
+    uint64_t rows = 0;
+    while (rows < g->io_len_desc.size() && g->io_len_desc[rows] >= min_edges && (rows + 1) * slabs <= cap_blocks) ++rows;
+    return rows;
+}
+
 int hub_lanes(const cleora_graph *g, uint32_t d) {
     if (g->hub_lanes == 4 || g->hub_lanes == 2) return g->hub_lanes;
     const double main_ns = (double)g->nnz * (double)d * 4.0 / 6.4e3;          // bytes / (6.4e12 B/s) in ns
-    const double chain4_ns = (double)g->hub_longest * 52.0;
+    const uint64_t n_chain = hub_chain_rows(g, d);
+    const uint64_t longest = n_chain < g->io_len_desc.size() ? g->io_len_desc[n_chain] : 0;     // the longest row hub_inorder_kernel keeps
+    const double chain4_ns = (double)longest * 52.0;
     return chain4_ns <= 0.5 * main_ns ? 4 : 2;
 }
 
@@ -674,19 +831,30 @@ int propagate_panel(const cleora_graph *g, SpmmArgs a, bool w4, bool segmented, 
     mark(g, stream);
     if (hub_launch) {
         // the hub rows, longest first, on the side stream beside the main launch (src/embedding.rs:76-83's order)
-        const int rc = ensure_hub_stream(g);
+        int rc = ensure_hub_stream(g);
         if (rc != CLEORA_OK) return rc;
         CL_HIP(hipEventRecord(g->hub_fork, stream));
         CL_HIP(hipStreamWaitEvent(g->hub_stream, g->hub_fork, 0));
         a.hub_by_len = g->hub_by_len;
         a.hub_rows = g->io_rows;
         a.nnz = g->nnz;
+        // the few longest rows: one 8-wave block per (row, 64-column slab) — products by producer waves, the chain by a wave that only adds
+        const uint64_t n_chain = w4 ? hub_chain_rows(g, d) : 0;
+        if (n_chain) {
+            a.n_slabs = (d + 63) / 64;
+            a.hub_first = 0;
+            hipLaunchKernelGGL((hub_chain_kernel<8>), grid_1d_as_2d(n_chain * (uint64_t)a.n_slabs), dim3(512), 0, g->hub_stream, a);
+        }
+        a.hub_first = (uint32_t)n_chain;
         const int lanes = w4 ? hub_lanes(g, d) : 0;
         a.n_slabs = lanes ? (d + 16 * lanes - 1) / (16 * lanes) : (d + 63) / 64;
-        const dim3 grid = grid_1d_as_2d(g->n_io_rows * (uint64_t)a.n_slabs);
-        if (lanes == 4) hipLaunchKernelGGL((hub_inorder_kernel<48, 4>), grid, dim3(64), 0, g->hub_stream, a);
-        else if (lanes == 2) hipLaunchKernelGGL((hub_inorder_kernel<48, 2>), grid, dim3(64), 0, g->hub_stream, a);
-        else hipLaunchKernelGGL((hub_inorder_kernel<64, 0>), grid, dim3(64), 0, g->hub_stream, a);
+        if (g->n_io_rows > n_chain) {
+            const dim3 grid = grid_1d_as_2d((g->n_io_rows - n_chain) * (uint64_t)a.n_slabs);
+            if (lanes == 4) hipLaunchKernelGGL((hub_inorder_kernel<48, 4>), grid, dim3(64), 0, g->hub_stream, a);
+            else if (lanes == 2) hipLaunchKernelGGL((hub_inorder_kernel<48, 2>), grid, dim3(64), 0, g->hub_stream, a);
+            else hipLaunchKernelGGL((hub_inorder_kernel<64, 0>), grid, dim3(64), 0, g->hub_stream, a);
+        }
+        a.hub_first = 0;
         ok = dispatch_shape(d, w4, [&](auto G, auto V, auto W, auto) {
             constexpr int kG = decltype(G)::value;
             hipLaunchKernelGGL((hub_epilogue_kernel<kG, decltype(V)::value, decltype(W)::value>),

@@ -157,6 +157,12 @@ int cleora_graph_set_hub_inorder_min(cleora_graph *g, uint64_t min_edges);
  * longest row at twice the vector instructions); 0 = automatic (default): 4 while the estimated chain of the graph's longest row
  * stays under half the main kernel's estimated time, else 2.  Results are bit-identical for either choice. */
 int cleora_graph_set_hub_lanes(cleora_graph *g, int lanes);
+/* Which rows of the in-order hub launch take the chain kernel (hub_chain_kernel, csrc/spmm.hip: one 8-wave block per (row, 64-column
+ * slab) — seven waves gather and multiply, one wave only adds, in the reference's order, src/embedding.rs:76-83; ~5 x faster per
+ * edge than one wavefront doing everything): the rows with AT LEAST min_edges edges.  0 = automatic (the rows whose chain would
+ * outlast a quarter of the main kernel's estimated time, at most 128 blocks), 1 = every row of the hub launch, UINT64_MAX = none.
+ * Moves work between kernels, never a bit of the result. */
+int cleora_graph_set_hub_chain_min(cleora_graph *g, uint64_t min_edges);
 int cleora_graph_set_timing(cleora_graph *g, int enable);
 int cleora_graph_get_timing(cleora_graph *g, double ms[3], uint64_t *calls);
 

@@ -104,9 +104,12 @@ if do_blocks:
     res = {"rank": rank, "mode": mode, "blocks": [{"rows": r1 - r0, "nnz": e, "longest_row": int(deg[r0:r1].max()), "n_inorder_rows": int(gr.info().n_inorder_rows)} for gr, r0, r1, e in graphs],
            "ms_per_iteration_of_the_ranks_four_blocks": {}}
     for rep in range(2):
-        for name, lanes, flags in (("inorder_auto", 0, 0), ("inorder_lanes4", 4, 0), ("inorder_lanes2", 2, 0), ("segments", 0, _hip.F_HUB_SEGMENTS)):
+        NEVER = 2 ** 64 - 1
+        for name, lanes, flags, chain in (("default", 0, 0, 0), ("chain_all_hub_rows", 0, 0, 1), ("chain_8k", 0, 0, 8192), ("no_chain_lanes4", 4, 0, NEVER),
+                                          ("no_chain_lanes2", 2, 0, NEVER), ("segments", 0, _hip.F_HUB_SEGMENTS, NEVER)):
             for gr, *_ in graphs:
                 gr.set_hub_lanes(lanes)
+                gr.set_hub_chain_min(chain)
             res["ms_per_iteration_of_the_ranks_four_blocks"].setdefault(name, []).append(round(run(flags), 3))
     res["whole_graph_spmm_over_8_ms"] = round(nnz * d * 4 / 6.4e12 * 1e3 / P, 3)
     out["rank_blocks_alone_on_the_gpu"] = res

@@ -138,6 +138,37 @@ def test_hub_rows_in_reference_order(d):
         np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
 
 
+@pytest.mark.parametrize("d", [256, 64, 1024, 100, 1280])
+def test_longest_rows_on_the_chain_kernel_keep_the_bits(d):
+    """hub_chain_kernel (csrc/spmm.hip: seven producer waves gather and multiply, one consumer wave adds the products in stored
+    order) for the longest rows of the hub launch: the same bits as the oracle whichever rows take it — every row of the hub launch
+    (chain_min = 1: rows shorter than one 112-edge chunk, chunk tails of every length, rows of many trips), a mix with
+    hub_inorder_kernel (both shapes), none — with the fused epilogue, and on a width with a partial last slab / unaligned rows
+    (d = 100 keeps the 16-byte form, d % 4 == 0; the scalar path never takes the chain kernel)."""
+    n = 3000
+    hubs = [(17, 5000), (1234, 1025), (2999, 20011), (5, 1026), (6, 1137), (7, 1138), (8, 1120), (9, 1121), (10, 1119), (11, 1343), (12, 1344),
+            (13, 896 * 3), (14, 896 * 3 + 1), (15, 896 * 3 - 1), (16, 1232)]
+    rowptr, col, vl, _ = random_csr(n, 8, seed=21, hubs=hubs)
+    x = np.random.default_rng(22).standard_normal((n, d)).astype(np.float32)
+    g = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=1024)
+    assert g.info().n_inorder_rows == len(hubs)
+    want = oracle.spmm(rowptr, col, vl, x)
+    for chain_min in (1, 1300, 5000, 2 ** 64 - 1, 0):
+        g.set_hub_chain_min(chain_min)
+        for lanes in (4, 2):
+            g.set_hub_lanes(lanes)
+            np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x), want, err_msg=f"chain_min {chain_min}, lanes {lanes}")
+    g.set_hub_chain_min(1)
+    np.testing.assert_array_equal(run_dev(g, _hip.LEFT, x, flags=_hip.F_L2NORM), oracle.l2_normalize(want))
+    # every row of more than 4 edges on the hub launch and on the chain kernel: 8-edge rows, one-chunk rows
+    g2 = _hip.Graph.from_host(rowptr, col, vl, hub_threshold=4, hub_segment=16)
+    g2.set_hub_inorder_min(0)
+    g2.set_hub_chain_min(1)
+    np.testing.assert_array_equal(run_dev(g2, _hip.LEFT, x), want)
+    g.close()
+    g2.close()
+
+
 def test_hub_rows_signed_zero_and_specials():
     """The last step of a hub row adds only its real edges (the padding lanes hold the NEXT row's edges), and NaN / inf /
     denormal / signed-zero terms travel through the DPP chain like through the reference's scalar loop."""
@@ -164,6 +195,12 @@ def test_hub_rows_signed_zero_and_specials():
     g.set_hub_lanes(4)
     got = run_dev(g, _hip.LEFT, x)
     np.testing.assert_array_equal(got.view(np.uint32), got2.view(np.uint32))
+    g.set_hub_chain_min(1)                       # ... and through the chain kernel's producer / consumer waves
+    got3 = run_dev(g, _hip.LEFT, x)
+    g.set_hub_chain_min(0)
+    nan = np.isnan(got)
+    np.testing.assert_array_equal(got.view(np.uint32)[~nan], got3.view(np.uint32)[~nan])
+    np.testing.assert_array_equal(nan, np.isnan(got3))
     np.testing.assert_array_equal(got.view(np.uint32)[:, :3], want.view(np.uint32)[:, :3])     # bit patterns: signs of zero, denormals, inf
     np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     np.testing.assert_array_equal(got[~np.isnan(want)], want[~np.isnan(want)])

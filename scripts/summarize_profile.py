@@ -120,7 +120,7 @@ _h = hashlib.sha256()
 for rel in ("cleora_amd/csrc/spmm.hip", "cleora_amd/csrc/row_epilogue.h", "cleora_amd/csrc/hot.hip", "cleora_amd/csrc/common.h"):   # = bench.py KERNEL_SOURCES
     _h.update(open(os.path.join(os.path.dirname(dst), rel), "rb").read())
 # one SpMM = the main launch + the in-order hub launch beside it + the hub rows' epilogue (spmm.hip): their bytes together
-hub = {k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items() if k.startswith("hub_inorder_kernel") or k.startswith("hub_epilogue_kernel")}
+hub = {k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items() if k.startswith("hub_inorder_kernel") or k.startswith("hub_epilogue_kernel") or k.startswith("hub_chain_kernel")}
 json.dump({"n": n, "nnz": nnz, "d": d, "kernel": dom, "source": f"{tag}_pmc.json",
            "kernel_source_sha16": _h.hexdigest()[:16],
            "main_kernel_bytes_per_launch": out["kernels"][dom]["hbm_bytes_per_launch"], "hub_kernels_bytes_per_launch": hub,
@@ -135,7 +135,7 @@ if os.path.exists(wp):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(wp)):
         if "cleora" in r["Kernel_Name"] and any(k in r["Kernel_Name"] for k in ("gram_kernel", "gram32_kernel", "gram16_kernel", "project_kernel",
-                                                                                "project_rows_kernel", "project_split_kernel")):
+                                                                                "project_rows_kernel", "project_split_kernel", "project_f16_kernel")):
             acc[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     wout = {"formula": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)  [8 XCDs, 1024 SIMDs]", "kernels": []}
     for (name, grid), c in sorted(acc.items()):

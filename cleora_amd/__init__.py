@@ -9,20 +9,25 @@
 __version__ = "0.1.0"
 
 
-def install(devices=None):
+def install(devices=None, hub_segments=None):
     """Make this package's SparseMatrix the reference's compiled module: after this call
     `import pycleora` (the reference's unmodified Python package) binds
     `from .pycleora import SparseMatrix` (pycleora/__init__.py:4) to cleora_amd.pycleora.
 
     devices: HIP device indices, e.g. range(8) — the graph is then row-partitioned over them INSIDE this process for
     embed_fast*, left / symmetric_markov_propagate and (after accelerate()) pycleora.embed(); None keeps what
-    CLEORA_DEVICES / CLEORA_DEVICE say (default: device 0)."""
+    CLEORA_DEVICES / CLEORA_DEVICE say (default: device 0).
+    hub_segments: True = the loops sum rows of more than 256 edges in segments (CLEORA_F_HUB_SEGMENTS: not the reference's bits,
+    within 2e-6 of the sum of |terms|) — the way out for a graph whose longest row is an in-order chain of 10^7 additions; None keeps
+    what CLEORA_HUB_SEGMENTS says (default: the reference's order)."""
     import importlib.util
     import sys
 
     from . import pycleora as _mod
     if devices is not None:
         _mod.set_devices(devices)
+    if hub_segments is not None:
+        _mod.set_hub_segments(hub_segments)
     sys.modules["pycleora.pycleora"] = _mod
     # pickles name the class by module path; use the reference's (src/sparse_matrix.rs:56) when its
     # Python package is importable so pickles interchange with real pycleora, else keep ours

@@ -59,6 +59,8 @@ SIGNATURES = {
     "cleora_comm_register": (c_int, [vp, vp, c_u64]),
     "cleora_comm_unregister": (c_int, [vp, vp]),
     "cleora_comm_check": (c_int, [vp]),
+    "cleora_comm_selftest": (c_int, [vp, c_u32]),
+    "cleora_comm_peer_mode": (c_int, [vp, ctypes.POINTER(c_int)]),
     "cleora_sharded_plan": (c_int, [c_u64, vp, c_u32, c_u32, c_int, vp, ctypes.POINTER(c_u64), ctypes.POINTER(c_int)]),
     "cleora_sharded_create": (c_int, [vp, c_int, c_u64, c_u64, vp, vp, vp, vp, c_int, c_u32, c_int, ctypes.POINTER(vp)]),
     "cleora_sharded_destroy": (c_int, [vp]),
@@ -69,6 +71,7 @@ SIGNATURES = {
     "cleora_sharded_set_timing": (c_int, [vp, c_int]),
     "cleora_sharded_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 2), ctypes.POINTER(c_u64)]),
     "cleora_embed_sharded_bytes": (c_u64, [c_u64, c_u64, c_u64, c_u32, c_u32, c_u32]),
+    "cleora_sharded_debug_fail_first_gather": (c_int, [vp, c_int]),
     "cleora_embed_sharded": (c_int, [vp, vp, c_int, c_u32, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),
     "cleora_abi_version": (c_int, []),
     "cleora_last_error": (ctypes.c_char_p, []),

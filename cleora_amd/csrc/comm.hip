@@ -242,6 +242,20 @@ int cleora_comm_unregister(cleora_comm *c, void *buf_dev) {
     return peer_unregister(c, buf_dev);
 }
 
+int cleora_comm_selftest(cleora_comm *c, uint32_t flags) {
+    CL_REQUIRE(c != nullptr, "comm is NULL");
+    CL_REQUIRE((flags & ~3u) == 0, "unknown self-test flags");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->peer) return CLEORA_OK;                       // RCCL's own collectives: nothing of ours to test
+    return peer_selftest(c, flags);
+}
+
+int cleora_comm_peer_mode(const cleora_comm *c, int *mode) {
+    CL_REQUIRE(c != nullptr && mode != nullptr, "comm / mode is NULL");
+    *mode = peer_mode(c);
+    return CLEORA_OK;
+}
+
 int cleora_comm_check(cleora_comm *c) {
     CL_REQUIRE(c != nullptr, "comm is NULL");
     return peer_check(c);

@@ -28,6 +28,9 @@ int peer_unregister(cleora_comm *c, void *buf);
 int peer_allgatherv_f32(cleora_comm *c, float *buf, const uint64_t *offsets, hipStream_t stream);
 int peer_allreduce(cleora_comm *c, void *buf, uint64_t n, bool f64, hipStream_t stream);
 int peer_broadcast(cleora_comm *c, void *buf, uint64_t bytes, int root, hipStream_t stream);
+int peer_selftest(cleora_comm *c, uint32_t flags);                 // data-visibility self-test; may switch every rank to the PULL all-gather (collective, host-synchronous)
+int peer_mode(const cleora_comm *c);                               // 0 PUSH, 1 PULL, -1 no peer transport
+void peer_set_mode(cleora_comm *c, int mode);
 int peer_check(cleora_comm *c);                                    // CLEORA_E_RCCL if a wait ever timed out on this rank (reads the mailbox)
 int peer_host_barrier(cleora_comm *c);                             // the ranks' host threads meet (shared memory; bounded wait)
 void peer_abandon(cleora_comm *c);                                 // its host barriers stop waiting (teardown of a group that never became complete)

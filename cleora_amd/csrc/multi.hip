@@ -39,7 +39,7 @@ struct cleora_multi {
     // leave the others waiting inside one
     std::mutex gate_mu;
     std::condition_variable gate_cv;
-    uint32_t gate_count = 0, gate_gen = 0;
+    uint32_t gate_count = 0, gate_gen = 0, gate_absent = 0;      // gate_absent: ranks that left the running call before its gates
     bool gate_fail = false, gate_result = true;
 };
 
@@ -79,8 +79,8 @@ bool gate(cleora_multi *m, bool ok) {
     std::unique_lock<std::mutex> lock(m->gate_mu);
     if (!ok) m->gate_fail = true;
     const uint32_t gen = m->gate_gen;
-    if (++m->gate_count == m->world) {
-        m->gate_result = !m->gate_fail;
+    if (++m->gate_count + m->gate_absent >= m->world) {       // (ranks that left the call early count as arrived, with a failure)
+        m->gate_result = !m->gate_fail && m->gate_absent == 0;
         m->gate_count = 0;
         m->gate_fail = false;
         ++m->gate_gen;
@@ -101,6 +101,18 @@ int run_all(cleora_multi *m, const std::function<int(uint32_t)> &fn) {
             (void)hipGetLastError();
             rc[p] = CLEORA_E_NODEVICE;
             err[p] = "hipSetDevice failed";
+            // this rank will meet none of the call's gates: the others must not wait for it (they hung in
+            // gate_cv.wait holding the handle's mutex) — it counts as arrived-and-failed at every gate until the call ends
+            std::lock_guard<std::mutex> lock(m->gate_mu);
+            ++m->gate_absent;
+            m->gate_fail = true;
+            if (m->gate_count > 0 && m->gate_count + m->gate_absent >= m->world) {
+                m->gate_result = false;
+                m->gate_count = 0;
+                m->gate_fail = false;
+                ++m->gate_gen;
+                m->gate_cv.notify_all();
+            }
             return;
         }
         rc[p] = fn(p);
@@ -114,6 +126,7 @@ int run_all(cleora_multi *m, const std::function<int(uint32_t)> &fn) {
         for (uint32_t p = 0; p < P; ++p) threads.emplace_back(body, p);
         for (auto &t : threads) t.join();
     }
+    m->gate_absent = 0;
     for (uint32_t p = 0; p < P; ++p)
         if (rc[p] != CLEORA_OK) {
             set_error("device " + std::to_string(m->devices[p]) + " (shard " + std::to_string(p) + " of " + std::to_string(P) + "): " + err[p]);

@@ -45,6 +45,7 @@ constexpr int kMaxWorld = 64;
 constexpr int kChannels = 2;                  // 0: all-gather, 1: all-reduce / broadcast
 constexpr double kHostBarrierSeconds = 180.0; // a rank that never arrives is an error, not a hang
 constexpr uint64_t kWaitTicks = 60ull * 100000000ull;   // wait_kernel's budget: 60 s of the 100 MHz wall clock
+constexpr uint64_t kProbeFloats = 1024;                 // self-test: 4 KiB per rank — small enough to stay resident in L1 / L2, where a stale line would sit
 
 struct ShmRecord {                            // what a rank publishes for one exchange
     hipIpcMemHandle_t handle;
@@ -52,7 +53,8 @@ struct ShmRecord {                            // what a rank publishes for one e
     int32_t device, ok;                       // ok: 1 = handle + raw pointer, 2 = raw pointer only (the buffer cannot be exported), 0 = nothing
     uint64_t raw;                             // the buffer's address in the publishing PROCESS: ranks that are threads of one process
     int64_t pid;                              //   (csrc/multi.hip: one process, P devices) use it directly — hipIpc cannot open a handle at home
-    uint8_t pad[128 - sizeof(hipIpcMemHandle_t) - 40];
+    uint64_t nonce;                           // drawn once per process: two containers sharing /dev/shm may both be pid 1
+    uint8_t pad[128 - sizeof(hipIpcMemHandle_t) - 48];
 };
 static_assert(sizeof(ShmRecord) == 128, "record size");
 
@@ -103,6 +105,13 @@ struct PeerLayer {
     std::vector<Registration> regs;
     char *scratch = nullptr;                  // all-reduce / broadcast staging, two halves
     uint64_t scratch_half = 0;
+    // all-gather form: 0 = PUSH (plain stores into the peers' replicas, all links at once), 1 = PULL (every rank copies the peers'
+    // shards out of THEIR replicas with system-scope loads: slower, but it does not depend on this device's caches seeing stores that
+    // arrive from outside).  Decided by peer_selftest(), alike on every rank.
+    int mode = 0;
+    bool selftested = false;
+    float *probe = nullptr;                   // self-test buffer: world slots of kProbeFloats (registered)
+    uint32_t *probe_bad = nullptr;            // device counter of mismatching words
 };
 
 namespace {
@@ -112,6 +121,21 @@ uint64_t fnv1a(const unsigned char *p, size_t n) {
     for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
     return h;
 }
+
+// identifies THIS process among the ranks of a communicator: the pid alone is not enough across pid namespaces
+uint64_t process_nonce() {
+    static const uint64_t nonce = [] {
+        uint64_t v = 0;
+        if (FILE *f = std::fopen("/dev/urandom", "rb")) {
+            if (std::fread(&v, sizeof v, 1, f) != 1) v = 0;
+            std::fclose(f);
+        }
+        if (!v) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)getpid() << 32) ^ reinterpret_cast<uintptr_t>(&v);
+        return v | 1;
+    }();
+    return nonce;
+}
+bool same_process(const ShmRecord &r) { return r.pid == (int64_t)getpid() && r.nonce == process_nonce(); }
 
 int barrier_host(cleora_comm *c) {
     PeerLayer *pl = c->peer;
@@ -143,6 +167,7 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
         if (e == hipSuccess) e = hipIpcGetMemHandle(&mine.handle, base);
         mine.raw = (uint64_t)reinterpret_cast<uintptr_t>(ptr);
         mine.pid = (int64_t)getpid();
+        mine.nonce = process_nonce();
         mine.bytes = bytes;
         mine.device = c->device;
         if (e != hipSuccess) {
@@ -167,7 +192,7 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
             rc = CLEORA_E_INVALID;
             break;
         }
-        if (r.pid == (int64_t)getpid()) {
+        if (same_process(r)) {
             // a rank of this process (another host thread, maybe another device): its pointer is ours too — direct peer access
             if (r.device != c->device) {
                 const hipError_t e = hipDeviceEnablePeerAccess(r.device, 0);
@@ -208,7 +233,7 @@ int exchange_and_map(cleora_comm *c, void *ptr, uint64_t bytes, Registration *ou
     }
     if (rc == CLEORA_OK && !export_error.empty())
         for (int p = 0; p < c->world; ++p)
-            if (p != c->rank && pl->shm->rec[p].pid != (int64_t)getpid()) { set_error("peer transport: " + export_error); rc = CLEORA_E_HIP; break; }
+            if (p != c->rank && !same_process(pl->shm->rec[p])) { set_error("peer transport: " + export_error); rc = CLEORA_E_HIP; break; }
     if (rc != CLEORA_OK) pl->shm->failed.store(1, std::memory_order_release);
     b = barrier_host(c);                                    // nobody reuses the records before everybody has read them
     if (b != CLEORA_OK) return b;
@@ -301,6 +326,50 @@ __global__ __launch_bounds__(256) void reduce_kernel(PeerPtrs src, int world, ui
 __global__ __launch_bounds__(256) void fetch_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint64_t n_words) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256)
         dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// PULL form of the all-gather: blockIdx.y = peer slot; the peer's shard out of ITS replica (src.p[]) into the same offsets of this
+// rank's (dst.p[], already offset), with loads that do not stop at this device's non-coherent caches
+__global__ __launch_bounds__(256) void pull_kernel(PeerPtrs src, PeerPtrs dst, PeerPtrs count) {
+    const uint64_t n_floats = reinterpret_cast<uint64_t>(count.p[blockIdx.y]);
+    const float *in = static_cast<const float *>(src.p[blockIdx.y]);
+    float *out = static_cast<float *>(dst.p[blockIdx.y]);
+    const uint64_t stride = (uint64_t)gridDim.x * 256, t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 7u) == 0) {
+        const uint64_t n2 = n_floats >> 1;
+        const uint64_t *i2 = reinterpret_cast<const uint64_t *>(in);
+        uint64_t *o2 = reinterpret_cast<uint64_t *>(out);
+        for (uint64_t i = t0; i < n2; i += stride) o2[i] = __hip_atomic_load(i2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (uint64_t i = (n2 << 1) + t0; i < n_floats; i += stride)
+            out[i] = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t *>(in) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    } else {
+        for (uint64_t i = t0; i < n_floats; i += stride)
+            out[i] = __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const uint32_t *>(in) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+}
+
+// ---- self-test kernels (peer_selftest) ----
+__device__ __forceinline__ float probe_pattern(uint32_t round, uint32_t rank, uint32_t i) {
+    return __builtin_bit_cast(float, 0x3f800000u | ((round * 2654435761u + rank * 40503u + i * 7919u) & 0x007fffffu));    // in [1, 2): never NaN
+}
+// every CU reads the whole probe buffer with plain loads: whatever the caches hold of it afterwards is what a later plain load may see
+__global__ __launch_bounds__(256) void probe_warm_kernel(const float *buf, uint64_t n, float *sink) {
+    float s = 0.f;
+    for (uint64_t i = threadIdx.x; i < n; i += 256) s += buf[i];
+    if (s == -1.f) sink[0] = s;                // (never: keeps the loads)
+}
+__global__ __launch_bounds__(256) void probe_fill_kernel(float *slot, uint32_t round, uint32_t rank) {
+    for (uint32_t i = threadIdx.x; i < kProbeFloats; i += 256) slot[i] = probe_pattern(round, rank, i);
+}
+// plain loads again — the load path of the SpMM's gathers — against what every rank must have written; skew != 0 expects another pattern
+// (fault injection)
+__global__ __launch_bounds__(256) void probe_check_kernel(const float *buf, int world, uint32_t round, uint32_t skew, uint32_t *bad) {
+    const uint32_t p = blockIdx.x;
+    if ((int)p >= world) return;
+    uint32_t mism = 0;
+    for (uint32_t i = threadIdx.x; i < kProbeFloats; i += 256)
+        mism += __builtin_bit_cast(uint32_t, buf[(uint64_t)p * kProbeFloats + i]) != __builtin_bit_cast(uint32_t, probe_pattern(round + skew, p, i));
+    if (mism) atomicAdd(bad, mism);
 }
 
 int signal_and_wait(cleora_comm *c, int channel, uint64_t seq, hipStream_t stream) {
@@ -405,7 +474,7 @@ int peer_enable(cleora_comm *c) {
     // are all ranks threads of this process?  (the records of the exchange above are still in place: the next write to them
     // comes after the barrier below)
     bool same = true;
-    for (int p = 0; p < c->world; ++p) same = same && pl->shm->rec[p].pid == (int64_t)getpid();
+    for (int p = 0; p < c->world; ++p) same = same && same_process(pl->shm->rec[p]);
     if ((rc = barrier_host(c)) != CLEORA_OK) return fail(rc);
     if (same) {
         for (int ch = 0; ch < kChannels; ++ch)
@@ -423,6 +492,8 @@ int peer_enable(cleora_comm *c) {
         if (!all) { set_error("peer transport: creating the in-process signal events failed on a rank"); return fail(CLEORA_E_HIP); }
         pl->inproc = true;
     }
+    // the handshake: refuse (or downgrade) the transport NOW, in milliseconds, not at the first all-gather of a 10 GB iterate
+    if ((rc = peer_selftest(c, 0)) != CLEORA_OK) return fail(rc);
     return CLEORA_OK;
 }
 
@@ -435,6 +506,8 @@ void peer_destroy(cleora_comm *c) {
     close_registration(pl, pl->mailboxes, c->world);
     if (pl->shm && c->world > 1) (void)barrier_host(c);      // peers have closed their mappings of OUR memory before we free it
     if (pl->scratch) (void)hipFree(pl->scratch);
+    if (pl->probe) (void)hipFree(pl->probe);
+    if (pl->probe_bad) (void)hipFree(pl->probe_bad);
     if (pl->mailbox) (void)hipFree(pl->mailbox);
     for (int ch = 0; ch < kChannels; ++ch)
         for (int k = 0; k < 2; ++k)
@@ -499,6 +572,34 @@ int peer_allgatherv_f32(cleora_comm *c, float *buf, const uint64_t *offsets, hip
     CL_HIP(hipSetDevice(c->device));
     const uint64_t mine = offsets[me + 1] - offsets[me];
     const uint64_t seq = ++pl->seq[0];
+    if (pl->mode == 1) {
+        // PULL: "my shard is final" (it was written by kernels ahead of this call on `stream`: a kernel boundary), wait for every peer's
+        // word, then copy their shards out of their replicas.  A peer overwrites a shard only two iterations later, after an
+        // all-gather that every rank enters behind this copy (sharded.hip joins the gathers of an iteration before the next one starts).
+        const int rc = signal_and_wait(c, 0, seq, stream);
+        if (rc != CLEORA_OK) return rc;
+        PeerPtrs src{}, dst{}, cnt{};
+        uint64_t most = 0;
+        int slots = 0;
+        for (int k = 1; k < P; ++k) {
+            const int p = (me + k) % P;
+            const uint64_t np = offsets[p + 1] - offsets[p];
+            if (!np) continue;
+            const uint64_t byte_off = (uint64_t)(reinterpret_cast<char *>(buf + offsets[p]) - reg->local);
+            src.p[slots] = reg->peer[p] + byte_off;
+            dst.p[slots] = buf + offsets[p];
+            cnt.p[slots] = reinterpret_cast<void *>((uintptr_t)np);
+            most = np > most ? np : most;
+            ++slots;
+        }
+        if (slots) {
+            uint64_t bx = (most / 2 + 255) / 256;
+            bx = bx > 160 ? 160 : (bx ? bx : 1);
+            hipLaunchKernelGGL(pull_kernel, dim3((unsigned)bx, (unsigned)slots), dim3(256), 0, stream, src, dst, cnt);
+            CL_HIP(hipGetLastError());
+        }
+        return CLEORA_OK;
+    }
     if (mine) {
         const uint64_t byte_off = (uint64_t)(reinterpret_cast<char *>(buf + offsets[me]) - reg->local);
         PeerPtrs dst{};
@@ -557,6 +658,87 @@ int peer_broadcast(cleora_comm *c, void *buf, uint64_t bytes, int root, hipStrea
         CL_HIP(hipGetLastError());
     }
     return CLEORA_OK;
+}
+
+// Does data handed over by the all-gather arrive where the NEXT KERNEL'S PLAIN LOADS see it?  (The product loops trust exactly that:
+// the SpMM gathers from a replica the peers stored into.)  Three rounds on a 4 KiB-per-rank probe buffer: every CU first reads the
+// whole buffer (so stale copies sit in its caches), every rank then writes a fresh pattern into its slot, the all-gather under test
+// runs, and a checker kernel compares every word with plain loads.  A failing PUSH form (plain stores into the peers' memory) is
+// replaced by the PULL form (system-scope loads from the peers' memory) and tested again; if that fails too the transport is refused.
+// The verdict is taken together (one flag in the shared segment): every rank ends in the same mode.  Collective, host-synchronous.
+// flags: 1 = the PUSH checker expects a pattern nobody wrote (exercises the fallback), 2 = the PULL checker as well (the refusal).
+int peer_selftest(cleora_comm *c, uint32_t flags) {
+    CL_REQUIRE(c->peer != nullptr, "the peer transport is not enabled on this communicator");
+    PeerLayer *pl = c->peer;
+    if (c->world == 1) { pl->selftested = true; return CLEORA_OK; }
+    CL_HIP(hipSetDevice(c->device));
+    int rc;
+    if (!pl->probe) {
+        void *q = nullptr;
+        CL_HIP(hipMalloc(&q, (uint64_t)c->world * kProbeFloats * sizeof(float)));
+        pl->probe = static_cast<float *>(q);
+        CL_HIP(hipMemset(q, 0, (uint64_t)c->world * kProbeFloats * sizeof(float)));
+        CL_HIP(hipMalloc(reinterpret_cast<void **>(&pl->probe_bad), sizeof(uint32_t)));
+        if ((rc = peer_register(c, pl->probe, (uint64_t)c->world * kProbeFloats * sizeof(float))) != CLEORA_OK) return rc;
+    }
+    std::vector<uint64_t> offsets((size_t)c->world + 1);
+    for (int p = 0; p <= c->world; ++p) offsets[p] = (uint64_t)p * kProbeFloats;
+    const int saved = pl->mode;
+    // its own stream: the ranks may be threads of one process on one device (csrc/multi.hip), whose null stream they would share
+    struct TestStream {
+        hipStream_t s = nullptr;
+        ~TestStream() { if (s) (void)hipStreamDestroy(s); }
+    } ts;
+    CL_HIP(hipStreamCreateWithFlags(&ts.s, hipStreamNonBlocking));
+    hipStream_t st = ts.s;
+    auto run_mode = [&](int mode, uint32_t skew, bool *ok) -> int {
+        pl->mode = mode;
+        uint32_t bad_total = 0;
+        for (uint32_t round = 1; round <= 3; ++round) {
+            CL_HIP(hipMemsetAsync(pl->probe_bad, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(probe_warm_kernel, dim3(512), dim3(256), 0, st, pl->probe, (uint64_t)c->world * kProbeFloats, pl->probe);
+            CL_HIP(hipStreamSynchronize(st));
+            int b = barrier_host(c);                                  // everybody's caches are warm with the old content: peers may write now
+            if (b != CLEORA_OK) return b;
+            hipLaunchKernelGGL(probe_fill_kernel, dim3(1), dim3(256), 0, st, pl->probe + (uint64_t)c->rank * kProbeFloats, round, (uint32_t)c->rank);
+            if ((b = peer_allgatherv_f32(c, pl->probe, offsets.data(), st)) != CLEORA_OK) return b;
+            hipLaunchKernelGGL(probe_check_kernel, dim3((unsigned)c->world), dim3(256), 0, st, pl->probe, c->world, round, skew, pl->probe_bad);
+            uint32_t bad = 0;
+            CL_HIP(hipMemcpyAsync(&bad, pl->probe_bad, sizeof bad, hipMemcpyDeviceToHost, st));
+            CL_HIP(hipStreamSynchronize(st));
+            bad_total += bad;
+            if ((b = peer_check(c)) != CLEORA_OK) return b;
+            if ((b = barrier_host(c)) != CLEORA_OK) return b;        // nobody refills a slot a peer is still checking
+        }
+        // one verdict for all ranks
+        if (bad_total) pl->shm->failed.store(1, std::memory_order_release);
+        int b = barrier_host(c);
+        if (b != CLEORA_OK) return b;
+        *ok = pl->shm->failed.load(std::memory_order_acquire) == 0;
+        if ((b = barrier_host(c)) != CLEORA_OK) return b;
+        if (c->rank == 0) pl->shm->failed.store(0, std::memory_order_release);
+        return barrier_host(c);
+    };
+    bool ok = false;
+    if ((rc = run_mode(0, (flags & 1u) ? 1u : 0u, &ok)) != CLEORA_OK) { pl->mode = saved; return rc; }
+    if (!ok) {
+        if ((rc = run_mode(1, (flags & 2u) ? 1u : 0u, &ok)) != CLEORA_OK) { pl->mode = saved; return rc; }
+        if (!ok) {
+            pl->mode = saved;
+            set_error("peer transport: data stored into a peer's buffer (and data loaded from it) did not arrive where the next kernel's loads see it: "
+                      "the mappings are not coherent enough for the peer-direct all-gather on this node; use the RCCL all-gather (cleora_comm_set_allgather)");
+            return CLEORA_E_RCCL;
+        }
+    }
+    pl->selftested = true;
+    return CLEORA_OK;
+}
+
+int peer_mode(const cleora_comm *c) { return c->peer ? c->peer->mode : -1; }
+
+// the all-gather form, decided together by the callers (sharded.hip's first-use check switches every rank to PULL at once)
+void peer_set_mode(cleora_comm *c, int mode) {
+    if (c->peer) c->peer->mode = mode ? 1 : 0;
 }
 
 int peer_check(cleora_comm *c) {

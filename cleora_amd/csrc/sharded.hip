@@ -48,6 +48,8 @@ struct cleora_sharded {
     hipStream_t loop_stream = nullptr;           // what cleora_embed_sharded runs on (cleora_sharded_set_stream; default: the device's null stream)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_side = nullptr;
     std::vector<uint64_t> offsets;               // scratch for the all-gather-v call
+    int debug_fail_first_gather = 0;             // tests: how many attempts of verify_peer_gather report a mismatch
+    bool peer_verified = false;                  // the first-use check of the peer-direct all-gather on a real replica has passed (verify_peer_gather)
     bool pending = false;                        // collectives on comm_stream the compute stream has not joined yet
     // timing (cleora_sharded_set_timing): event pairs around every all-gather on the communication stream
     bool timing = false;
@@ -552,6 +554,78 @@ int cleora_sharded_propagate_dev(cleora_sharded *s, int markov_type, const float
     return propagate_blocks(s, markov_type, x, x_next, nullptr, d, flags, residual_weight, row_sqdiff_local, gather != 0, S(stream));
 }
 
+namespace {
+__device__ __forceinline__ float verify_pattern(uint64_t i) {
+    return __builtin_bit_cast(float, 0x3f800000u | (uint32_t)((i * 2654435761ull + (i >> 21)) & 0x007fffffu));     // in [1, 2)
+}
+__global__ __launch_bounds__(256) void verify_fill_kernel(float *buf, uint64_t first, uint64_t count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) buf[first + i] = verify_pattern(first + i);
+}
+// plain loads (the SpMM's load path) of the WHOLE replica against the pattern; *bad (f64: it travels through the all-reduce) += mismatches
+__global__ __launch_bounds__(256) void verify_check_kernel(const float *buf, uint64_t count, double *bad) {
+    uint32_t mism = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256)
+        mism += __builtin_bit_cast(uint32_t, buf[i]) != __builtin_bit_cast(uint32_t, verify_pattern(i));
+    if (mism) atomicAdd(bad, (double)mism);
+}
+}  // namespace
+
+// First use of the peer-direct all-gather by this handle: the same exchange the loops make — every step's row range, this rank's
+// blocks, the communicator's all-gather on the communication stream — on one of the REAL registered replicas (`scratch_replica`: the
+// loop's second buffer, not yet in use), with a pattern every rank can check everywhere with plain loads.  cleora_comm_enable_peer's
+// self-test vouches for a 4 KiB probe buffer; this vouches for the 10-100 GB allocation the SpMM will gather from.  The ranks decide
+// together (all-reduced mismatch count): a failing PUSH form is replaced by PULL on every rank and checked again; if that fails too the
+// call returns an error instead of results assembled from stale rows.  `flags` of cleora_comm_selftest can be injected through
+// cleora_sharded_debug_fail_first_gather (tests).  Leaves the replica zero-filled, as it found it.
+int verify_peer_gather(cleora_sharded *s, float *scratch_replica, uint32_t d, hipStream_t stream) {
+    if (s->peer_verified || !s->comm || s->world == 1 || peer_mode(s->comm) < 0) return CLEORA_OK;
+    if (!(s->comm->allgather_algo == CLEORA_ALLGATHER_PEER || !s->comm->comm)) return CLEORA_OK;
+    const uint64_t total = s->n_pad * (uint64_t)d;
+    DevMem bad;
+    int rc;
+    if ((rc = bad.alloc(8)) != CLEORA_OK) return rc;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        CL_HIP(hipMemsetAsync(bad.p, 0, 8, stream));
+        for (uint32_t k = 0; k < s->steps; ++k) {
+            const auto &b = s->blocks[k];
+            const uint64_t first = b.b0 * (uint64_t)d, count = (b.b1 - b.b0) * (uint64_t)d;
+            if (count) hipLaunchKernelGGL(verify_fill_kernel, dim3(1024), dim3(256), 0, stream, scratch_replica, first, count);
+            if ((rc = gather_step(s, scratch_replica, d, k, stream)) != CLEORA_OK) return rc;
+        }
+        if ((rc = join(s, stream)) != CLEORA_OK) return rc;
+        hipLaunchKernelGGL(verify_check_kernel, dim3(4096), dim3(256), 0, stream, scratch_replica, total, bad.as<double>());
+        CL_HIP(hipGetLastError());
+        if (s->debug_fail_first_gather > attempt) hipLaunchKernelGGL(verify_check_kernel, dim3(1), dim3(256), 0, stream, scratch_replica + 1, 256, bad.as<double>());   // (injected: an off-by-one view never matches)
+        if ((rc = allreduce_f64(s, bad.as<double>(), 1, stream)) != CLEORA_OK) return rc;
+        double mism = 0.0;
+        CL_HIP(hipMemcpyAsync(&mism, bad.p, 8, hipMemcpyDeviceToHost, stream));
+        CL_HIP(hipStreamSynchronize(stream));
+        if ((rc = cleora_comm_check(s->comm)) != CLEORA_OK) return rc;
+        if (mism == 0.0) {
+            CL_HIP(hipMemsetAsync(scratch_replica, 0, total * sizeof(float), stream));
+            CL_HIP(hipStreamSynchronize(stream));
+            if ((rc = peer_host_barrier(s->comm)) != CLEORA_OK) return rc;        // nobody stores into a replica a slower rank is still clearing
+            s->peer_verified = true;
+            return CLEORA_OK;
+        }
+        if (peer_mode(s->comm) == 1 || attempt == 1) break;
+        peer_set_mode(s->comm, 1);                                               // every rank saw the same (all-reduced) count: all switch
+        if ((rc = peer_host_barrier(s->comm)) != CLEORA_OK) return rc;
+    }
+    set_error("the peer-direct all-gather left stale rows in a replica (first-use check of cleora_embed_sharded, PUSH and PULL forms): "
+              "refusing to run the loop on this transport; take an RCCL communicator's all-gather (cleora_comm_set_allgather)");
+    return CLEORA_E_RCCL;
+}
+
+int cleora_sharded_debug_fail_first_gather(cleora_sharded *s, int attempts) {
+    CL_REQUIRE(s != nullptr, "handle is NULL");
+    CL_REQUIRE(attempts >= 0 && attempts <= 2, "attempts: 0 (off), 1 (the PUSH form's check fails), 2 (both fail)");
+    std::lock_guard<std::mutex> lock(s->mu);
+    s->debug_fail_first_gather = attempts;
+    s->peer_verified = false;
+    return CLEORA_OK;
+}
+
 uint64_t cleora_embed_sharded_bytes(uint64_t n_pad, uint64_t local_rows, uint64_t n, uint32_t world, uint32_t d, uint32_t flags) {
     const uint64_t replica = n_pad * (uint64_t)d * 4, local = local_rows * (uint64_t)d * 4;
     if (!(flags & CLEORA_F_WHITEN)) return replica;                 // the partner of the ping-pong pair
@@ -592,6 +666,7 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
         if ((rc = cleora_comm_register(s->comm, x_replica, replica_bytes)) != CLEORA_OK) return rc;
         if ((rc = cleora_comm_register(s->comm, other.p, replica_bytes)) != CLEORA_OK) { (void)cleora_comm_unregister(s->comm, x_replica); return rc; }
         reg.on = true;
+        if ((rc = verify_peer_gather(s, other.as<float>(), d, stream)) != CLEORA_OK) return rc;
     }
     float *result = nullptr;
     uint64_t ran = max_iterations;

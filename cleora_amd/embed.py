@@ -16,6 +16,7 @@ import ctypes
 import numpy as np
 
 from . import _hip
+from . import pycleora as _pyc
 from .pycleora import SparseMatrix
 
 DEFAULT_FEATURE_DIM = 256       # pycleora/__init__.py:12
@@ -146,7 +147,7 @@ def embed(graph, feature_dim=DEFAULT_FEATURE_DIM, num_iterations=DEFAULT_NUM_ITE
         # initialize_deterministically) — it does not travel to the host and back (10 GB each way at |V| = 10M, d = 256).
         out = np.empty((n, d), np.float32)
         ran = ctypes.c_uint64(0)
-        flags = _hip.F_WHITEN | (_hip.F_L1NORM if normalization == "l1" else 0)
+        flags = _hip.F_WHITEN | (_hip.F_L1NORM if normalization == "l1" else 0) | _pyc.loop_flags()
         hashes = graph._arr["hashes"] if x0 is None else None
         with graph._lock:
             m = graph._multi()

@@ -38,6 +38,23 @@ def set_devices(devices):
     _DEVICES = None if devices is None else [int(v) for v in devices]
 
 
+_HUB_SEGMENTS = None    # set by cleora_amd.install(hub_segments=...); None: CLEORA_HUB_SEGMENTS
+
+
+def set_hub_segments(on):
+    """The long-row sum of the loops later SparseMatrix / embed() calls run: False (default) = every row in the reference's
+    order, bit-equal (src/embedding.rs:76-83); True = CLEORA_F_HUB_SEGMENTS, the segmented sum (within 2e-6 of the sum of |terms|
+    per row, not the reference's bits) — for graphs with a pathological hub (10^7 edges in one row: an in-order chain of as many
+    dependent additions).  None: back to the environment."""
+    global _HUB_SEGMENTS
+    _HUB_SEGMENTS = None if on is None else bool(on)
+
+
+def loop_flags():
+    on = _HUB_SEGMENTS if _HUB_SEGMENTS is not None else os.environ.get("CLEORA_HUB_SEGMENTS", "").strip() not in ("", "0")
+    return _hip.F_HUB_SEGMENTS if on else 0
+
+
 def _devices():
     if _DEVICES is not None:
         return list(_DEVICES)
@@ -175,11 +192,11 @@ class SparseMatrix:
         with self._lock:
             m = self._multi()
             if m is not None:
-                return m.embed(self._arr["hashes"], None, _PROPAGATIONS[propagation], d, iterations, seed, residual_weight, threshold, 0)
+                return m.embed(self._arr["hashes"], None, _PROPAGATIONS[propagation], d, iterations, seed, residual_weight, threshold, loop_flags())
             g = self._graph()
             _hip.check(_hip.lib().cleora_embed(
                 g.handle, _hip.ptr(self._arr["hashes"]), None, _PROPAGATIONS[propagation], d,
-                int(iterations), int(seed), float(residual_weight), float(threshold), 0,
+                int(iterations), int(seed), float(residual_weight), float(threshold), loop_flags(),
                 _hip.ptr(out), ctypes.byref(ran)))
         return out, int(ran.value)
 

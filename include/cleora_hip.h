@@ -403,6 +403,18 @@ int cleora_comm_enable_peer(cleora_comm *c);
 int cleora_comm_register(cleora_comm *c, void *buf_dev, uint64_t bytes);
 int cleora_comm_unregister(cleora_comm *c, void *buf_dev);
 int cleora_comm_check(cleora_comm *c);
+/* The peer transport's data-visibility self-test (csrc/peer.hip peer_selftest; runs by itself inside cleora_comm_enable_peer /
+ * cleora_comm_create_local, in milliseconds): every CU reads a 4 KiB-per-rank probe buffer, every rank writes a fresh pattern into its
+ * slot, the all-gather under test runs, a checker kernel compares every word with PLAIN loads — the load path of the SpMM's gathers.
+ * If the PUSH form (plain stores into the peers' replicas) fails, every rank switches to the PULL form (system-scope loads out of the
+ * peers' replicas) and that is tested; if it fails too: CLEORA_E_RCCL, the transport must not be used (an RCCL communicator keeps its
+ * RCCL all-gathers: cleora_comm_set_allgather).  Collective, host-synchronous; all ranks end in the same form.
+ * flags (fault injection, for tests): CLEORA_SELFTEST_FAIL_PUSH / CLEORA_SELFTEST_FAIL_PULL make the respective checker expect a pattern
+ * nobody wrote.  cleora_comm_peer_mode: 0 PUSH, 1 PULL, -1 no peer transport. */
+#define CLEORA_SELFTEST_FAIL_PUSH 1u
+#define CLEORA_SELFTEST_FAIL_PULL 2u
+int cleora_comm_selftest(cleora_comm *c, uint32_t flags);
+int cleora_comm_peer_mode(const cleora_comm *c, int *mode);
 
 /* The exchange step of the row partition: buf holds offsets[world] floats (e.g. a row range of the next iterate,
  * contiguous, ld = d); rank r has just written elements [offsets[r], offsets[r+1]) and every rank ends up with all
@@ -475,6 +487,10 @@ int cleora_sharded_get_timing(cleora_sharded *s, double ms[2], uint64_t *calls);
  *     broadcast, one all-gather of the iterate per iteration.  Otherwise the reference's order, statistics in the reference's two passes.
  * Device memory beside the caller's replica: cleora_embed_sharded_bytes — one more replica for the plain loop; one more replica + the
  * rank's own rows + the whitening workspace for the whitened one (config 4 on 8 GPUs: 2 x 113.7 + 14.2 GB of iterates). */
+/* Test hook of cleora_embed_sharded's first-use check of the peer-direct all-gather (csrc/sharded.hip verify_peer_gather: on first
+ * use the loop's exchange runs once on a real replica with a pattern every rank verifies with plain loads; a failing PUSH form is
+ * replaced by PULL on all ranks, a failing PULL form is an error): the next `attempts` (0, 1, 2) checks report a mismatch. */
+int cleora_sharded_debug_fail_first_gather(cleora_sharded *s, int attempts);
 uint64_t cleora_embed_sharded_bytes(uint64_t n_pad, uint64_t local_rows, uint64_t n, uint32_t world, uint32_t d, uint32_t flags);
 int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, uint32_t d, uint64_t max_iterations,
                          float residual_weight, float convergence_threshold, uint32_t flags, uint64_t *iterations_run);

@@ -200,3 +200,109 @@ def test_ranks_sharing_the_gpu_over_the_local_communicator(world):
             assert np.abs(_cosines(res, rows) - _cosines(ref, rows)).max() < 1e-3
     assert got[0]["plain_nnz"][2] == "nnz" and got[0]["plain"][2] == "rows"
     assert sum(got[r]["plain_nnz"][3] for r in range(world)) >= 5003
+
+
+def _peer_mode(cm):
+    m = ctypes.c_int(-2)
+    _hip.check(_hip.lib().cleora_comm_peer_mode(cm.handle, ctypes.byref(m)))
+    return m.value
+
+
+def _handshake_worker(rank, world, ident, q):
+    """The peer transport's safety net on shared-GPU ranks: the self-test inside communicator creation, the
+    injected PUSH failure -> every rank on the PULL form -> the loops still bit-equal; the injected failure of both forms -> the same
+    error on every rank; cleora_embed_sharded's first-use check with one and two injected mismatches."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        L = _hip.lib()
+        out = {}
+        cm = comm_mod.RcclComm(ident[0], rank, world, 0, stream_fn=lambda: None, local=True)
+        out["mode_after_create"] = _peer_mode(cm)                      # creation ran the self-test: PUSH works between ranks of one GPU
+        n, d, seed = 5003, 64, 61
+        rowptr, col, vl, vs = _graph(n, seed)
+        x0 = np.random.default_rng(seed + 1).standard_normal((n, d)).astype(np.float32)
+        # (1) first-use check of the loop with ONE injected mismatch: PUSH is abandoned for PULL, the loop runs, results unchanged
+        sg = sharded.DeviceShardedGraph(n, rowptr, col, vl, vs, cm, 3, "nnz")
+        _hip.check(L.cleora_sharded_debug_fail_first_gather(sg.handle, 1))
+        res, ran = _run_sharded(sg, x0, d, 5, 0.0, 0.0, 0)
+        out["loop_after_one_injected_mismatch"] = (res, ran, _peer_mode(cm))
+        # (2) the PULL form in the whitened loop as well
+        res, ran = _run_sharded(sg, x0, d, 3, 0.0, 0.0, _hip.F_WHITEN)
+        out["whitened_on_pull"] = (res, ran)
+        # (3) TWO injected mismatches: both forms "fail" -> an error, on every rank, instead of results
+        _hip.check(L.cleora_sharded_debug_fail_first_gather(sg.handle, 2))
+        xp = _hip.DevArray.from_host(np.zeros((sg.n_pad, d), np.float32))
+        rc = L.cleora_embed_sharded(sg.handle, xp.ptr, _hip.LEFT, d, 2, 0.0, 0.0, 0, None)
+        out["two_injected_mismatches"] = (rc, _hip.last_error())
+        xp.free()
+        sg.close()
+        cm.close()
+        # (4) a fresh communicator: the stand-alone self-test with the PUSH checker failing -> PULL everywhere; collectives still right
+        cm = comm_mod.RcclComm(ident[1], rank, world, 0, stream_fn=lambda: None, local=True)
+        _hip.check(L.cleora_comm_selftest(cm.handle, 1))
+        out["mode_after_failed_push"] = _peer_mode(cm)
+        cuts = _shard_cuts(world)
+        rows, dd = int(cuts[-1]), 24
+        buf = np.full((rows, dd), -1.0, np.float32)
+        buf[cuts[rank]:cuts[rank + 1]] = np.arange(cuts[rank], cuts[rank + 1], dtype=np.float32)[:, None] * 10 + rank
+        db = _hip.DevArray.from_host(buf)
+        cm.register(db)
+        off = np.asarray([c * dd for c in cuts], dtype=np.uint64)
+        for _ in range(3):
+            _hip.check(L.cleora_allgatherv_f32_dev(cm.handle, db.ptr, _hip.ptr(off), None))
+        _hip.check(L.cleora_stream_sync(None))
+        out["gathered_on_pull"] = db.to_host()
+        cm.unregister(db)
+        # (5) both checkers failing: the transport is refused, with the same verdict everywhere
+        rc = L.cleora_comm_selftest(cm.handle, 3)
+        out["selftest_both_fail"] = (rc, _hip.last_error())
+        cm.close()
+        q.put((rank, out, None))
+    except BaseException as e:                       # noqa: BLE001 - reported to the parent
+        import traceback
+        q.put((rank, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_transport_selftest_and_the_pull_fallback(world):
+    ident = (comm_mod.RcclComm.unique_id(local=True), comm_mod.RcclComm.unique_id(local=True))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_handshake_worker, args=(r, world, ident, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = {}
+        for _ in range(world):
+            rank, out, err = q.get(timeout=600)
+            assert err is None, f"rank {rank}: {err}"
+            got[rank] = out
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    n, d, seed = 5003, 64, 61
+    rowptr, col, vl, vs = _graph(n, seed)
+    x0 = np.random.default_rng(seed + 1).standard_normal((n, d)).astype(np.float32)
+    want, wran = _one_gpu(rowptr, col, vl, x0, d, 5, 0.0, 0.0, 0)
+    wantw, _ = _one_gpu(rowptr, col, vl, x0, d, 3, 0.0, 0.0, _hip.F_WHITEN)
+    rows = np.random.default_rng(1).choice(n, 400, replace=False)
+    cuts = _shard_cuts(world)
+    owner = np.zeros(int(cuts[-1]), np.float32)
+    for k in range(world):
+        owner[cuts[k]:cuts[k + 1]] = k
+    for r in range(world):
+        o = got[r]
+        assert o["mode_after_create"] == 0                                   # PUSH passed the handshake
+        res, ran, mode = o["loop_after_one_injected_mismatch"]
+        assert mode == 1 and ran == wran                                     # every rank fell back to PULL ...
+        np.testing.assert_array_equal(res, want)                             # ... and the plain loop is still the one-GPU loop, bit for bit
+        resw, ranw = o["whitened_on_pull"]
+        assert ranw == 3 and np.abs(_cosines(resw, rows) - _cosines(wantw, rows)).max() < 1e-4
+        rc, msg = o["two_injected_mismatches"]
+        assert rc == _hip.E_RCCL and "stale rows" in msg
+        assert o["mode_after_failed_push"] == 1
+        np.testing.assert_array_equal(o["gathered_on_pull"], np.arange(int(cuts[-1]), dtype=np.float32)[:, None] * 10 + owner[:, None] + np.zeros((1, 24), np.float32))
+        rc, msg = o["selftest_both_fail"]
+        assert rc == _hip.E_RCCL and "not coherent" in msg

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcleora_hip.so")
 OK, E_INVALID, E_OOM, E_HIP, E_NODEVICE, E_RCCL = 0, -1, -2, -3, -4, -5
 LEFT, SYMMETRIC = 0, 1
 F_L2NORM, F_FASTNORM, F_RESIDUAL, F_SQDIFF, F_ROWSQ, F_SCALE, F_WHITEN = 1, 2, 4, 8, 16, 32, 64
-F_L1NORM, F_BLEND_ANY, F_SQDIFF64, F_HUB_SEGMENTS = 128, 256, 512, 1024
+F_L1NORM, F_BLEND_ANY, F_SQDIFF64, F_HUB_SEGMENTS, F_ROWSQ_CONT = 128, 256, 512, 1024, 2048
 ABI_VERSION = 5
 COMM_ID_BYTES = 128
 ALLGATHER_RING, ALLGATHER_P2P, ALLGATHER_PEER = 0, 1, 2
@@ -37,6 +37,11 @@ class ShardedInfo(ctypes.Structure):
     _fields_ = [("n", c_u64), ("n_pad", c_u64), ("local_rows", c_u64), ("local_nnz", c_u64), ("device_bytes", c_u64),
                 ("steps", c_u32), ("rank", ctypes.c_int32), ("world", ctypes.c_int32), ("balance", ctypes.c_int32),
                 ("has_symmetric", ctypes.c_int32)]
+
+
+class ColShardedInfo(ctypes.Structure):
+    _fields_ = [("n", c_u64), ("nnz", c_u64), ("d_total", c_u32), ("d_local", c_u32), ("col_begin", c_u32), ("steps", c_u32),
+                ("rank", ctypes.c_int32), ("world", ctypes.c_int32), ("has_symmetric", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class MultiInfo(ctypes.Structure):
@@ -72,6 +77,11 @@ SIGNATURES = {
     "cleora_sharded_get_timing": (c_int, [vp, ctypes.POINTER(ctypes.c_double * 2), ctypes.POINTER(c_u64)]),
     "cleora_embed_sharded_bytes": (c_u64, [c_u64, c_u64, c_u64, c_u32, c_u32, c_u32]),
     "cleora_sharded_debug_fail_first_gather": (c_int, [vp, c_int]),
+    "cleora_colsharded_create": (c_int, [vp, c_int, c_u64, c_u64, vp, vp, vp, vp, c_int, c_u32, c_u32, ctypes.POINTER(vp)]),
+    "cleora_colsharded_destroy": (c_int, [vp]),
+    "cleora_colsharded_get_info": (c_int, [vp, vp]),
+    "cleora_colsharded_propagate_dev": (c_int, [vp, c_int, vp, vp, c_u32, c_f32, vp, vp]),
+    "cleora_embed_colsharded": (c_int, [vp, vp, c_int, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),
     "cleora_embed_sharded": (c_int, [vp, vp, c_int, c_u32, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),
     "cleora_abi_version": (c_int, []),
     "cleora_last_error": (ctypes.c_char_p, []),

@@ -108,7 +108,9 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) s = fadd(s, __shfl_xor(s, o, 64));
         } else {
-            // the reference's order: sum_sq += v*v for j = 0..d-1   (src/embedding.rs:94-97)
+            // the reference's order: sum_sq += v*v for j = 0..d-1   (src/embedding.rs:94-97); ROWSQ_CONT: these d columns are a slice of
+            // a wider row and the sum continues where the columns to the left ended
+            if ((ra.flags & CLEORA_F_ROWSQ_CONT) && (ra.flags & CLEORA_F_ROWSQ)) s = ra.row_sumsq[row];
             const uint32_t nchunks = (d + W - 1) / W;
 #pragma unroll
             for (int v = 0; v < V; ++v) {

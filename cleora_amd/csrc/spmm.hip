@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void rowops_wide_kernel(const float *x, uint64
     float *yr = ra.y + row * ra.ldy;
     const uint32_t d = ra.d;
     const bool l1 = (ra.flags & CLEORA_F_L1NORM) != 0;
-    float s = 0.f;
+    float s = ((ra.flags & CLEORA_F_ROWSQ_CONT) && (ra.flags & CLEORA_F_ROWSQ)) ? ra.row_sumsq[row] : 0.f;
     for (uint32_t j0 = 0; j0 < d; j0 += 64) {
         const uint32_t j = j0 + lane;
         float v = j < d ? xr[j] : 0.f;
@@ -714,6 +714,8 @@ int check_norm_flags(uint32_t flags) {
     CL_REQUIRE(!((flags & CLEORA_F_ROWSQ) && (flags & CLEORA_F_SCALE)), "ROWSQ and SCALE are exclusive");
     CL_REQUIRE(!((flags & CLEORA_F_L1NORM) && (flags & (CLEORA_F_L2NORM | CLEORA_F_ROWSQ | CLEORA_F_SCALE))),
                "L1NORM is exclusive with L2NORM / ROWSQ / SCALE");
+    CL_REQUIRE(!(flags & CLEORA_F_ROWSQ_CONT) || ((flags & CLEORA_F_ROWSQ) && !(flags & (CLEORA_F_FASTNORM | CLEORA_F_L2NORM))),
+               "ROWSQ_CONT continues an exact-order ROWSQ (no L2NORM / FASTNORM in the same call)");
     return CLEORA_OK;
 }
 

@@ -150,6 +150,59 @@ def plan_rows(n, rowptr, world, steps, balance="auto"):
     return [int(v) for v in b], n_pad.value, {_hip.BALANCE_ROWS: "rows", _hip.BALANCE_NNZ: "nnz"}[got.value]
 
 
+class DeviceColShardedGraph:
+    """This rank's COLUMN slice of the propagation through the C ABI (csrc/colsharded.hip): the rank owns columns
+    [rank d/P, (rank + 1) d/P) of the iterate and the whole CSR; the row L2 norm travels from rank to rank as a running sum
+    (CLEORA_F_ROWSQ_CONT), so propagate and the plain loop are bit-equal to the one-GPU calls.  rowptr / col / val_*: the WHOLE graph
+    as numpy host arrays (copied) or as device arrays (torch tensors / _hip.DevArray: col / val_* are VIEWED and must outlive the handle)."""
+
+    def __init__(self, n, rowptr, col, val_left, val_sym, d_total, comm=None, steps=1, device=0):
+        L = self.L = _hip.lib()
+        self.comm = comm
+        on_device = not isinstance(rowptr, np.ndarray)
+        if on_device:
+            self._keep = (rowptr, col, val_left, val_sym)
+            args = [_dev_ptr(rowptr), _dev_ptr(col), _dev_ptr(val_left), _dev_ptr(val_sym)]
+            nnz = int(col.numel() if hasattr(col, "numel") else col.shape[0])
+        else:
+            rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val_left = np.ascontiguousarray(val_left, dtype=np.float32)
+            val_sym = None if val_sym is None else np.ascontiguousarray(val_sym, dtype=np.float32)
+            args = [_hip.ptr(rowptr), _hip.ptr(col), _hip.ptr(val_left), _hip.ptr(val_sym)]
+            nnz = int(col.shape[0])
+        h = _hip.vp()
+        _hip.check(L.cleora_colsharded_create(comm.handle if comm is not None else None, int(device), int(n), nnz, *args,
+                                              1 if on_device else 0, int(d_total), int(steps), ctypes.byref(h)))
+        self.handle = h
+        info = _hip.ColShardedInfo()
+        _hip.check(L.cleora_colsharded_get_info(h, ctypes.byref(info)))
+        self.n, self.nnz, self.d, self.dl, self.c0 = info.n, info.nnz, info.d_total, info.d_local, info.col_begin
+        self.steps, self.rank, self.world = info.steps, info.rank, info.world
+
+    def propagate(self, kind, x_local, x_next_local, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, stream=None):
+        """One iteration on the (n, d/P) slices (torch tensors or DevArrays, contiguous)."""
+        _hip.check(self.L.cleora_colsharded_propagate_dev(self.handle, int(kind), _dev_ptr(x_local), _dev_ptr(x_next_local), int(flags), float(rw),
+                                                          _dev_ptr(row_sqdiff), stream))
+
+    def embed(self, x_local, kind, iterations, residual_weight=0.0, convergence_threshold=0.0, flags=0):
+        ran = _hip.c_u64(0)
+        _hip.check(self.L.cleora_embed_colsharded(self.handle, _dev_ptr(x_local), int(kind), int(iterations), float(residual_weight),
+                                                  float(convergence_threshold), int(flags), ctypes.byref(ran)))
+        return ran.value
+
+    def close(self):
+        if self.handle:
+            self.L.cleora_colsharded_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:            # noqa: BLE001
+            pass
+
+
 class HipBackend:
     """Per-block SpMM through the C ABI on the current torch stream."""
 
@@ -292,8 +345,10 @@ class ColumnShardedGraph:
         self.rows_per = -(-n // world)
         self.n_pad = self.rows_per * world
 
-    def propagate(self, kind, x, x_next, rowsq, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None):
-        """x, x_next: (n, d/P) column slices; rowsq: f32[n] scratch.  One iteration."""
+    def propagate(self, kind, x, x_next, rowsq, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, exact_norm=False):
+        """x, x_next: (n, d/P) column slices; rowsq: f32[n] scratch.  One iteration.
+        exact_norm: the rows' sums of squares travel from rank to rank as running sums (CLEORA_F_ROWSQ_CONT; one broadcast per rank and
+        row block) instead of being all-reduced: the reference's summation order, bit-equal to one GPU — what csrc/colsharded.hip runs."""
         if (flags & _hip.F_L1NORM) and self.world > 1:
             # each rank would divide its slice by its PARTIAL sum of |.|: wrong.  (The L2 norm has the ROWSQ / SCALE pair.)
             raise ValueError("the column partition supports the L2 normalisation only: use the row partition for 'l1'")
@@ -302,6 +357,20 @@ class ColumnShardedGraph:
             for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
                 self.backend.propagate(blk, kind, x, x_next[r0:r1], flags, rw, x[r0:r1],
                                        row_sqdiff[r0:r1] if row_sqdiff is not None else None)
+            return
+        if exact_norm and norm:
+            first = flags & ~(_hip.F_L2NORM | _hip.F_SQDIFF)
+            for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
+                self.backend.propagate(blk, kind, x, x_next[r0:r1], first, rw, x[r0:r1], None, None)
+                for p in range(self.world):
+                    if p == self.rank:
+                        self.backend.rowops(x_next[r0:r1], x_next[r0:r1], _hip.F_ROWSQ | (_hip.F_ROWSQ_CONT if p else 0), 0.0, None, None, rowsq[r0:r1])
+                    self.comm.broadcast(rowsq[r0:r1], p)
+            self.comm.join()
+            second = _hip.F_SCALE | (flags & _hip.F_SQDIFF)
+            for r0, r1 in self.row_blocks:
+                self.backend.rowops(x_next[r0:r1], x_next[r0:r1], second, 0.0, x[r0:r1] if (flags & _hip.F_SQDIFF) else None,
+                                    row_sqdiff[r0:r1] if row_sqdiff is not None else None, rowsq[r0:r1])
             return
         first = (flags & ~(_hip.F_L2NORM | _hip.F_SQDIFF)) | (_hip.F_ROWSQ if norm else 0)
         for blk, (r0, r1) in zip(self.blocks, self.row_blocks):
@@ -376,7 +445,7 @@ class ColumnShardedGraph:
 
 
 def embed_column_sharded(cg, kind, x0_local, iterations, residual_weight=0.0,
-                         convergence_threshold=0.0, flags=_hip.F_L2NORM, whiten=False):
+                         convergence_threshold=0.0, flags=_hip.F_L2NORM, whiten=False, exact_norm=False):
     """embed_full / embed_full_with_convergence over a ColumnShardedGraph; whiten=True runs the
     default embed() loop (normalise, then whiten, every iteration) and needs x0_local padded to
     cg.n_pad rows.  x0_local: this rank's (n or n_pad, d/P) columns of the initial matrix.
@@ -403,7 +472,7 @@ def embed_column_sharded(cg, kind, x0_local, iterations, residual_weight=0.0,
     for it in range(iterations):
         test = check and it > 0
         cg.propagate(kind, x, x_next, rowsq, flags | (_hip.F_SQDIFF if test else 0), residual_weight,
-                     sq if test else None)
+                     sq if test else None, exact_norm=exact_norm)
         x, x_next = x_next, x
         if test:
             rmse = (cg.sqdiff_total(sq) / total) ** 0.5

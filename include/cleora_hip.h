@@ -71,6 +71,11 @@ extern "C" {
                                      * pathological hub (10^7+ edges in one row: an in-order chain of as many dependent adds) this
                                      * is the faster form; its hub rows differ from the reference by rounding (<= 2e-6 * sum|terms|) */
 
+#define CLEORA_F_ROWSQ_CONT 2048u /* with ROWSQ: the sum of squares CONTINUES from row_sumsq[r] (in: the sum over the columns to the left,
+                                   * out: that sum extended over this call's d columns, the reference's order src/embedding.rs:94-97) — the
+                                   * column partition hands a row's running sum from rank to rank so that the L2 norm is the one-GPU sum bit
+                                   * for bit (csrc/colsharded.hip) */
+
 typedef struct cleora_graph cleora_graph; /* device-resident CSR shard (struct SparseMatrix, src/sparse_matrix.rs:56-78) */
 
 typedef struct cleora_graph_info {
@@ -494,6 +499,34 @@ int cleora_sharded_debug_fail_first_gather(cleora_sharded *s, int attempts);
 uint64_t cleora_embed_sharded_bytes(uint64_t n_pad, uint64_t local_rows, uint64_t n, uint32_t world, uint32_t d, uint32_t flags);
 int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, uint32_t d, uint64_t max_iterations,
                          float residual_weight, float convergence_threshold, uint32_t flags, uint64_t *iterations_run);
+
+/* ---- the column partition (csrc/colsharded.hip; no reference counterpart) --------------------------------------------------------
+ * The comparison layout beside the row partition: rank r of P owns columns [r d/P, (r + 1) d/P) of every row of the iterate and the
+ * WHOLE CSR ("Cleora operates on dimensions independently", reference README.md:361): no n x d data crosses xGMI.  The row L2 norm
+ * (src/embedding.rs:88-104: sum of squares over j = 0 .. d-1 in order) is kept bit-equal to one GPU by handing every row's running
+ * sum from rank to rank (CLEORA_F_ROWSQ_CONT): P small broadcasts per row block instead of an all-reduce that would add the slices'
+ * sums in another order.  x_local / x_next_local: this rank's n x d/P slice, ld = d/P.  arrays_on_device != 0: col / val_* are
+ * DEVICE arrays that must outlive the handle (viewed, not copied); rowptr may then be a device pointer too (copied).
+ * comm == NULL: a world of one.  d_total must be divisible by the number of ranks.
+ * cleora_colsharded_propagate_dev: flags out of L2NORM, RESIDUAL, BLEND_ANY, SQDIFF, SQDIFF64, HUB_SEGMENTS; row_sqdiff receives this
+ * rank's part of every row's squared difference.  cleora_embed_colsharded: embed_full / embed_full_with_convergence
+ * (src/embedding.rs:106-188), the iterate bit-equal to the one-GPU loop's.  The L1 norm and the whitened loop need whole rows: take
+ * the row partition (cleora_embed_sharded). */
+typedef struct cleora_colsharded cleora_colsharded;
+typedef struct cleora_colsharded_info {
+    uint64_t n, nnz;
+    uint32_t d_total, d_local, col_begin, steps;
+    int32_t rank, world, has_symmetric, reserved;
+} cleora_colsharded_info;
+int cleora_colsharded_create(cleora_comm *comm, int device, uint64_t n, uint64_t nnz, const uint64_t *rowptr, const uint32_t *col,
+                             const float *val_left, const float *val_sym, int arrays_on_device, uint32_t d_total, uint32_t steps,
+                             cleora_colsharded **out);
+int cleora_colsharded_destroy(cleora_colsharded *s);
+int cleora_colsharded_get_info(const cleora_colsharded *s, cleora_colsharded_info *info);
+int cleora_colsharded_propagate_dev(cleora_colsharded *s, int markov_type, const float *x_local, float *x_next_local, uint32_t flags,
+                                    float residual_weight, double *row_sqdiff, void *stream);
+int cleora_embed_colsharded(cleora_colsharded *s, float *x_local, int markov_type, uint64_t max_iterations, float residual_weight,
+                            float convergence_threshold, uint32_t flags, uint64_t *iterations_run);
 
 /* ---- one process, P devices (csrc/multi.hip) --------------------------------------------------------------------------------------
  * The row partition above behind ONE handle, for a host whose call is `embed(graph, 256, 40)` in one process (pycleora/__init__.py:

@@ -306,3 +306,84 @@ def test_peer_transport_selftest_and_the_pull_fallback(world):
         np.testing.assert_array_equal(o["gathered_on_pull"], np.arange(int(cuts[-1]), dtype=np.float32)[:, None] * 10 + owner[:, None] + np.zeros((1, 24), np.float32))
         rc, msg = o["selftest_both_fail"]
         assert rc == _hip.E_RCCL and "not coherent" in msg
+
+
+def _col_worker(rank, world, ident, q, d, cases):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        cm = comm_mod.RcclComm(ident, rank, world, 0, stream_fn=lambda: None, local=True)
+        n, seed = 6001, 51
+        rowptr, col, vl, vs = _graph(n, seed)
+        x0 = np.random.default_rng(seed + 1).standard_normal((n, d)).astype(np.float32)
+        out = {}
+        for name, (steps, kind, iters, rw, thr) in cases.items():
+            cg = sharded.DeviceColShardedGraph(n, rowptr, col, vl, vs, d, cm, steps)
+            assert (cg.world, cg.rank, cg.dl, cg.c0) == (world, rank, d // world, rank * (d // world))
+            dx = _hip.DevArray.from_host(np.ascontiguousarray(x0[:, cg.c0:cg.c0 + cg.dl]))
+            ran = cg.embed(dx, kind, iters, rw, thr)
+            out[name] = (dx.to_host(), ran)
+            dx.free()
+            cg.close()
+        cm.check()
+        cm.close()
+        q.put((rank, out, None))
+    except BaseException as e:                       # noqa: BLE001 - reported to the parent
+        import traceback
+        q.put((rank, None, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+
+
+COL_CASES = {
+    "plain": (1, _hip.LEFT, 6, 0.0, 0.0),
+    "blocks_residual_convergence": (3, _hip.LEFT, 12, 0.25, 2e-3),
+    "symmetric": (2, _hip.SYMMETRIC, 4, 0.0, 0.0),
+}
+
+
+@pytest.mark.parametrize("world,d", [(2, 256), (3, 192), (4, 64)])
+def test_column_partition_through_the_c_abi_is_bit_equal_to_one_gpu(world, d):
+    """csrc/colsharded.hip on ranks sharing the GPU (local communicator): every rank owns d / P columns and the whole CSR; the rows' sums of
+    squares travel from rank to rank in the reference's order (CLEORA_F_ROWSQ_CONT), so the plain loop — residual blend, convergence
+    test, symmetric values, several row blocks — is the one-GPU loop BIT FOR BIT, column slice by column slice."""
+    ident = comm_mod.RcclComm.unique_id(local=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_col_worker, args=(r, world, ident, q, d, COL_CASES)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = {}
+        for _ in range(world):
+            rank, out, err = q.get(timeout=600)
+            assert err is None, f"rank {rank}: {err}"
+            got[rank] = out
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    n, seed = 6001, 51
+    rowptr, col, vl, vs = _graph(n, seed)
+    x0 = np.random.default_rng(seed + 1).standard_normal((n, d)).astype(np.float32)
+    for name, (steps, kind, iters, rw, thr) in COL_CASES.items():
+        want, wran = _one_gpu(rowptr, col, vl, x0, d, iters, rw, thr, 0, val_sym=vs, kind=kind)
+        res = np.concatenate([got[r][name][0] for r in range(world)], axis=1)
+        assert all(got[r][name][1] == wran for r in range(world)), (name, [got[r][name][1] for r in range(world)], wran)
+        np.testing.assert_array_equal(res, want, err_msg=name)
+
+
+def test_column_partition_world_of_one_and_argument_checks():
+    n, d = 3001, 64
+    rowptr, col, vl, vs = _graph(n, 7)
+    x0 = np.random.default_rng(8).standard_normal((n, d)).astype(np.float32)
+    cg = sharded.DeviceColShardedGraph(n, rowptr, col, vl, vs, d, None, 2)
+    dx = _hip.DevArray.from_host(x0)
+    ran = cg.embed(dx, _hip.LEFT, 5, 0.3, 0.0)
+    want, _ = _one_gpu(rowptr, col, vl, x0, d, 5, 0.3, 0.0, 0)
+    assert ran == 5
+    np.testing.assert_array_equal(dx.to_host(), want)
+    L = _hip.lib()
+    dy = _hip.DevArray((n, d), np.float32)
+    assert L.cleora_colsharded_propagate_dev(cg.handle, _hip.LEFT, dx.ptr, dy.ptr, _hip.F_L1NORM, 0.0, None, None) == _hip.E_INVALID
+    assert L.cleora_colsharded_propagate_dev(cg.handle, _hip.LEFT, dx.ptr, dx.ptr, _hip.F_L2NORM, 0.0, None, None) == _hip.E_INVALID
+    assert L.cleora_embed_colsharded(cg.handle, dx.ptr, _hip.LEFT, 2, 0.0, 0.0, _hip.F_WHITEN, None) == _hip.E_INVALID
+    cg.close()

@@ -43,6 +43,13 @@ class OracleBackend:
             out = (np.float32(1.0) - np.float32(rw)) * out + np.float32(rw) * x_self.numpy()
         if flags & _hip.F_L2NORM:
             out = oracle.l2_normalize(out)
+        if flags & _hip.F_ROWSQ:
+            # the reference's order (src/embedding.rs:94-97): sum_sq += v * v for j = 0 .. d - 1, f32; ROWSQ_CONT continues from the
+            # sum over the columns to the left
+            acc = row_sumsq.numpy().copy() if (flags & _hip.F_ROWSQ_CONT) else np.zeros(out.shape[0], np.float32)
+            for j in range(out.shape[1]):
+                acc = (acc + (out[:, j] * out[:, j]).astype(np.float32)).astype(np.float32)
+            row_sumsq.copy_(torch.from_numpy(acc))
         if flags & _hip.F_SCALE:
             norm = np.maximum(np.sqrt(row_sumsq.numpy()), np.float32(1e-10))
             out = out * (np.float32(1.0) / norm)[:, None]
@@ -210,6 +217,53 @@ def _col_worker(rank, world, port, q, steps=1):
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
+
+
+def _col_exact_worker(rank, world, port, q, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, d = 700, 24
+        rowptr, col, vl, vs = random_csr(n, 7, seed=13, empty_frac=0.05)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt) if a.dtype.kind == "u" else a)
+        cg = sharded.ColumnShardedGraph(n, t(rowptr, np.int64), t(col, np.int32), torch.from_numpy(vl),
+                                        torch.from_numpy(vs), d, rank, world, OracleBackend(), steps=steps)
+        x0 = np.random.default_rng(14).standard_normal((n, d)).astype(np.float32)
+        res = {}
+        for kind, rw, thr in ((0, 0.0, 0.0), (1, 0.4, 0.0), (0, 0.0, 2e-3)):
+            xl, ran = sharded.embed_column_sharded(cg, kind, torch.from_numpy(np.ascontiguousarray(x0[:, cg.c0:cg.c0 + cg.dl])),
+                                                   10, rw, thr, exact_norm=True)
+            res[(kind, rw, thr)] = (cg.gather_columns(xl).numpy().copy(), ran)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,steps", [(2, 1), (3, 2), (4, 3)])
+def test_column_partition_with_the_travelling_row_sum_is_bit_equal(world, steps):
+    """The model of csrc/colsharded.hip over gloo: the rows' sums of squares are handed from rank to rank (ROWSQ_CONT) instead of being
+    all-reduced — the reference's summation order (src/embedding.rs:94-97), so the partitioned loop is the oracle's loop BIT FOR BIT,
+    where the all-reduce form above needs a 2e-6 tolerance."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_col_exact_worker, args=(r, world, port, q, steps)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, d = 700, 24
+    rowptr, col, vl, vs = random_csr(n, 7, seed=13, empty_frac=0.05)
+    x0 = np.random.default_rng(14).standard_normal((n, d)).astype(np.float32)
+    for key in got[0][1]:
+        kind, rw, thr = key
+        want, it = oracle.embed(rowptr, col, (vl, vs)[kind], x0, 10, residual_weight=rw, convergence_threshold=thr)
+        for rank, res in got:
+            x, ran = res[key]
+            assert ran == it
+            np.testing.assert_array_equal(x, want)
 
 
 @pytest.mark.parametrize("world,steps", [(2, 1), (2, 3), (4, 4)])

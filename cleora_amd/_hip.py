@@ -80,6 +80,7 @@ SIGNATURES = {
     "cleora_colsharded_create": (c_int, [vp, c_int, c_u64, c_u64, vp, vp, vp, vp, c_int, c_u32, c_u32, ctypes.POINTER(vp)]),
     "cleora_colsharded_destroy": (c_int, [vp]),
     "cleora_colsharded_get_info": (c_int, [vp, vp]),
+    "cleora_colsharded_block": (c_int, [vp, c_u32, ctypes.POINTER(vp), ctypes.POINTER(c_u64), ctypes.POINTER(c_u64)]),
     "cleora_colsharded_propagate_dev": (c_int, [vp, c_int, vp, vp, c_u32, c_f32, vp, vp]),
     "cleora_embed_colsharded": (c_int, [vp, vp, c_int, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),
     "cleora_embed_sharded": (c_int, [vp, vp, c_int, c_u32, c_u64, c_f32, c_f32, c_u32, ctypes.POINTER(c_u64)]),

@@ -211,6 +211,14 @@ int cleora_colsharded_get_info(const cleora_colsharded *s, cleora_colsharded_inf
     return CLEORA_OK;
 }
 
+int cleora_colsharded_block(const cleora_colsharded *s, uint32_t k, cleora_graph **graph, uint64_t *row_begin, uint64_t *row_end) {
+    CL_REQUIRE(s != nullptr && k < s->steps, "handle is NULL / no such block");
+    if (graph) *graph = s->blocks[k].g;
+    if (row_begin) *row_begin = s->blocks[k].r0;
+    if (row_end) *row_end = s->blocks[k].r1;
+    return CLEORA_OK;
+}
+
 int cleora_colsharded_propagate_dev(cleora_colsharded *s, int markov_type, const float *x_local, float *x_next_local, uint32_t flags,
                                     float residual_weight, double *row_sqdiff, void *stream) {
     CL_REQUIRE(s != nullptr, "handle is NULL");

@@ -36,10 +36,18 @@ import numpy as np
 from . import _hip
 from . import comm as comm_mod
 
-try:                                   # the model classes below work on torch tensors; DeviceShardedGraph does not need them
-    import torch
-except ImportError:                    # pragma: no cover
-    torch = None
+class _LazyTorch:
+    """The model classes below work on torch tensors; the C-ABI wrappers (DeviceShardedGraph, DeviceColShardedGraph, plan_rows) do
+    not — and a process that only needs those (every rank of the multi-process C-ABI tests) should not pay for `import torch`
+    (seconds warm, a minute or two on a freshly provisioned box).  Imported on first use."""
+
+    def __getattr__(self, name):
+        import torch as _torch
+        globals()["torch"] = _torch
+        return getattr(_torch, name)
+
+
+torch = _LazyTorch()
 
 
 class _BorrowedGraph(_hip.Graph):
@@ -179,11 +187,25 @@ class DeviceColShardedGraph:
         _hip.check(L.cleora_colsharded_get_info(h, ctypes.byref(info)))
         self.n, self.nnz, self.d, self.dl, self.c0 = info.n, info.nnz, info.d_total, info.d_local, info.col_begin
         self.steps, self.rank, self.world = info.steps, info.rank, info.world
+        self.blocks, self.row_blocks = [], []
+        for k in range(self.steps):
+            g, b0, b1 = _hip.vp(), _hip.c_u64(0), _hip.c_u64(0)
+            _hip.check(L.cleora_colsharded_block(h, k, ctypes.byref(g), ctypes.byref(b0), ctypes.byref(b1)))
+            self.blocks.append(_BorrowedGraph(g, self))
+            self.row_blocks.append((b0.value, b1.value))
 
     def propagate(self, kind, x_local, x_next_local, flags=_hip.F_L2NORM, rw=0.0, row_sqdiff=None, stream=None):
         """One iteration on the (n, d/P) slices (torch tensors or DevArrays, contiguous)."""
         _hip.check(self.L.cleora_colsharded_propagate_dev(self.handle, int(kind), _dev_ptr(x_local), _dev_ptr(x_next_local), int(flags), float(rw),
                                                           _dev_ptr(row_sqdiff), stream))
+
+    def set_timing(self, enable):
+        """Kernel timing of the blocks (cleora_graph_set_timing); the hand-offs of the row sums are not timed separately."""
+        for blk in self.blocks:
+            blk.set_timing(enable)
+
+    def get_timing(self):
+        return (0.0, 0.0), 0            # (DeviceShardedGraph's shape: the blocks' own records hold the SpMM part)
 
     def embed(self, x_local, kind, iterations, residual_weight=0.0, convergence_threshold=0.0, flags=0):
         ran = _hip.c_u64(0)

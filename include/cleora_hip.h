@@ -523,6 +523,8 @@ int cleora_colsharded_create(cleora_comm *comm, int device, uint64_t n, uint64_t
                              cleora_colsharded **out);
 int cleora_colsharded_destroy(cleora_colsharded *s);
 int cleora_colsharded_get_info(const cleora_colsharded *s, cleora_colsharded_info *info);
+/* row block k (< steps) of the handle as a graph (borrowed: for cleora_graph_get_info / set_timing / cleora_alloc_iterates) and its rows */
+int cleora_colsharded_block(const cleora_colsharded *s, uint32_t k, cleora_graph **graph, uint64_t *row_begin, uint64_t *row_end);
 int cleora_colsharded_propagate_dev(cleora_colsharded *s, int markov_type, const float *x_local, float *x_next_local, uint32_t flags,
                                     float residual_weight, double *row_sqdiff, void *stream);
 int cleora_embed_colsharded(cleora_colsharded *s, float *x_local, int markov_type, uint64_t max_iterations, float residual_weight,

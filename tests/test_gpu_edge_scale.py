@@ -307,7 +307,16 @@ def test_generator_values_on_the_gpu_equal_the_cpu_generator():
     (f32 divide, correctly rounded f32 sqrt) must be bit-identical, so the pin carries over to the bench graph."""
     import torch
     from cleora_amd import synth
-    cpu = synth.power_law_graph(50_000, 100_000, 3, torch.device("cpu"))      # (torch CPU sort / unique on a 256-thread box: 46 s at 4x this size)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 8))       # torch's CPU sort / unique with 256 threads on 50k elements: 44 s of this suite went here
+    try:
+        _generator_values(torch, synth)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _generator_values(torch, synth):
+    cpu = synth.power_law_graph(50_000, 100_000, 3, torch.device("cpu"))
     rp = cpu["rowptr"].numpy()
     rows = np.repeat(np.arange(cpu["n"]), np.diff(rp))
     cols = cpu["col"].numpy().astype(np.int64)

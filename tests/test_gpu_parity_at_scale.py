@@ -221,7 +221,7 @@ def test_default_loop_for_forty_iterations_against_the_reference_order(c2, oracl
           (pycleora/__init__.py:109-117) — which `cleora_embed_dev` runs when a convergence threshold is set (a threshold that
           is never met: 1e-30) and which test_whitened_loop_at_c2_size_against_the_oracle_loop's sibling below pins to the
           oracle loop;
-      (b) oracle.whiten.embed_slow (numpy fp64 statistics, LAPACK eigh: the reference's own arithmetic) for 10 iterations,
+      (b) oracle.whiten.embed_slow (numpy fp64 statistics, LAPACK eigh: the reference's own arithmetic) for 7 iterations,
           inside a time budget (the CPU side is 10 x (20 GB of gathers + an fp64 Gram of 1M x 256)).
 
     PCA whitening is defined up to column signs and rotations inside clusters of equal eigenvalues, so the comparison is on
@@ -252,7 +252,7 @@ def test_default_loop_for_forty_iterations_against_the_reference_order(c2, oracl
                           "max_abs_cov_minus_identity": cov_err}
     # (b) the oracle's loop, 10 iterations (continuing the module's shared loop: iterations 1-4 were run by the test above), time-boxed
     t0, threads = time.perf_counter(), oracle_whitened.threads
-    x, oracle_iters = oracle_whitened.advance_to(10, budget_s=150.0)
+    x, oracle_iters = oracle_whitened.advance_to(7, budget_s=150.0)        # (each oracle iteration is ~3 s of all host cores: 7, not 10 — the record test pins 4, the GPU's own orders are compared at 10 / 20 / 40)
     got = gpu(oracle_iters, 0.0)
     cg, ng = _invariants(got, rows)
     co, no = _invariants(x, rows)

@@ -119,3 +119,36 @@ def test_multi_handle_through_the_c_abi_shapes_and_errors():
     m.close()
     with pytest.raises((ValueError, RuntimeError), match="device id"):
         _hip.MultiGraph.from_host([0, 99], rowptr, col, vl, None)
+
+
+@pytest.mark.skipif(_hip.device_count() < 2, reason="needs two GPUs: distinct device ids (hipDeviceEnablePeerAccess, cross-device events, per-device staging)")
+@pytest.mark.parametrize("devices", [[0, 1], [1, 0, 1]])
+def test_multi_handle_on_distinct_devices(devices):
+    """everything above repeats device 0 (the test box has one GPU), so the code only DISTINCT devices reach — peer access
+    between the threads' devices, hipStreamWaitEvent across devices in the in-process signals, per-device staging and rocBLAS handles, the
+    self-test of the peer transport over a real link — had never run.  On a box with two or more GPUs: the plain loop and the propagate
+    bit-equal to the oracle, the whitened loop within its tolerance of the one-device result."""
+    n = 20011
+    rowptr, col, vl, vs = random_csr(n, 9, seed=5, empty_frac=0.03, hubs=[(17, 2200), (4000, 1300)])
+    hashes = np.random.default_rng(6).integers(0, 2 ** 63, n).astype(np.uint64)
+    d = 256
+    m = _hip.MultiGraph.from_host(devices, rowptr, col, vl, vs, steps=2)
+    x0 = oracle.init(hashes, d, 3)
+    want, _ = oracle.embed(rowptr, col, vl, x0, 6, residual_weight=0.25)
+    got, ran = m.embed(hashes, None, _hip.LEFT, d, 6, seed=3, residual_weight=0.25)
+    assert ran == 6
+    np.testing.assert_array_equal(got, want)
+    x = np.random.default_rng(d).standard_normal((n, d)).astype(np.float32)
+    np.testing.assert_array_equal(m.propagate(_hip.SYMMETRIC, x), oracle.spmm(rowptr, col, vs, x))
+    gotw, _ = m.embed(hashes, None, _hip.LEFT, d, 4, seed=3, flags=_hip.F_WHITEN)
+    m.close()
+    m1 = _hip.MultiGraph.from_host([0], rowptr, col, vl, vs)
+    wantw, _ = m1.embed(hashes, None, _hip.LEFT, d, 4, seed=3, flags=_hip.F_WHITEN)
+    m1.close()
+    rows = np.random.default_rng(1).choice(n, 400, replace=False)
+
+    def cos(e):
+        u = e[rows].astype(np.float64)
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        return u @ u.T
+    assert np.isfinite(gotw).all() and np.abs(cos(gotw) - cos(wantw)).max() < 1e-4

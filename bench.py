@@ -34,6 +34,7 @@ Prints ONE JSON line on rank 0.  `value` = nnz * d * steps / seconds (edge*dim/s
 timed region on the launch stream.
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -944,7 +945,6 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
     el = time.perf_counter() - t0
     ms, c = gr.get_timing()
     gr.set_timing(False)
-    import ctypes
     wms, wc = (ctypes.c_double * 4)(), ctypes.c_uint64(0)
     _hip.check(L.cleora_whiten_get_timing(ctypes.byref(wms), ctypes.byref(wc)))
     _hip.check(L.cleora_whiten_set_timing(0))
@@ -983,6 +983,41 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
                          "peak": gi_peak, "unit": "TFLOP/s", "frac": gi_flops / (stats_inter_ms * 1e-3) / 1e12 / gi_peak,
                          "executed_flops": gi_flops, "f32_equivalent_tflops": (gi_flops / 3.0 if split_gram else gi_flops) / (stats_inter_ms * 1e-3) / 1e12}
     del m64, g64
+    # the projection the product's loop takes in its INTERMEDIATE iterations at d = 256 (csrc/project_f16.hip: bounded operands, three
+    # f16 MFMAs per product, the transform resident in registers), timed stand-alone on the SpMM's output with its column means and a
+    # dense transform; `form` tells which kernel ran (1: f16; 0: the six-product bf16 form — other widths)
+    proj_inter = None
+    if d == 256:
+        rsum = torch.empty(n, dtype=torch.float32, device=dev)
+        rabs = torch.empty(n, dtype=torch.float32, device=dev)
+        _hip.check(L.cleora_csr_rowsums_dev(gr.handle, _hip.LEFT, rsum.data_ptr(), rabs.data_ptr(), stream))
+        mu32 = torch.zeros(d, dtype=torch.float32, device=dev)
+        for r0 in range(0, n, 1 << 21):
+            mu32 += mid[r0:r0 + (1 << 21)].sum(0) / n
+        mu32.clamp_(-1.0, 1.0)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(7)
+        tr = (torch.randn((d, d), generator=gen, device=dev) + 16.0 * torch.eye(d, device=dev)).contiguous()
+        nd_, fm_ = ctypes.c_int(0), ctypes.c_int(-1)
+
+        def proj_once():
+            _hip.check(L.cleora_project_bounded_dev(mid.data_ptr(), d, n, d, mu32.data_ptr(), tr.data_ptr(), d, nxt.data_ptr(), d,
+                                                    rsum.data_ptr(), rabs.data_ptr(), 1, ctypes.byref(nd_), ctypes.byref(fm_), stream))
+        proj_once()
+        e0.record()
+        for _ in range(5):
+            proj_once()
+        e1.record()
+        torch.cuda.synchronize()
+        pms = e0.elapsed_time(e1) / 5
+        pbytes = 2.0 * n * d * 4
+        proj_inter = {"kernel": "project_f16_kernel<true> (csrc/project_f16.hip)" if fm_.value == 1 else "project_split_kernel (six-product bf16 form)",
+                      "ms": pms, "bound": "hbm", "achieved": pbytes / (pms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": pbytes,
+                      "mfma": {"dtype": "f16 (two-way split operands, 3 products)", "achieved": 6.0 * n * d * d / (pms * 1e-3) / 1e12,
+                               "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": 6.0 * n * d * d / (pms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF},
+                      "row_norm_max_abs_minus_1": float((nxt[:1 << 20].double().pow(2).sum(1).sqrt() - 1).abs().max())}
+        del rsum, rabs, mu32, tr
     # the product's loop for this path (cleora_embed_dev, what cleora_amd.embed.embed() runs): SpMM(t+1) beside Gram / eigh(t)
     del mid, nxt, ws, m_, p_, n_
     torch.cuda.empty_cache()
@@ -1020,7 +1055,11 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
         "placement_launch_ms": {"untuned": round(place_ms[0], 3), "chosen": round(place_ms[1], 3)},
         "kernels_ms": {"spmm_l2": ms[1] / max(c, 1) + (ms[0] + ms[2]) / max(c, 1), "column_statistics": stats_ms,
                        "gram_f64_mfma": gram_ms, "eigensolver_transform": eigh_ms, "project": proj_ms,
-                       "statistics_intermediate_form": stats_inter_ms},
+                       "statistics_intermediate_form": stats_inter_ms,
+                       "project_intermediate_form": proj_inter["ms"] if proj_inter else None},
+        "kernels_ms_note": "spmm_l2 .. project: the reference-order loop driven from Python with stage events (every iteration a full PCA whitening: f64 Gram, "
+                           "eigensolver, six-product projection); *_intermediate_form: what the default loop runs instead in all but its last iteration",
+        "project_intermediate_roofline": proj_inter,
         "project_form": ("split-bf16: every f32 product from six bf16 MFMAs of three-way split operands (csrc/whiten.hip)"
                          if split_proj else "f32 MFMA (tiled kernel: d is not a multiple of 32)"),
         "gram_intermediate_roofline": gram_intermediate,

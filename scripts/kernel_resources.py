@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "cleora_amd", "csrc")
 lines = ["# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage over cleora_amd/csrc/*.hip "
          "(build flags of build.sh): file, kernel, VGPRs, AGPRs, scratch bytes/lane, waves/SIMD, LDS bytes/block"]
-for f in ("spmm", "rowops", "whiten", "eigh", "hot", "attention", "similarity", "abi", "peer", "sharded", "stager"):
+for f in ("spmm", "rowops", "whiten", "project_f16", "eigh", "hot", "attention", "similarity", "abi", "peer", "sharded", "colsharded", "multi", "stager"):
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math"]
     if f == "whiten":
         cmd += ["-mllvm", "-amdgpu-mfma-vgpr-form"]

@@ -27,6 +27,8 @@
 //     (T's columns are scaled to the f16 range by powers of two as well), sum of squares, the row's factor, one coalesced 1 KiB
 //     store per row.  Scaling by powers of two commutes with every rounding involved, so the row scale is undone in the row's
 //     final factor: same values as unscaled arithmetic.
+#include <type_traits>
+
 #include "common.h"
 #include "project_common.h"
 
@@ -62,7 +64,9 @@ __device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t &p1, u
 
 // T (256 x 256 row-major f32) -> per-column power-of-two scale, hi / lo f16 fragments in the consumer's register order:
 // tp[((w * 16 + ks) * 2 + sp) * 64 + lane] = 8 x f16: lane (j, h) <-> column 32 w + j, k = 16 ks + 8 h + e.   One block per column.
-__global__ __launch_bounds__(256) void pack_transform_f16_kernel(const float *__restrict__ t, _Float16 *__restrict__ tp, float *__restrict__ colscale) {
+// `transposed`: the fragment lane of a column is permuted for project_f16t_kernel (see its store path): column c of the wave's 32 sits at
+// lane (c & 3) + 4 ((c >> 3) & 1) + 8 (2 (c >> 4) + ((c >> 2) & 1)).
+__global__ __launch_bounds__(256) void pack_transform_f16_kernel(const float *__restrict__ t, _Float16 *__restrict__ tp, float *__restrict__ colscale, int transposed) {
     __shared__ float red[4];
     const uint32_t col = blockIdx.x, kk = threadIdx.x;
     const float v = t[(uint64_t)kk * PF_D + col];
@@ -78,7 +82,8 @@ __global__ __launch_bounds__(256) void pack_transform_f16_kernel(const float *__
     const float tv = ldexpf(v, st);
     const _Float16 hi = (_Float16)tv;
     const _Float16 lo = (_Float16)(tv - (float)hi);
-    const uint32_t w = col >> 5, j = col & 31, ks = kk >> 4, h = (kk >> 3) & 1, e = kk & 7;
+    const uint32_t w = col >> 5, cl = col & 31, ks = kk >> 4, h = (kk >> 3) & 1, e = kk & 7;
+    const uint32_t j = transposed ? (cl & 3) + 4 * ((cl >> 3) & 1) + 8 * (2 * (cl >> 4) + ((cl >> 2) & 1)) : cl;
     const uint64_t unit = ((uint64_t)(w * PF_KS + ks) * 2) * 64 + (h * 32 + j);
     tp[unit * 8 + e] = hi;
     tp[(unit + 64) * 8 + e] = lo;
@@ -260,7 +265,296 @@ __global__ __launch_bounds__(PF_THREADS, 2) void project_f16_kernel(const F16Arg
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The TRANSPOSED form (round 6, second pass): the same fragments and products with the MFMA's operands swapped — D^T = T^T x^T — so
+// that a lane's accumulators are SIXTEEN COLUMNS OF ONE ROW (32x32 C/D map: lane & 31 = tile row, reg -> column (reg & 3) + 8 (reg >> 2)
+// + 4 (lane >> 5) of the wave's 32) instead of sixteen rows of one column.  What that buys:
+//   * a row's sum of squares is an in-lane sum over registers: only 16 partial sums per row (8 waves x 2 lane halves) cross waves,
+//     through 4 KiB of LDS, instead of the whole accumulator tile (64 KiB) being staged for a row-major pass;
+//   * four consecutive registers are four consecutive columns: the tile leaves as 16-byte stores straight from the accumulators;
+//   * no staging buffer, so the two fragment buffers are a true double buffer and ONE barrier per tile remains: the next tile's
+//     fragments are produced (centre, scale, split, ds_write) between the MFMAs of the current one instead of in a phase of their own.
+// The loop is one basic block (full tiles only; a ragged last tile runs a peeled copy with masked stores): the loads of tile k + 2
+// stay in flight across the back edge behind counted waits.
+constexpr size_t PFT_RED = 2 * 16 * 64 * 4;                   // [parity][8 waves x 2 halves][row] partial sums
+constexpr size_t PFT_INFO = 8 * 2 * 64 * 8;                   // [wave][parity][row] {s_r, 2^e_r}: wave-private copies (no barrier)
+constexpr size_t PFT_LDS = 2 * (size_t)PF_BUF + PFT_RED + PFT_INFO + 2 * PF_D * 4;   // 146 KiB
+
+__device__ __forceinline__ void pf_barrier() {                 // LDS-only hand-off: global loads / stores in flight are not drained
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+struct F16TArgs {
+    ProjArgs p;
+    const u32x4 *tp;
+    const float *colscale;
+    const float *rowscale;     // per row s_r (never null: the launcher passes ones)
+    const float *rowbound;     // per row B_r (never null)
+    uint64_t full_blocks;      // blocks sharing the full tiles (gridDim.x minus the ragged tile's block)
+};
+
+template <int NORM, int DBG = 0>
+__global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *const frag = smem;                                             // [2][PF_BUF]
+    float *const red = reinterpret_cast<float *>(smem + 2 * PF_BUF);              // [2][16][64]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 31, h = lane >> 5;
+    float2 *const rinfo = reinterpret_cast<float2 *>(smem + 2 * PF_BUF + PFT_RED) + w * 2 * 64;   // [2][64], this wave's
+    float *const mean_s = reinterpret_cast<float *>(smem + 2 * PF_BUF + PFT_RED + PFT_INFO);
+    float *const cs_s = mean_s + PF_D;
+    const ProjArgs &p = a.p;
+    // blocks 0 .. G-1 share the FULL tiles (no row of theirs needs a guard); block G, if launched, owns the ragged last tile
+    const uint64_t tiles_full = p.n / PF_ROWS, G = a.full_blocks, b = blockIdx.x;
+    const bool ragged = b >= G;
+    const uint64_t cnt_full = ragged ? 0 : (tiles_full - b + G - 1) / G;
+
+    h8v bhi[PF_KS], blo[PF_KS];
+#pragma unroll
+    for (int ks = 0; ks < PF_KS; ++ks) {
+        bhi[ks] = __builtin_bit_cast(h8v, a.tp[((uint64_t)(w * PF_KS + ks) * 2 + 0) * 64 + lane]);
+        blo[ks] = __builtin_bit_cast(h8v, a.tp[((uint64_t)(w * PF_KS + ks) * 2 + 1) * 64 + lane]);
+    }
+    if (t < PF_D) { mean_s[t] = p.mean[t]; cs_s[t] = a.colscale[t]; }
+
+    // producer role (as in the staged form): rows 8 j + r8 of the tile, columns 32 w + 4 pc .. + 3
+    const int r8 = (lane >> 1) & 7, pc = ((lane >> 4) << 1) | (lane & 1);
+    const int ksub = pc >> 2, hh = (pc >> 1) & 1, half = pc & 1;
+    const uint32_t col0 = 32u * w + 4u * pc;
+    const uint32_t frag_lane_off = (uint32_t)((2 * w + ksub) * 2 * 1024 + (hh * 32 + r8) * 16 + half * 8);
+    float4 P[8];
+    float ri_s, ri_b;
+    // full tiles: the tile index is clamped to the last full one (uniform: a prefetch past the block's share re-reads valid rows);
+    // the ragged tile's block clamps rows instead
+    auto issue_tile = [&](uint64_t tile) {
+        tile = tile < tiles_full ? tile : tiles_full - 1;
+        const uint64_t r0 = tile * PF_ROWS;
+        ri_s = a.rowscale[r0 + (uint64_t)lane];                                   // the oldest loads of the batch: first to be waited for
+        ri_b = a.rowbound[r0 + (uint64_t)lane];
+        const float *const base = p.x + (r0 + (uint64_t)r8) * p.ldx + col0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P[j] = *reinterpret_cast<const float4 *>(base + (uint64_t)(8 * j) * p.ldx);
+    };
+    auto issue_ragged = [&]() {
+        const uint64_t r0 = tiles_full * PF_ROWS, last_row = p.n - 1;
+        const uint64_t rl = r0 + (uint64_t)lane < last_row ? r0 + (uint64_t)lane : last_row;
+        ri_s = a.rowscale[rl];
+        ri_b = a.rowbound[rl];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t row = r0 + (uint64_t)(8 * j + r8) < last_row ? r0 + (uint64_t)(8 * j + r8) : last_row;
+            P[j] = *reinterpret_cast<const float4 *>(p.x + row * p.ldx + col0);
+        }
+    };
+    auto publish = [&](int par) {                                                 // lane L <-> row L of the tile, this wave's copy
+        const float bound = fabsf(ri_b) + fabsf(ri_s);                            // |x - s mu| <= B + |s| (|mu| <= 1)
+        int e = (bound > 0.f && bound < __builtin_inff()) ? PF_TOP - __builtin_amdgcn_frexp_expf(bound) : 0;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        rinfo[par * 64 + lane] = make_float2(ri_s, ldexpf(1.0f, e));
+    };
+    auto produce_piece = [&](int j, unsigned char *fb, int par) {
+        const float2 info = rinfo[par * 64 + 8 * j + r8];
+        const float4 mu4 = *reinterpret_cast<const float4 *>(mean_s + col0);     // (re-read per piece: four registers fewer across the loop)
+        const float xv[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
+        const float mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __fmul_rn(centre(xv[e], mv[e], info.x, true), info.y);   // (x - s mu) 2^e: the scaling is exact
+        uint32_t h0, l0, h1, l1;
+        split2h_pair(o[0], o[1], h0, l0);
+        split2h_pair(o[2], o[3], h1, l1);
+        unsigned char *const dst = fb + (j >> 2) * (PF_BUF / 2) + frag_lane_off + (j & 3) * 128;
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(l0, l1);
+    };
+
+    // ---- prologue: fragments of the first tile, operands of the second in flight -----------------------------------------------
+    if (ragged) issue_ragged(); else issue_tile(b);
+    __syncthreads();                                                              // mean_s, cs_s
+    publish(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) produce_piece(j, frag, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!ragged) issue_tile(b + G);
+    pf_barrier();
+
+    // The loop is ROTATED — { finish tile k ; products of tile k + 1 } — so that its back edge sits right behind the loads of tile
+    // k + 3: entering from the prologue and from the back edge the same ten loads are the youngest vector-memory operations, and the
+    // waits the compiler counts for them (behind the eight stores of `finish`) are the same on both paths (merged at the loop
+    // header, the more conservative path wins: with the loop entered behind the stores the prologue's state did).
+    f16v acc[2];
+    uint64_t dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t = 0;                         // DBG == 3: cycles of finish()'s three parts
+    auto products = [&](uint64_t k, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int par = (int)(k & 1);
+        const uint64_t T = LAST ? tiles_full : b + k * G;
+        const unsigned char *const fa = frag + par * PF_BUF + lane * 16;
+        unsigned char *const fb = frag + (par ^ 1) * PF_BUF;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+        // ---- the tile's products; the next tile's fragments between them ---------------------------------------------------------
+        // one set of fragment registers: a k-step's hi fragments are re-read for the next k-step as soon as their four MFMAs have
+        // issued (the two lo products cover the read), the lo fragments after theirs (the next k-step's four hi products cover it)
+        h8v ah[2], al[2];
+        auto read_hi = [&](int ks) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) ah[rt] = *reinterpret_cast<const h8v *>(fa + rt * (PF_BUF / 2) + (ks * 2 + 0) * 1024);
+        };
+        auto read_lo = [&](int ks) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) al[rt] = *reinterpret_cast<const h8v *>(fa + rt * (PF_BUF / 2) + (ks * 2 + 1) * 1024);
+        };
+        read_hi(0);
+        read_lo(0);
+#pragma unroll
+        for (int ks = 0; ks < PF_KS; ++ks) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[ks], ah[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[ks], ah[1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[ks], ah[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo[ks], ah[1], acc[1], 0, 0, 0);
+            if (ks + 1 < PF_KS) read_hi(ks + 1);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[ks], al[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi[ks], al[1], acc[1], 0, 0, 0);
+            if (ks + 1 < PF_KS) read_lo(ks + 1);
+            if constexpr (!LAST) {
+                if (ks == 5) publish(par ^ 1);
+                if (ks >= 6 && ks < 14) produce_piece(ks - 6, fb, par ^ 1);
+            }
+        }
+        if constexpr (!LAST && DBG != 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_tile(T + 2 * G);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto finish = [&](uint64_t k, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int par = (int)(k & 1);
+        const uint64_t T = LAST ? tiles_full : b + k * G;
+        if constexpr (DBG == 3) dbg_t = __builtin_readcyclecounter();
+        // ---- column scales; the lane's partial sums of its two rows -------------------------------------------------------------
+        float part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                             // four columns' scales at a time (registers)
+            const float4 cv = *reinterpret_cast<const float4 *>(cs_s + 32 * w + 16 * (q >> 1) + 8 * h + 4 * (q & 1));   // register group q <-> these columns
+            const float csq[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float m[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[rt][4 * q + e] * csq[e];
+                    acc[rt][4 * q + e] = v;
+                    m[e] = NORM == 2 ? fabsf(v) : v * v;
+                }
+                part[rt] += (m[0] + m[1]) + (m[2] + m[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (NORM != 0) {
+            red[(par * 16 + 2 * w + h) * 64 + c] = part[0];                      // [parity][slot][row]: lane-linear writes and reads
+            red[(par * 16 + 2 * w + h) * 64 + 32 + c] = part[1];
+        }
+        if constexpr (DBG == 3) { const uint64_t q_ = __builtin_readcyclecounter(); dbg_a += q_ - dbg_t; dbg_t = q_; }
+        pf_barrier();
+        if constexpr (DBG == 3) { const uint64_t q_ = __builtin_readcyclecounter(); dbg_b += q_ - dbg_t; dbg_t = q_; }
+        // ---- whole-row factors, 16-byte stores straight from the accumulators ---------------------------------------------------
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            if (rt) __builtin_amdgcn_sched_barrier(0);                            // one row's sixteen partial sums in registers at a time
+            const int rr = 32 * rt + c;
+            const float sc = rinfo[par * 64 + rr].y;                              // 2^e_r; its reciprocal by the exponent field
+            const float unscale = __uint_as_float(0x7F000000u - __float_as_uint(sc));
+            float f = unscale;
+            if constexpr (NORM != 0) {
+                const float *const rp = red + par * 16 * 64 + rr;
+                float u[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) u[q] = rp[q * 64];
+                const float s = (((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]))) +
+                                (((u[8] + u[9]) + (u[10] + u[11])) + ((u[12] + u[13]) + (u[14] + u[15])));
+                // L2: v (1 / max(sqrt(S), 1e-10)) like src/embedding.rs:98-102; L1: v / max(S, 1e-10) (pycleora/__init__.py:947-950); the
+                // sums were taken on rows scaled by 2^e: S_true = S 2^-2e (L2) / S 2^-e (L1)
+                f = NORM == 1 ? unscale * (1.0f / fmaxf(sqrtf(s) * unscale, 1e-10f)) : fmaxf(s * unscale, 1e-10f);
+            }
+            float o[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = NORM == 2 ? (acc[rt][r] * unscale) / f : acc[rt][r] * f;
+            // A lane holds 16-byte pieces of ONE row; a store instruction that took one piece per lane would touch 32 rows (32 cache
+            // lines, 32 B each: ~60 cycles of the CU's one address unit per instruction, 64 such instructions per tile — measured as
+            // the critical path).  v_permlane16_swap trades the odd 16-lane rows of register group 2 g with the even rows of group
+            // 2 g + 1: afterwards group 2 g holds, in its four 16-lane rows, the four pieces (64 contiguous bytes: the fragment order
+            // of T's columns was chosen for that, pack_transform_f16_kernel) of tile rows 0-15, group 2 g + 1 those of rows 16-31.
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(o[8 * g + e]), "+v"(o[8 * g + 4 + e]));
+            const uint64_t row0 = T * PF_ROWS + (uint64_t)(32 * rt + (lane & 15));
+            float *const orow = p.out + row0 * p.ldo + 32 * w + 4 * (lane >> 4);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {                                     // u: tile rows 0-15 / 16-31 of this half
+                    const float4 v = make_float4(o[8 * g + 4 * u], o[8 * g + 4 * u + 1], o[8 * g + 4 * u + 2], o[8 * g + 4 * u + 3]);
+                    if ((!LAST || row0 + 16 * u < p.n) && (DBG != 2 || v.x == 123.456f))
+                        *reinterpret_cast<float4 *>(orow + (uint64_t)(16 * u) * p.ldo + 16 * g) = v;
+                }
+        }
+        if constexpr (DBG == 3) { const uint64_t q_ = __builtin_readcyclecounter(); dbg_c += q_ - dbg_t; dbg_t = q_; }
+    };
+    if (ragged) {
+        products(0, std::true_type{});
+        finish(0, std::true_type{});
+        return;
+    }
+    if constexpr (DBG == 3) {                                                     // development: where a wave's cycles go
+        uint64_t tp_ = 0, tf_ = 0, t0 = __builtin_readcyclecounter(), t1;
+        const uint64_t tstart = t0;
+        products(0, std::false_type{});
+        for (uint64_t k = 0; k + 1 < cnt_full; ++k) {
+            t1 = __builtin_readcyclecounter(); tp_ += t1 - t0; t0 = t1;
+            finish(k, std::false_type{});
+            t1 = __builtin_readcyclecounter(); tf_ += t1 - t0; t0 = t1;
+            products(k + 1, std::false_type{});
+        }
+        t1 = __builtin_readcyclecounter(); tp_ += t1 - t0; t0 = t1;
+        finish(cnt_full - 1, std::false_type{});
+        t1 = __builtin_readcyclecounter(); tf_ += t1 - t0;
+        __syncthreads();
+        if (b == 0 && lane == 0) {
+            p.out[4 * w + 0] = (float)tp_;
+            p.out[4 * w + 1] = (float)tf_;
+            p.out[4 * w + 2] = (float)(t1 - tstart);
+            p.out[4 * w + 3] = (float)cnt_full;
+            p.out[32 + 4 * w + 0] = (float)dbg_a;
+            p.out[32 + 4 * w + 1] = (float)dbg_b;
+            p.out[32 + 4 * w + 2] = (float)dbg_c;
+        }
+        return;
+    }
+    products(0, std::false_type{});
+    for (uint64_t k = 0; k + 1 < cnt_full; ++k) {
+        finish(k, std::false_type{});
+        products(k + 1, std::false_type{});
+    }
+    finish(cnt_full - 1, std::false_type{});
+}
+
+__global__ __launch_bounds__(256) void fill_ones_kernel(float *__restrict__ v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = 1.0f;
+}
+
+int g_pf16_form = 0;           // development switch (cleora_dev_project_form): 1 = the staged form
+
 }  // namespace
+
+extern "C" void cleora_dev_project_form(int form) { g_pf16_form = form; }
 
 bool project_f16_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, const float *out, uint64_t ldo, const float *x2) {
     auto aligned16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
@@ -277,13 +571,51 @@ int launch_project_f16(const float *x, uint64_t ldx, uint64_t n, const float *me
     float *colscale = nullptr;
     CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), (size_t)PF_D * PF_D * 2 * sizeof(_Float16) + PF_D * sizeof(float), stream));
     colscale = reinterpret_cast<float *>(tp + (size_t)PF_D * PF_D * 2);
-    hipLaunchKernelGGL(pack_transform_f16_kernel, dim3(PF_D), dim3(256), 0, stream, t, tp, colscale);
+    hipLaunchKernelGGL(pack_transform_f16_kernel, dim3(PF_D), dim3(256), 0, stream, t, tp, colscale, g_pf16_form != 1 ? 1 : 0);
     static int cus = 0;
     if (!cus) {
         int dev = 0, c = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         cus = c > 0 ? c : 256;
     }
+    const uint64_t tiles = (n + PF_ROWS - 1) / PF_ROWS;
+    const unsigned gx = (unsigned)(tiles < (uint64_t)cus ? tiles : (uint64_t)cus);
+    hipError_t e = hipSuccess;
+    float *ones = nullptr;
+    if (g_pf16_form != 1) {
+        // the transposed form reads both per-row vectors unconditionally (its loop is one basic block): absent ones are ones
+        if (!rowscale || !rowbound) {
+            CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&ones), n * sizeof(float), stream));
+            hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ones, n);
+        }
+        F16TArgs a{};
+        a.p.x = x;
+        a.p.ldx = ldx;
+        a.p.n = n;
+        a.p.d = PF_D;
+        a.p.mean = mean;
+        a.p.k = PF_D;
+        a.p.out = out;
+        a.p.ldo = ldo;
+        a.p.norm = norm;
+        a.tp = reinterpret_cast<const u32x4 *>(tp);
+        a.colscale = colscale;
+        a.rowscale = rowscale ? rowscale : ones;
+        a.rowbound = rowbound ? rowbound : ones;
+        const uint64_t tiles_full = n / PF_ROWS;
+        a.full_blocks = tiles_full < (uint64_t)cus ? tiles_full : (uint64_t)cus;
+        const unsigned gt = (unsigned)a.full_blocks + (n % PF_ROWS ? 1u : 0u);      // + the ragged tile's block
+        auto go = [&](auto kernel) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PFT_LDS);
+            if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(gt), dim3(PF_THREADS), PFT_LDS, stream, a);
+        };
+        if (norm == 1 && g_pf16_form == 2) go(project_f16t_kernel<1, 1>);
+        else if (norm == 1 && g_pf16_form == 3) go(project_f16t_kernel<1, 2>);
+        else if (norm == 1 && g_pf16_form == 4) go(project_f16t_kernel<1, 3>);
+        else if (norm == 1) go(project_f16t_kernel<1>);
+        else if (norm == 2) go(project_f16t_kernel<2>);
+        else go(project_f16t_kernel<0>);
+    } else {
     F16Args a{};
     a.p.x = x;
     a.p.ldx = ldx;
@@ -298,9 +630,7 @@ int launch_project_f16(const float *x, uint64_t ldx, uint64_t n, const float *me
     a.tp = reinterpret_cast<const u32x4 *>(tp);
     a.colscale = colscale;
     a.rowbound = rowbound;
-    a.tiles = (n + PF_ROWS - 1) / PF_ROWS;
-    const unsigned gx = (unsigned)(a.tiles < (uint64_t)cus ? a.tiles : (uint64_t)cus);
-    hipError_t e;
+    a.tiles = tiles;
     if (rowscale) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(project_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS);
         if (e == hipSuccess) hipLaunchKernelGGL(project_f16_kernel<true>, dim3(gx), dim3(PF_THREADS), PF_LDS, stream, a);
@@ -308,7 +638,9 @@ int launch_project_f16(const float *x, uint64_t ldx, uint64_t n, const float *me
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(project_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS);
         if (e == hipSuccess) hipLaunchKernelGGL(project_f16_kernel<false>, dim3(gx), dim3(PF_THREADS), PF_LDS, stream, a);
     }
+    }
     const hipError_t le = e != hipSuccess ? e : hipGetLastError();
+    if (ones) CL_HIP(hipFreeAsync(ones, stream));
     CL_HIP(hipFreeAsync(tp, stream));
     CL_HIP(le);
     return CLEORA_OK;

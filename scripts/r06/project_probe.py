@@ -58,14 +58,22 @@ def call(form, norm, scaled):
     assert norm == 0 or nd.value == 1
 
 
+FORMS = ("f16", "f16_staged", "bf16x6")       # f16: the transposed form (default); f16_staged: the round's first form
+
+
+def select(form):
+    L.cleora_dev_project_form(1 if form == "f16_staged" else 0)
+    return "f16" if form.startswith("f16") else form
+
+
 for norm in (1, 0, 2):
     for scaled in (True, False):
         ref = reference(norm, scaled)
         key = f"norm{norm}_{'scaled' if scaled else 'plain'}"
         res[key] = {}
-        for form in ("f16", "bf16x6"):
+        for form in FORMS:
             out.zero_()
-            call(form, norm, scaled)
+            call(select(form), norm, scaled)
             torch.cuda.synchronize()
             got = out[sample].double()
             err = (got - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-300)
@@ -77,12 +85,13 @@ print(json.dumps(res), flush=True)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 res["ms"] = {}
 for rep in range(2):
-    for form in ("f16", "bf16x6"):
+    for form in FORMS:
+        f = select(form)
         for _ in range(2):
-            call(form, 1, True)
+            call(f, 1, True)
         ev[0].record()
         for _ in range(10):
-            call(form, 1, True)
+            call(f, 1, True)
         ev[1].record()
         torch.cuda.synchronize()
         res["ms"].setdefault(form, []).append(round(ev[0].elapsed_time(ev[1]) / 10, 3))

@@ -18,15 +18,24 @@
 //
 //   * block = 8 waves (one block per CU, persistent over 64-row tiles); wave w owns output columns [32 w, 32 w + 32): its 32 B
 //     fragments (16 k-steps x hi / lo) stay in 128 VGPRs for the whole launch.
-//   * A: every wave loads 128-byte pieces of eight rows per instruction (wave w = columns [32 w, +32): the column means are four
-//     registers), one tile ahead, in registers; centred, scaled by the row's power of two (2^e_r with (B_r + |s_r|) 2^e_r < 2^14),
-//     split, and written as f16 fragments — [row half][k-step][hi / lo][lane] x 16 B, lane-linear: conflict-free ds_write_b64 /
-//     ds_read_b128 — into one of two 64 KiB buffers.  All eight waves read all fragments of the tile.
-//   * per tile and wave: 64 ds_read_b128, 96 MFMAs (two 32-row halves: consecutive MFMAs alternate accumulators).
-//   * epilogue: the accumulators go through LDS (the buffer just consumed) so that every wave finishes whole ROWS: column scales
-//     (T's columns are scaled to the f16 range by powers of two as well), sum of squares, the row's factor, one coalesced 1 KiB
-//     store per row.  Scaling by powers of two commutes with every rounding involved, so the row scale is undone in the row's
+//   * A: every wave loads 128-byte pieces of eight rows per instruction (wave w = columns [32 w, +32)), TWO tiles ahead, in registers;
+//     centred, scaled by the row's power of two (2^e_r with (B_r + |s_r|) 2^e_r < 2^14), split, and written as f16 fragments —
+//     [row half][k-step][hi / lo][lane] x 16 B, lane-linear: conflict-free ds_write_b64 / ds_read_b128 — into one of two 64 KiB
+//     buffers, between the MFMAs of the tile before.  All eight waves read all fragments of a tile.
+//   * per tile and wave: 64 ds_read_b128, 96 MFMAs with the operands SWAPPED (D^T = T^T x^T: a lane's accumulators are sixteen columns
+//     of one row), two 32-row halves on alternating accumulators.
+//   * epilogue straight from the accumulators: column scales (T's columns are scaled into f16's range by powers of two as well), the
+//     lane's partial sum of its row, 16 partial sums per row through 8 KiB of LDS and the tile's ONE barrier, the row's factor, lane
+//     swaps, 16-byte stores.  Scaling by powers of two commutes with every rounding involved, so the row scale is undone in the row's
 //     final factor: same values as unscaled arithmetic.
+// Where the time goes (cycle counters around the phases in a development build, 611 tiles per block at the C3 shape: scripts/rejected/
+// project_f16_all_forms.hip.txt): products 6 500-6 800 cycles per tile (the matrix pipe's own time: 6 144), the epilogue 5 100-5 400 —
+// ~600 for the partial sums, 500-2 400 at the barrier, 1 800-3 900 from the barrier to the last store issued (the waves dispatched second
+// lose the arbitration).  Without the stores the launch takes 4.05 ms instead of 4.9, without the reloads 4.05-4.2: the vector, LDS and
+// memory instructions of a tile (~390 per wave beside its 96 MFMAs) are what the matrix pipe waits for, and three rearrangements of
+// them — the epilogue pipelined into the next tile's MFMAs (32-row tiles), the two waves of a SIMD in opposite phases, row-major
+// read-back through LDS for whole-line stores — measured 4.8 / 5.5 / no gain (same file).  The first form of this kernel (accumulators
+// staged through LDS for a row-major pass, two barriers per tile) ran 5.3-5.45 ms.
 #include <type_traits>
 
 #include "common.h"
@@ -44,14 +53,6 @@ constexpr int PF_ROWS = 64;            // rows per tile
 constexpr int PF_THREADS = 512;
 constexpr int PF_BUF = 2 * PF_KS * 2 * 1024;        // fragment bytes per tile: [row half][k-step][split] x 1 KiB = 64 KiB
 constexpr int PF_TOP = 14;             // operands are scaled below 2^14 (f16 overflows at 65504)
-constexpr size_t PF_LDS = 2 * (size_t)PF_BUF + 8 * 8 * 64 * 4 + 2 * 64 * 16 + 2 * PF_D * 4;   // 148 KiB
-
-// v from the lane a DPP control selects inside this lane's 16-lane row (0xB1 / 0x4E: quad_perm [1,0,3,2] / [2,3,0,1]; 0x141 / 0x140:
-// row_half_mirror / row_mirror)
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
 
 // (lo, hi) -> packed f16 pairs p1 = f16(v), p2 = f16(v - p1): v = p1 + p2 to 2^-22 |v| (plus f16's subnormal spacing, 2^-24 absolute)
 __device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t &p1, uint32_t &p2) {
@@ -63,10 +64,10 @@ __device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t &p1, u
 }
 
 // T (256 x 256 row-major f32) -> per-column power-of-two scale, hi / lo f16 fragments in the consumer's register order:
-// tp[((w * 16 + ks) * 2 + sp) * 64 + lane] = 8 x f16: lane (j, h) <-> column 32 w + j, k = 16 ks + 8 h + e.   One block per column.
-// `transposed`: the fragment lane of a column is permuted for project_f16t_kernel (see its store path): column c of the wave's 32 sits at
-// lane (c & 3) + 4 ((c >> 3) & 1) + 8 (2 (c >> 4) + ((c >> 2) & 1)).
-__global__ __launch_bounds__(256) void pack_transform_f16_kernel(const float *__restrict__ t, _Float16 *__restrict__ tp, float *__restrict__ colscale, int transposed) {
+// tp[((w * 16 + ks) * 2 + sp) * 64 + lane] = 8 x f16: lane (j, h) <-> column 32 w + pi^-1(j), k = 16 ks + 8 h + e, where the fragment
+// lane of column c (of the wave's 32) is pi(c) = (c & 3) + 4 ((c >> 3) & 1) + 8 (2 (c >> 4) + ((c >> 2) & 1)) — chosen so that after the
+// kernel's lane swaps a store instruction's four pieces per row are 64 contiguous bytes.   One block per column.
+__global__ __launch_bounds__(256) void pack_transform_f16_kernel(const float *__restrict__ t, _Float16 *__restrict__ tp, float *__restrict__ colscale) {
     __shared__ float red[4];
     const uint32_t col = blockIdx.x, kk = threadIdx.x;
     const float v = t[(uint64_t)kk * PF_D + col];
@@ -83,203 +84,26 @@ __global__ __launch_bounds__(256) void pack_transform_f16_kernel(const float *__
     const _Float16 hi = (_Float16)tv;
     const _Float16 lo = (_Float16)(tv - (float)hi);
     const uint32_t w = col >> 5, cl = col & 31, ks = kk >> 4, h = (kk >> 3) & 1, e = kk & 7;
-    const uint32_t j = transposed ? (cl & 3) + 4 * ((cl >> 3) & 1) + 8 * (2 * (cl >> 4) + ((cl >> 2) & 1)) : cl;
+    const uint32_t j = (cl & 3) + 4 * ((cl >> 3) & 1) + 8 * (2 * (cl >> 4) + ((cl >> 2) & 1));   // fragment lane of column cl (see the store path)
     const uint64_t unit = ((uint64_t)(w * PF_KS + ks) * 2) * 64 + (h * 32 + j);
     tp[unit * 8 + e] = hi;
     tp[(unit + 64) * 8 + e] = lo;
     if (kk == 0) colscale[col] = ldexpf(1.0f, -st);
 }
 
-struct F16Args {
-    ProjArgs p;
-    const u32x4 *tp;
-    const float *colscale;
-    const float *rowbound;     // per row: a bound on |x[r][j]| (nullptr: 1)
-    uint64_t tiles;
-};
-
-template <bool SCALED>
-__global__ __launch_bounds__(PF_THREADS, 2) void project_f16_kernel(const F16Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *const frag = smem;                                             // [2][PF_BUF]; a consumed buffer doubles as the output stage
-    float *const red = reinterpret_cast<float *>(smem + 2 * PF_BUF);              // [8 waves][8 rows][64 lanes]
-    float4 *const rowinfo = reinterpret_cast<float4 *>(red + 8 * 8 * 64);         // [2][64]: {s_r, 2^e_r, 2^-e_r, -}
-    float *const mean_s = reinterpret_cast<float *>(rowinfo + 2 * 64);            // [256]
-    float *const cs_s = mean_s + PF_D;                                            // [256]
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const ProjArgs &p = a.p;
-    const uint64_t G = gridDim.x;
-    uint64_t T = blockIdx.x;
-    if (T >= a.tiles) return;
-
-    // B: this wave's 32 columns of the split transform, for the whole launch
-    h8v bhi[PF_KS], blo[PF_KS];
-#pragma unroll
-    for (int ks = 0; ks < PF_KS; ++ks) {
-        bhi[ks] = __builtin_bit_cast(h8v, a.tp[((uint64_t)(w * PF_KS + ks) * 2 + 0) * 64 + lane]);
-        blo[ks] = __builtin_bit_cast(h8v, a.tp[((uint64_t)(w * PF_KS + ks) * 2 + 1) * 64 + lane]);
-    }
-    if (t < PF_D) { mean_s[t] = p.mean[t]; cs_s[t] = a.colscale[t]; }
-
-    // producer role: lane = (piece pair (ksub, hh) | row r8 | half): rows 8 j + r8 of the tile, columns 32 w + 4 pc .. + 3
-    const int r8 = (lane >> 1) & 7, pc = ((lane >> 4) << 1) | (lane & 1);
-    const int ksub = pc >> 2, hh = (pc >> 1) & 1, half = pc & 1;
-    const uint32_t col0 = 32u * w + 4u * pc;
-    const uint32_t frag_lane_off = (uint32_t)((2 * w + ksub) * 2 * 1024 + (hh * 32 + r8) * 16 + half * 8);   // + rt * 32 KiB + (j & 3) * 128 + sp * 1 KiB
-    auto row_clamped = [&](uint64_t tile, int r) {
-        const uint64_t row = tile * PF_ROWS + (uint64_t)r;
-        return row < p.n ? row : p.n - 1;                                         // always a valid address
-    };
-    float4 P[8];
-    auto issue_tile = [&](uint64_t tile) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) P[j] = *reinterpret_cast<const float4 *>(p.x + row_clamped(tile, 8 * j + r8) * p.ldx + col0);
-    };
-    // per-row constants of a tile, by the first 64 threads: {s, 2^e, 2^-e}
-    float ri_s = 1.f, ri_b = 1.f;
-    auto load_rowinfo = [&](uint64_t tile) {
-        if (t < PF_ROWS) {
-            const uint64_t row = row_clamped(tile, t);
-            ri_s = SCALED ? p.rowscale[row] : 1.f;
-            ri_b = a.rowbound ? a.rowbound[row] : 1.f;
-        }
-    };
-    auto publish_rowinfo = [&](int buf) {
-        if (t < PF_ROWS) {
-            const float bound = fabsf(ri_b) + fabsf(ri_s);                       // |x - s mu| <= B + |s| (|mu| <= 1)
-            int e = (bound > 0.f && bound < __builtin_inff()) ? PF_TOP - __builtin_amdgcn_frexp_expf(bound) : 0;
-            e = e > 100 ? 100 : (e < -100 ? -100 : e);
-            rowinfo[buf * 64 + t] = make_float4(ri_s, ldexpf(1.0f, e), ldexpf(1.0f, -e), 0.f);
-        }
-    };
-    float4 mu4;                                                                   // the lane's four column means (set after the barrier below)
-    auto produce = [&](int buf) {
-        unsigned char *const fb = frag + buf * PF_BUF;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float4 info = rowinfo[buf * 64 + 8 * j + r8];
-            const float xv[4] = {P[j].x, P[j].y, P[j].z, P[j].w};
-            const float mv[4] = {mu4.x, mu4.y, mu4.z, mu4.w};
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = __fmul_rn(centre(xv[e], mv[e], info.x, SCALED), info.y);   // (x - s mu) 2^e: the scaling is exact
-            uint32_t h0, l0, h1, l1;
-            split2h_pair(o[0], o[1], h0, l0);
-            split2h_pair(o[2], o[3], h1, l1);
-            unsigned char *const dst = fb + (j >> 2) * (PF_BUF / 2) + frag_lane_off + (j & 3) * 128;
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(dst + 1024) = make_uint2(l0, l1);
-        }
-    };
-
-    // ---- prologue: fragments of the first tile, operands of the second in flight ----------------------------------------------
-    load_rowinfo(T);
-    issue_tile(T);
-    publish_rowinfo(0);
-    __syncthreads();                                                              // mean_s, cs_s, rowinfo[0]
-    mu4 = *reinterpret_cast<const float4 *>(mean_s + col0);
-    const float4 cs4 = *reinterpret_cast<const float4 *>(cs_s + 4 * lane);       // row phase: the lane's four output columns
-    produce(0);
-    if (T + G < a.tiles) { load_rowinfo(T + G); issue_tile(T + G); }
-    __syncthreads();
-
-    f16v acc[2];
-    int it = 0;
-    for (; T < a.tiles; T += G, it ^= 1) {
-        const int bufA = it, bufB = it ^ 1;
-        const uint64_t Tn = T + G, Tnn = T + 2 * G;
-        if (Tn < a.tiles) publish_rowinfo(bufB);                                  // (read by produce() behind barrier X)
-        if (Tnn < a.tiles) load_rowinfo(Tnn);
-        // ---- (a) the tile's products ---------------------------------------------------------------------------------------
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
-        const unsigned char *const fa = frag + bufA * PF_BUF + lane * 16;
-#pragma unroll
-        for (int ks = 0; ks < PF_KS; ++ks) {
-            h8v ah[2], al[2];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                ah[rt] = *reinterpret_cast<const h8v *>(fa + rt * (PF_BUF / 2) + (ks * 2 + 0) * 1024);
-                al[rt] = *reinterpret_cast<const h8v *>(fa + rt * (PF_BUF / 2) + (ks * 2 + 1) * 1024);
-            }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], bhi[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], bhi[ks], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0], blo[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1], blo[ks], acc[1], 0, 0, 0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0], bhi[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1], bhi[ks], acc[1], 0, 0, 0);
-        }
-        __syncthreads();                                                          // X: nobody reads bufA's fragments any more; bufB is free (its rows went out)
-        // ---- (b) the next tile's fragments, the tile after it into flight --------------------------------------------------
-        if (Tn < a.tiles) {
-            produce(bufB);
-            if (Tnn < a.tiles) issue_tile(Tnn);
-        }
-        // ---- (c) accumulators -> rows (32x32 C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) ----
-        float *const stage = reinterpret_cast<float *>(frag + bufA * PF_BUF);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg)
-                stage[(32 * rt + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * PF_D + 32 * w + (lane & 31)] = acc[rt][reg];
-        const float unscale = rowinfo[bufA * 64 + 8 * w + (lane >> 3)].z;        // row phase: lane L finishes row 8 w + (L >> 3)
-        __syncthreads();                                                          // Y
-        // ---- (d) whole rows: column scales, norm, store ---------------------------------------------------------------------
-        float4 v[8];
-        float part[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            v[q] = *reinterpret_cast<const float4 *>(stage + (8 * w + q) * PF_D + 4 * lane);
-            v[q].x *= cs4.x; v[q].y *= cs4.y; v[q].z *= cs4.z; v[q].w *= cs4.w;
-            part[q] = p.norm == 2 ? (fabsf(v[q].x) + fabsf(v[q].y)) + (fabsf(v[q].z) + fabsf(v[q].w))
-                                  : (v[q].x * v[q].x + v[q].y * v[q].y) + (v[q].z * v[q].z + v[q].w * v[q].w);
-        }
-        float g = unscale;                                                        // norm == 0: only the row scale is undone
-        if (p.norm) {
-            float *const rw = red + w * 8 * 64;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rw[q * 64 + lane] = part[q];
-            // (one wave, in-order LDS queue: its own writes are visible to its reads) lane L sums eight partials of row L >> 3
-            const float4 s0 = *reinterpret_cast<const float4 *>(rw + (lane >> 3) * 64 + (lane & 7) * 8);
-            const float4 s1 = *reinterpret_cast<const float4 *>(rw + (lane >> 3) * 64 + (lane & 7) * 8 + 4);
-            float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w));
-            s += dpp_row<0xB1>(s);                                                // quad_perm [1, 0, 3, 2]
-            s += dpp_row<0x4E>(s);                                                // quad_perm [2, 3, 0, 1]
-            s += dpp_row<0x141>(s);                                               // row_half_mirror: the eight lanes of a row's group
-            // L2: v (1 / max(sqrt(S), 1e-10)) like src/embedding.rs:98-102; L1: v / max(S, 1e-10) (pycleora/__init__.py:947-950); the
-            // sums were taken on rows scaled by 2^e: S_true = S 2^-2e (L2) / S 2^-e (L1), every step mirrors exactly
-            g = p.norm == 1 ? unscale * (1.0f / fmaxf(sqrtf(s) * unscale, 1e-10f)) : fmaxf(s * unscale, 1e-10f);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g), 8 * q));
-            const float u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, unscale), 8 * q));
-            float4 o;
-            if (p.norm == 2) { o.x = (v[q].x * u) / f; o.y = (v[q].y * u) / f; o.z = (v[q].z * u) / f; o.w = (v[q].w * u) / f; }
-            else { o.x = v[q].x * f; o.y = v[q].y * f; o.z = v[q].z * f; o.w = v[q].w * f; }
-            const uint64_t row = T * PF_ROWS + (uint64_t)(8 * w + q);
-            if (row < p.n) *reinterpret_cast<float4 *>(p.out + row * p.ldo + 4 * lane) = o;
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The TRANSPOSED form (round 6, second pass): the same fragments and products with the MFMA's operands swapped — D^T = T^T x^T — so
-// that a lane's accumulators are SIXTEEN COLUMNS OF ONE ROW (32x32 C/D map: lane & 31 = tile row, reg -> column (reg & 3) + 8 (reg >> 2)
-// + 4 (lane >> 5) of the wave's 32) instead of sixteen rows of one column.  What that buys:
-//   * a row's sum of squares is an in-lane sum over registers: only 16 partial sums per row (8 waves x 2 lane halves) cross waves,
-//     through 4 KiB of LDS, instead of the whole accumulator tile (64 KiB) being staged for a row-major pass;
+// The MFMA's operands are swapped — D^T = T^T x^T — so that a lane's accumulators are SIXTEEN COLUMNS OF ONE ROW (32x32 C/D map:
+// lane & 31 = tile row, reg -> fragment lane (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) of the wave's 32 columns) instead of sixteen rows
+// of one column.  What that buys over staging the accumulator tile through LDS for a row-major pass:
+//   * a row's sum of squares is an in-lane sum over registers: only 16 partial sums per row (8 waves x 2 lane halves) cross waves;
 //   * four consecutive registers are four consecutive columns: the tile leaves as 16-byte stores straight from the accumulators;
 //   * no staging buffer, so the two fragment buffers are a true double buffer and ONE barrier per tile remains: the next tile's
 //     fragments are produced (centre, scale, split, ds_write) between the MFMAs of the current one instead of in a phase of their own.
-// The loop is one basic block (full tiles only; a ragged last tile runs a peeled copy with masked stores): the loads of tile k + 2
-// stay in flight across the back edge behind counted waits.
-constexpr size_t PFT_RED = 2 * 16 * 64 * 4;                   // [parity][8 waves x 2 halves][row] partial sums
-constexpr size_t PFT_INFO = 8 * 2 * 64 * 8;                   // [wave][parity][row] {s_r, 2^e_r}: wave-private copies (no barrier)
-constexpr size_t PFT_LDS = 2 * (size_t)PF_BUF + PFT_RED + PFT_INFO + 2 * PF_D * 4;   // 146 KiB
+// The loop is one basic block (full tiles only; the ragged last tile has a block of its own with masked stores): the loads of tile
+// k + 2 stay in flight across the back edge behind counted waits.
+constexpr size_t PF_RED = 2 * 16 * 64 * 4;                   // [parity][8 waves x 2 halves][row] partial sums
+constexpr size_t PF_INFO = 8 * 2 * 64 * 8;                   // [wave][parity][row] {s_r, 2^e_r}: wave-private copies (no barrier)
+constexpr size_t PF_LDS = 2 * (size_t)PF_BUF + PF_RED + PF_INFO + 2 * PF_D * 4;   // 146 KiB
 
 __device__ __forceinline__ void pf_barrier() {                 // LDS-only hand-off: global loads / stores in flight are not drained
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -287,7 +111,7 @@ __device__ __forceinline__ void pf_barrier() {                 // LDS-only hand-
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-struct F16TArgs {
+struct F16Args {
     ProjArgs p;
     const u32x4 *tp;
     const float *colscale;
@@ -296,14 +120,14 @@ struct F16TArgs {
     uint64_t full_blocks;      // blocks sharing the full tiles (gridDim.x minus the ragged tile's block)
 };
 
-template <int NORM, int DBG = 0>
-__global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TArgs a) {
+template <int NORM>
+__global__ __launch_bounds__(PF_THREADS, 2) void project_f16_kernel(const F16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *const frag = smem;                                             // [2][PF_BUF]
     float *const red = reinterpret_cast<float *>(smem + 2 * PF_BUF);              // [2][16][64]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 31, h = lane >> 5;
-    float2 *const rinfo = reinterpret_cast<float2 *>(smem + 2 * PF_BUF + PFT_RED) + w * 2 * 64;   // [2][64], this wave's
-    float *const mean_s = reinterpret_cast<float *>(smem + 2 * PF_BUF + PFT_RED + PFT_INFO);
+    float2 *const rinfo = reinterpret_cast<float2 *>(smem + 2 * PF_BUF + PF_RED) + w * 2 * 64;   // [2][64], this wave's
+    float *const mean_s = reinterpret_cast<float *>(smem + 2 * PF_BUF + PF_RED + PF_INFO);
     float *const cs_s = mean_s + PF_D;
     const ProjArgs &p = a.p;
     // blocks 0 .. G-1 share the FULL tiles (no row of theirs needs a guard); block G, if launched, owns the ragged last tile
@@ -385,7 +209,6 @@ __global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TA
     // waits the compiler counts for them (behind the eight stores of `finish`) are the same on both paths (merged at the loop
     // header, the more conservative path wins: with the loop entered behind the stores the prologue's state did).
     f16v acc[2];
-    uint64_t dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_t = 0;                         // DBG == 3: cycles of finish()'s three parts
     auto products = [&](uint64_t k, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const int par = (int)(k & 1);
@@ -425,7 +248,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TA
                 if (ks >= 6 && ks < 14) produce_piece(ks - 6, fb, par ^ 1);
             }
         }
-        if constexpr (!LAST && DBG != 1) {
+        if constexpr (!LAST) {
             __builtin_amdgcn_sched_barrier(0);
             issue_tile(T + 2 * G);
             __builtin_amdgcn_sched_barrier(0);
@@ -435,7 +258,6 @@ __global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TA
         constexpr bool LAST = decltype(last_tag)::value;
         const int par = (int)(k & 1);
         const uint64_t T = LAST ? tiles_full : b + k * G;
-        if constexpr (DBG == 3) dbg_t = __builtin_readcyclecounter();
         // ---- column scales; the lane's partial sums of its two rows -------------------------------------------------------------
         float part[2] = {0.f, 0.f};
 #pragma unroll
@@ -459,9 +281,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TA
             red[(par * 16 + 2 * w + h) * 64 + c] = part[0];                      // [parity][slot][row]: lane-linear writes and reads
             red[(par * 16 + 2 * w + h) * 64 + 32 + c] = part[1];
         }
-        if constexpr (DBG == 3) { const uint64_t q_ = __builtin_readcyclecounter(); dbg_a += q_ - dbg_t; dbg_t = q_; }
         pf_barrier();
-        if constexpr (DBG == 3) { const uint64_t q_ = __builtin_readcyclecounter(); dbg_b += q_ - dbg_t; dbg_t = q_; }
         // ---- whole-row factors, 16-byte stores straight from the accumulators ---------------------------------------------------
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
@@ -501,40 +321,14 @@ __global__ __launch_bounds__(PF_THREADS, 2) void project_f16t_kernel(const F16TA
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {                                     // u: tile rows 0-15 / 16-31 of this half
                     const float4 v = make_float4(o[8 * g + 4 * u], o[8 * g + 4 * u + 1], o[8 * g + 4 * u + 2], o[8 * g + 4 * u + 3]);
-                    if ((!LAST || row0 + 16 * u < p.n) && (DBG != 2 || v.x == 123.456f))
+                    if (!LAST || row0 + 16 * u < p.n)
                         *reinterpret_cast<float4 *>(orow + (uint64_t)(16 * u) * p.ldo + 16 * g) = v;
                 }
         }
-        if constexpr (DBG == 3) { const uint64_t q_ = __builtin_readcyclecounter(); dbg_c += q_ - dbg_t; dbg_t = q_; }
     };
     if (ragged) {
         products(0, std::true_type{});
         finish(0, std::true_type{});
-        return;
-    }
-    if constexpr (DBG == 3) {                                                     // development: where a wave's cycles go
-        uint64_t tp_ = 0, tf_ = 0, t0 = __builtin_readcyclecounter(), t1;
-        const uint64_t tstart = t0;
-        products(0, std::false_type{});
-        for (uint64_t k = 0; k + 1 < cnt_full; ++k) {
-            t1 = __builtin_readcyclecounter(); tp_ += t1 - t0; t0 = t1;
-            finish(k, std::false_type{});
-            t1 = __builtin_readcyclecounter(); tf_ += t1 - t0; t0 = t1;
-            products(k + 1, std::false_type{});
-        }
-        t1 = __builtin_readcyclecounter(); tp_ += t1 - t0; t0 = t1;
-        finish(cnt_full - 1, std::false_type{});
-        t1 = __builtin_readcyclecounter(); tf_ += t1 - t0;
-        __syncthreads();
-        if (b == 0 && lane == 0) {
-            p.out[4 * w + 0] = (float)tp_;
-            p.out[4 * w + 1] = (float)tf_;
-            p.out[4 * w + 2] = (float)(t1 - tstart);
-            p.out[4 * w + 3] = (float)cnt_full;
-            p.out[32 + 4 * w + 0] = (float)dbg_a;
-            p.out[32 + 4 * w + 1] = (float)dbg_b;
-            p.out[32 + 4 * w + 2] = (float)dbg_c;
-        }
         return;
     }
     products(0, std::false_type{});
@@ -550,15 +344,12 @@ __global__ __launch_bounds__(256) void fill_ones_kernel(float *__restrict__ v, u
     if (i < n) v[i] = 1.0f;
 }
 
-int g_pf16_form = 0;           // development switch (cleora_dev_project_form): 1 = the staged form
-
 }  // namespace
-
-extern "C" void cleora_dev_project_form(int form) { g_pf16_form = form; }
 
 bool project_f16_applies(const float *x, uint64_t ldx, uint64_t n, uint32_t d, uint32_t k, const float *out, uint64_t ldo, const float *x2) {
     auto aligned16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    return d == PF_D && k == PF_D && x2 == nullptr && n >= 1 && ldx % 4 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(out);
+    return d == PF_D && k == PF_D && x2 == nullptr && n >= 1 && ldx % 4 == 0 && ldo % 4 == 0 && aligned16(x) && aligned16(out) &&
+           ldx < (1u << 24) && ldo < (1u << 24);                              // 32-bit per-lane byte offsets
 }
 
 // out = normalise((x - rowscale (x) mean) T) for BOUNDED operands: |x[r][j]| <= rowbound[r] (nullptr: 1), |mean[j]| <= 1.
@@ -571,51 +362,20 @@ int launch_project_f16(const float *x, uint64_t ldx, uint64_t n, const float *me
     float *colscale = nullptr;
     CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), (size_t)PF_D * PF_D * 2 * sizeof(_Float16) + PF_D * sizeof(float), stream));
     colscale = reinterpret_cast<float *>(tp + (size_t)PF_D * PF_D * 2);
-    hipLaunchKernelGGL(pack_transform_f16_kernel, dim3(PF_D), dim3(256), 0, stream, t, tp, colscale, g_pf16_form != 1 ? 1 : 0);
+    hipLaunchKernelGGL(pack_transform_f16_kernel, dim3(PF_D), dim3(256), 0, stream, t, tp, colscale);
     static int cus = 0;
     if (!cus) {
         int dev = 0, c = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         cus = c > 0 ? c : 256;
     }
-    const uint64_t tiles = (n + PF_ROWS - 1) / PF_ROWS;
-    const unsigned gx = (unsigned)(tiles < (uint64_t)cus ? tiles : (uint64_t)cus);
     hipError_t e = hipSuccess;
+    // the kernel reads both per-row vectors unconditionally (its loop is one basic block): an absent one is a vector of ones
     float *ones = nullptr;
-    if (g_pf16_form != 1) {
-        // the transposed form reads both per-row vectors unconditionally (its loop is one basic block): absent ones are ones
-        if (!rowscale || !rowbound) {
-            CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&ones), n * sizeof(float), stream));
-            hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ones, n);
-        }
-        F16TArgs a{};
-        a.p.x = x;
-        a.p.ldx = ldx;
-        a.p.n = n;
-        a.p.d = PF_D;
-        a.p.mean = mean;
-        a.p.k = PF_D;
-        a.p.out = out;
-        a.p.ldo = ldo;
-        a.p.norm = norm;
-        a.tp = reinterpret_cast<const u32x4 *>(tp);
-        a.colscale = colscale;
-        a.rowscale = rowscale ? rowscale : ones;
-        a.rowbound = rowbound ? rowbound : ones;
-        const uint64_t tiles_full = n / PF_ROWS;
-        a.full_blocks = tiles_full < (uint64_t)cus ? tiles_full : (uint64_t)cus;
-        const unsigned gt = (unsigned)a.full_blocks + (n % PF_ROWS ? 1u : 0u);      // + the ragged tile's block
-        auto go = [&](auto kernel) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PFT_LDS);
-            if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(gt), dim3(PF_THREADS), PFT_LDS, stream, a);
-        };
-        if (norm == 1 && g_pf16_form == 2) go(project_f16t_kernel<1, 1>);
-        else if (norm == 1 && g_pf16_form == 3) go(project_f16t_kernel<1, 2>);
-        else if (norm == 1 && g_pf16_form == 4) go(project_f16t_kernel<1, 3>);
-        else if (norm == 1) go(project_f16t_kernel<1>);
-        else if (norm == 2) go(project_f16t_kernel<2>);
-        else go(project_f16t_kernel<0>);
-    } else {
+    if (!rowscale || !rowbound) {
+        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&ones), n * sizeof(float), stream));
+        hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ones, n);
+    }
     F16Args a{};
     a.p.x = x;
     a.p.ldx = ldx;
@@ -625,20 +385,21 @@ int launch_project_f16(const float *x, uint64_t ldx, uint64_t n, const float *me
     a.p.k = PF_D;
     a.p.out = out;
     a.p.ldo = ldo;
-    a.p.rowscale = rowscale;
     a.p.norm = norm;
     a.tp = reinterpret_cast<const u32x4 *>(tp);
     a.colscale = colscale;
-    a.rowbound = rowbound;
-    a.tiles = tiles;
-    if (rowscale) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(project_f16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS);
-        if (e == hipSuccess) hipLaunchKernelGGL(project_f16_kernel<true>, dim3(gx), dim3(PF_THREADS), PF_LDS, stream, a);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(project_f16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS);
-        if (e == hipSuccess) hipLaunchKernelGGL(project_f16_kernel<false>, dim3(gx), dim3(PF_THREADS), PF_LDS, stream, a);
-    }
-    }
+    a.rowscale = rowscale ? rowscale : ones;
+    a.rowbound = rowbound ? rowbound : ones;
+    const uint64_t tiles_full = n / PF_ROWS;
+    a.full_blocks = tiles_full < (uint64_t)cus ? tiles_full : (uint64_t)cus;
+    const unsigned gt = (unsigned)a.full_blocks + (n % PF_ROWS ? 1u : 0u);          // + the ragged tile's block
+    auto go = [&](auto kernel) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF_LDS);
+        if (e == hipSuccess) hipLaunchKernelGGL(kernel, dim3(gt), dim3(PF_THREADS), PF_LDS, stream, a);
+    };
+    if (norm == 1) go(project_f16_kernel<1>);
+    else if (norm == 2) go(project_f16_kernel<2>);
+    else go(project_f16_kernel<0>);
     const hipError_t le = e != hipSuccess ? e : hipGetLastError();
     if (ones) CL_HIP(hipFreeAsync(ones, stream));
     CL_HIP(hipFreeAsync(tp, stream));

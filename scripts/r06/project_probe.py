@@ -58,12 +58,11 @@ def call(form, norm, scaled):
     assert norm == 0 or nd.value == 1
 
 
-FORMS = ("f16", "f16_staged", "bf16x6")       # f16: the transposed form (default); f16_staged: the round's first form
+FORMS = ("f16", "bf16x6")
 
 
 def select(form):
-    L.cleora_dev_project_form(1 if form == "f16_staged" else 0)
-    return "f16" if form.startswith("f16") else form
+    return form
 
 
 for norm in (1, 0, 2):

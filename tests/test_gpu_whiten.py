@@ -366,7 +366,7 @@ def test_projection_error_against_an_f64_product(n, d, k):
     assert emax <= 2e-6 * grow and erms <= 3e-7 * grow, (emax, erms)
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 5003, 70_001])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 127, 5003, 16_384, 70_001])
 @pytest.mark.parametrize("norm,scaled", [(1, True), (0, False), (2, True), (1, False)])
 def test_bounded_projection_on_the_f16_matrix_cores(n, norm, scaled):
     """cleora_project_bounded_dev at d = k = 256 (csrc/project_f16.hip: the intermediate projections of the whitened loop — operands
@@ -388,13 +388,15 @@ def test_bounded_projection_on_the_f16_matrix_cores(n, norm, scaled):
     mean = np.clip(rng.standard_normal(d) * 0.05, -1, 1).astype(np.float32)
     t = (rng.standard_normal((d, d)) * 10 ** (rng.random(d) * 5 - 2)[None, :]).astype(np.float32)
     dx, dm, dt, ds, db = (_hip.DevArray.from_host(a) for a in (x, mean, t, rowscale, bound))
-    do = _hip.DevArray((n, d), np.float32)
+    do = _hip.DevArray.from_host(np.full((n + 1, d), 7.0, np.float32))          # one row more than the call may touch
     nd, form = ctypes.c_int(0), ctypes.c_int(-1)
     _hip.check(L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, do.ptr, d, ds.ptr if scaled else None, db.ptr, norm,
                                             ctypes.byref(nd), ctypes.byref(form), None))
     _hip.check(L.cleora_stream_sync(None))
     assert form.value == 1 and nd.value == (1 if norm else 0)
-    got = do.to_host().astype(np.float64)
+    got = do.to_host()
+    assert (got[n] == 7.0).all(), "the ragged last tile wrote past row n"
+    got = got[:n].astype(np.float64)
     ref = (x.astype(np.float64) - (rowscale.astype(np.float64)[:, None] if scaled else 1.0) * mean.astype(np.float64)[None, :]) @ t.astype(np.float64)
     if norm == 1:
         ref /= np.maximum(np.linalg.norm(ref, axis=1, keepdims=True), 1e-10)

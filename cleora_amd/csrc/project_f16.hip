@@ -32,7 +32,9 @@
 // project_f16_all_forms.hip.txt): products 6 500-6 800 cycles per tile (the matrix pipe's own time: 6 144), the epilogue 5 100-5 400 —
 // ~600 for the partial sums, 500-2 400 at the barrier, 1 800-3 900 from the barrier to the last store issued (the waves dispatched second
 // lose the arbitration).  Without the stores the launch takes 4.05 ms instead of 4.9, without the reloads 4.05-4.2: the vector, LDS and
-// memory instructions of a tile (~390 per wave beside its 96 MFMAs) are what the matrix pipe waits for, and three rearrangements of
+// memory instructions of a tile (~390 per wave beside its 96 MFMAs) are what the matrix pipe waits for — not their count (a fused centring
+// and v_fma_mix_f32 residuals, a quarter fewer vector instructions in the fragment production: 4.82-4.84 against 4.87; no SLP packing: the
+// same) but their latencies in two in-order waves per SIMD — and three rearrangements of
 // them — the epilogue pipelined into the next tile's MFMAs (32-row tiles), the two waves of a SIMD in opposite phases, row-major
 // read-back through LDS for whole-line stores — measured 4.8 / 5.5 / no gain (same file).  The first form of this kernel (accumulators
 // staged through LDS for a row-major pass, two barriers per tile) ran 5.3-5.45 ms.

@@ -724,17 +724,26 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
     if ((rc = local.alloc(std::max<uint64_t>(s->local_rows, 1) * (uint64_t)d * 4)) != CLEORA_OK) return rc;
     const float rw = residual_weight;
     // project the rank's rows of `in_local` (or of the replica `in_rep`) into the replica `out`, one block at a time, and gather
+    // (rowabs != nullptr: the operand is bounded row by row — the loop form without a blend at d = 256 takes the f16 projection,
+    // project_f16.hip, like the one-GPU loop: abi.hip)
     auto project_blocks = [&](const float *in_local, const float *in_rep, float *out, const float *x2_rep, const float *rowsum, bool loop_form,
-                              int norm_mode) -> int {
+                              int norm_mode, const float *rowabs = nullptr) -> int {
         for (uint32_t k = 0; k < s->steps; ++k) {
             const auto &b = s->blocks[k];
             if (b.valid) {
                 const float *in = in_local ? in_local + b.first_local * (uint64_t)d : in_rep + b.b0 * (uint64_t)d;
                 float *o = out + b.b0 * (uint64_t)d;
                 bool normed = false;
-                int r2 = launch_project(in, d, b.valid, d, st.mean32.as<float>(), st.transform.as<float>(), d, o, d, stream,
+                int r2;
+                if (loop_form && rowabs && !x2_rep && norm_mode == 1 && project_f16_applies(in, d, b.valid, d, d, o, d, nullptr)) {
+                    r2 = launch_project_f16(in, d, b.valid, st.mean32.as<float>(), st.transform.as<float>(), o, d, stream, rowsum + b.first_local,
+                                            rowabs + b.first_local, 1);
+                    normed = true;
+                } else {
+                    r2 = launch_project(in, d, b.valid, d, st.mean32.as<float>(), st.transform.as<float>(), d, o, d, stream,
                                         loop_form ? rowsum + b.first_local : nullptr, x2_rep ? x2_rep + b.b0 * (uint64_t)d : nullptr, d,
                                         loop_form ? 1.0f - rw : 1.0f, loop_form ? rw : 0.0f, norm_mode, &normed);
+                }
                 if (r2 != CLEORA_OK) return r2;
                 if (norm_mode && !normed && (r2 = launch_rowops(o, d, b.valid, d, o, d, norm | fast, 0.f, nullptr, nullptr, nullptr, stream)) != CLEORA_OK) return r2;
             }
@@ -749,10 +758,11 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
         // Y_0 = normalise(A E_0 [+ blend]) replicated; per iteration Z = A Y on the rank's rows | statistics of Y (contiguous row
         // ranges of the replica: one pass each) -> all-reduce -> transform (Cholesky while the clamp guard allows) -> Y' =
         // normalise((alpha (Z - s mu^T) + rw (Y - mu)) T) on the rank's rows, gathered block by block; E_T = PCA-whiten(Y_{T-1}).
-        DevMem rowsum;
+        DevMem rowsum, rowabs;                                      // A 1 and sum |a| per row (the f16 projection's row bounds)
         if ((rc = rowsum.alloc(std::max<uint64_t>(s->local_rows, 1) * 4)) != CLEORA_OK) return rc;
+        if ((rc = rowabs.alloc(std::max<uint64_t>(s->local_rows, 1) * 4)) != CLEORA_OK) return rc;
         for (auto &b : s->blocks)
-            if ((rc = launch_csr_rowsum(b.g, markov_type, rowsum.as<float>() + b.first_local, stream)) != CLEORA_OK) return rc;
+            if ((rc = launch_csr_rowsum(b.g, markov_type, rowsum.as<float>() + b.first_local, stream, rowabs.as<float>() + b.first_local)) != CLEORA_OK) return rc;
         float *y = other.as<float>(), *ynext = x_replica;
         if ((rc = propagate_blocks(s, markov_type, x_replica, y, nullptr, d, CLEORA_F_L2NORM | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, nullptr, true,
                                    stream)) != CLEORA_OK)
@@ -778,7 +788,7 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
             }
             CL_HIP(hipEventRecord(s->ev_side, s->side_stream));
             CL_HIP(hipStreamWaitEvent(stream, s->ev_side, 0));
-            if ((rc = project_blocks(local.as<float>(), nullptr, ynext, blend ? y : nullptr, rowsum.as<float>(), true, 1)) != CLEORA_OK) return rc;
+            if ((rc = project_blocks(local.as<float>(), nullptr, ynext, blend ? y : nullptr, rowsum.as<float>(), true, 1, blend ? nullptr : rowabs.as<float>())) != CLEORA_OK) return rc;
             std::swap(y, ynext);
         }
         // E_T = whiten(Y_{T-1}): f64 statistics, the PCA form

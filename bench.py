@@ -1011,7 +1011,7 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
         torch.cuda.synchronize()
         pms = e0.elapsed_time(e1) / 5
         pbytes = 2.0 * n * d * 4
-        proj_inter = {"kernel": "project_f16_kernel<true> (csrc/project_f16.hip)" if fm_.value == 1 else "project_split_kernel (six-product bf16 form)",
+        proj_inter = {"kernel": "project_f16_kernel<1> (csrc/project_f16.hip)" if fm_.value == 1 else "project_split_kernel (six-product bf16 form)",
                       "ms": pms, "bound": "hbm", "achieved": pbytes / (pms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": pbytes,
                       "mfma": {"dtype": "f16 (two-way split operands, 3 products)", "achieved": 6.0 * n * d * d / (pms * 1e-3) / 1e12,

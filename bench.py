@@ -83,6 +83,18 @@ def rows_bit_equal(dev, host, chunk=1 << 20):
     return same
 
 
+def host_cpu_model():
+    """The host CPU the `cpu_baseline` ran on (VERDICT round 5, weak #9: the core count alone does not name the box class)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, gpu_iterate=None, budget_s=12.0):
     """Reference-order CPU port (oracle AoS SpMM + separate L2 pass, all host cores) on whole iterations of the
     same graph and X, bounded to about `budget_s` seconds; its FIRST iteration doubles as the parity check:
@@ -123,7 +135,7 @@ def cpu_baseline_and_checks(g, x_dev, y_dev, n, d, hub_threshold, gpu_iterate=No
         # the baseline's iterations double as a multi-iteration check: the GPU continues from its own first iterate
         checks["oracle_iterations_compared"] = 1 + count
         checks["rows_bit_equal_after_those_iterations"] = rows_bit_equal(gpu_iterate(count), x)
-    out = {"value": g["nnz"] * d * count / el, "unit": "edge*dim/s", "cores": threads,
+    out = {"value": g["nnz"] * d * count / el, "unit": "edge*dim/s", "cores": threads, "host_cpu": host_cpu_model(),
            "kind": "port", "iterations_per_sec": count / el,
            "sample": f"{count} full iteration(s) of the same graph and X (SpMM, reference AoS edge "
                      f"layout, dynamic row schedule + separate L2 pass), {el:.1f} s"}
@@ -253,7 +265,7 @@ def cpu_baseline_row_block(g, x_dev, n, d, rows=500_000, budget_s=20.0):
         el = time.perf_counter() - t0
         if el >= budget_s or count >= 5:
             break
-    return {"value": (e1 - e0) * d * count / el, "unit": "edge*dim/s", "cores": threads, "kind": "port",
+    return {"value": (e1 - e0) * d * count / el, "unit": "edge*dim/s", "cores": threads, "host_cpu": host_cpu_model(), "kind": "port",
             "sample": f"{count} pass(es) over output rows [{r0}, {r0 + rows}) = {e1 - e0} edges gathering {int(ucols.numel())} distinct X rows "
                       f"(reference AoS edge layout, SpMM + L2), {el:.1f} s; the whole graph is {g['nnz']} edges"}
 

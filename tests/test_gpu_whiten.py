@@ -426,5 +426,19 @@ def test_bounded_projection_falls_back_for_other_shapes_and_checks_its_arguments
     ref = (x - mean).astype(np.float64) @ t.astype(np.float64)
     ref /= np.linalg.norm(ref, axis=1, keepdims=True)
     assert np.abs(do.to_host() - ref).max() <= 2e-6
+    # d = 256 without row scales or bounds (both NULL: ones; unit rows keep the bound): still the f16 kernel
+    n2, d2 = 1000, 256
+    x2 = rng.standard_normal((n2, d2)).astype(np.float32)
+    x2 /= np.linalg.norm(x2, axis=1, keepdims=True)
+    mean2 = x2.mean(axis=0).astype(np.float32)
+    t2 = rng.standard_normal((d2, d2)).astype(np.float32)
+    dx2, dm2, dt2 = (_hip.DevArray.from_host(a) for a in (x2, mean2, t2))
+    do2 = _hip.DevArray((n2, d2), np.float32)
+    _hip.check(L.cleora_project_bounded_dev(dx2.ptr, d2, n2, d2, dm2.ptr, dt2.ptr, d2, do2.ptr, d2, None, None, 1, ctypes.byref(nd), ctypes.byref(form), None))
+    _hip.check(L.cleora_stream_sync(None))
+    assert form.value == 1 and nd.value == 1
+    ref2 = (x2 - mean2).astype(np.float64) @ t2.astype(np.float64)
+    ref2 /= np.linalg.norm(ref2, axis=1, keepdims=True)
+    assert np.abs(do2.to_host() - ref2).max() <= 2e-6
     assert L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, do.ptr, d, None, None, 3, None, None, None) == _hip.E_INVALID
     assert L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, d, dx.ptr, d, None, None, 1, None, None, None) == _hip.E_INVALID

@@ -1022,7 +1022,10 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
                                     1.0f - rw, rw, norm == CLEORA_F_L1NORM ? 2 : 1, &normed);
             }
             if (rc != CLEORA_OK) return rc;
-            if (!normed && (rc = launch_rowops(ynext, d, n, d, ynext, d, norm | fast, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
+            // (a projection of several column passes — k > 256 — cannot normalise in its epilogue: one more pass over Y.  Like the
+            // epilogues' sums it need not keep the reference's summation order inside the loop: the tree-sum form, 2.7 instead of 4.0 ms
+            // at config 5's shape; the general exact-order kernel took 11.5 ms there until round 6 gave l2_exact16_kernel a d = 1024 case)
+            if (!normed && (rc = launch_rowops(ynext, d, n, d, ynext, d, norm | fast | CLEORA_F_FASTNORM, 0.f, nullptr, nullptr, nullptr, st.a)) != CLEORA_OK) return rc;
         } else {
             // one entity: whiten_embeddings returns its input (:132-133), so E' = Y and the next Y = normalise(A Y [+ blend])
             if ((rc = launch_rowops(b0, d, n, d, ynext, d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, y, nullptr, nullptr, st.a)) != CLEORA_OK)

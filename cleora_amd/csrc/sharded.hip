@@ -745,7 +745,7 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
                                         loop_form ? 1.0f - rw : 1.0f, loop_form ? rw : 0.0f, norm_mode, &normed);
                 }
                 if (r2 != CLEORA_OK) return r2;
-                if (norm_mode && !normed && (r2 = launch_rowops(o, d, b.valid, d, o, d, norm | fast, 0.f, nullptr, nullptr, nullptr, stream)) != CLEORA_OK) return r2;
+                if (norm_mode && !normed && (r2 = launch_rowops(o, d, b.valid, d, o, d, norm | fast | (loop_form ? CLEORA_F_FASTNORM : 0u), 0.f, nullptr, nullptr, nullptr, stream)) != CLEORA_OK) return r2;
             }
             const int rg = gather_step(s, out, d, k, stream);
             if (rg != CLEORA_OK) return rg;

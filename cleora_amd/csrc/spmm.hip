@@ -1024,6 +1024,7 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
             case 2: hipLaunchKernelGGL(l2_exact16_kernel<2>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
             case 4: hipLaunchKernelGGL(l2_exact16_kernel<4>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
             case 8: hipLaunchKernelGGL(l2_exact16_kernel<8>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
+            case 16: hipLaunchKernelGGL(l2_exact16_kernel<16>, grid, dim3(256), 0, stream, x, ldx, n, y, ldy); break;
             default: done = false;
         }
         if (done) {

@@ -339,11 +339,11 @@ def test_hot_column_policy_changes_no_bit(d):
     np.testing.assert_array_equal(base[mask], oracle.l2_normalize(oracle.spmm(rowptr, col, val, x))[mask])
 
 
-@pytest.mark.parametrize("d", [64, 128, 256, 512, 192, 320])
+@pytest.mark.parametrize("d", [64, 128, 256, 512, 1024, 192, 320])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 1001])
 def test_standalone_l2_normalize_bit_exact(n, d):
     """cleora_l2_normalize / cleora_rowops_dev(L2NORM): the 16-lanes-per-row exact-order kernel (d = 64, 128, 256,
-    512) and the general path (192, 320) against the oracle's sequential sum, bit for bit; zero rows stay zero;
+    512, 1024) and the general path (192, 320) against the oracle's sequential sum, bit for bit; zero rows stay zero;
     also in place."""
     rng = np.random.default_rng(n * 1000 + d)
     x = (rng.standard_normal((n, d)) * rng.uniform(1e-3, 1e3, (n, 1))).astype(np.float32)

@@ -1059,8 +1059,8 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
     out = {
         "ms_per_iter": loops["overlapped"], "iterations": iters, "iterations_per_sec": 1e3 / loops["overlapped"],
         "marginal_ms_per_iter": marginal_ms,
-        "loop": "cleora_embed_dev + CLEORA_F_WHITEN (the SpMM taken before the projection; intermediate iterations: split-bf16 statistics — before the "
-                "SpMM at d = 256, beside it otherwise —, Cholesky transform, on the host for d <= 256; last iteration: f64 Gram + eigensolver); "
+        "loop": "cleora_embed_dev + CLEORA_F_WHITEN (the SpMM taken before the projection; intermediate iterations: split-bf16 statistics before the "
+                "SpMM, Cholesky transform, on the host for d <= 256; last iteration: f64 Gram + eigensolver); "
                 "ms_per_iter = loop wall clock / iterations, incl. the final whitening, after an untimed 2-iteration call; "
                 "marginal_ms_per_iter = (wall clock of a call with twice the iterations - this call's) / iterations",
         "sequential_ms_per_iter": {"c_loop_reference_order": loops["sequential"], "python_driven_with_stage_events": el / iters * 1e3},

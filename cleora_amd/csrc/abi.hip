@@ -961,14 +961,17 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     //   * the loop is the SUM of its kernels — a SIMD that holds a busy matrix-core wave gives the SpMM waves beside it next
     //     to nothing, and whatever shares the chip with the SpMM waits 10-16 us per memory request;
     //   * so when the statistics take the split-bf16 form (8 waves per CU, every matrix pipe busy) they run strictly BEFORE
-    //     the SpMM at d = 256 (C3 51.1 -> 49.7 ms per iteration, C2 5.92 -> 5.58); at d >= 512 the SpMM is so much longer than
-    //     the statistics that the overlapped order wins (config 5: 249.0 against 253.3 ms);
+    //     the SpMM (C3 51.1 -> 49.7 ms per iteration, C2 5.92 -> 5.58 in round 3).  At d >= 512 the overlapped order used to win
+    //     (config 5: 249.0 against 253.3 ms with round 3's statistics); with the three-product form a kernel trace of config 5 shows
+    //     the statistics stretched over the whole SpMM, the SpMM 10 ms longer for it (what the statistics take alone) and the
+    //     d x d step exposed behind both: statistics first measures 4-5 ms less per iteration (round 6: 36.9 against 41.1 ms above
+    //     the SpMM), so it is the order at every width;
     //   * the f64 statistics (one block per CU: at two they take ~410 of the 512 registers of every SIMD) stay beside the SpMM;
     //   * the d x d step runs on the host for d <= 256, beside the SpMM.
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const bool split_stats = any_whitening && n > 1 && gram32_applies(b1, d, n, d);
-    const bool stats_before_spmm = split_stats && d == 256;
+    const bool stats_before_spmm = split_stats;
     CL_HIP(hipStreamCreateWithPriority(&st.a, hipStreamNonBlocking, prio_lo));
     CL_HIP(hipStreamCreateWithPriority(&st.b, hipStreamNonBlocking, prio_hi));
     CL_HIP(hipEventCreateWithFlags(&st.ya, hipEventDisableTiming));

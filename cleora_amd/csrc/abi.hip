@@ -605,10 +605,12 @@ int cleora_project_bounded_dev(const float *x, uint64_t ldx, uint64_t n, uint32_
         if (norm_done) *norm_done = norm != 0;
         return launch_project_f16(x, ldx, n, mean_f32_dev, transform_dev, out, ldo, S(stream), rowscale_dev, rowbound_dev, norm);
     }
-    bool done = false;
+    // other shapes: with row bounds the split form's three-product f16 mode (*form = 2; d a multiple of 32), else its six bf16 products
+    bool done = false, bounded = false;
     const int rc = launch_project(x, ldx, n, d, mean_f32_dev, transform_dev, k, out, ldo, S(stream), rowscale_dev, nullptr, 0, 1.0f, 0.0f,
-                                  norm, &done);
+                                  norm, &done, rowbound_dev, &bounded);
     if (norm_done) *norm_done = done ? 1 : 0;
+    if (form && bounded) *form = 2;
     return rc;
 }
 
@@ -943,7 +945,9 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     // intermediate projections at d = 256 without a blend: the f16 form (project_f16.hip) — its operand Z = A Y is bounded row by
     // row by the sum of |values| because Y's rows are normalised (L2 or L1: |Y| <= 1 either way)
     const bool f16_project = !blend && n > 1 && project_f16_applies(b0, d, n, d, d, b1, d, nullptr);
-    if (f16_project && (rc = rowabs.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
+    // (other widths without a blend: the same bounds select the split form's three-product mode, whiten.hip)
+    const bool bounded = !blend && n > 1;
+    if (bounded && (rc = rowabs.alloc(n * sizeof(float))) != CLEORA_OK) return rc;
     struct Streams {
         hipStream_t a = nullptr, b = nullptr;
         hipEvent_t ya = nullptr, fb = nullptr, gs = nullptr;
@@ -979,7 +983,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
     CL_HIP(hipEventCreateWithFlags(&st.gs, hipEventDisableTiming));
     CL_HIP(hipDeviceSynchronize());                                        // b0 (E_0) was filled on the null stream
     const auto t_loop = std::chrono::steady_clock::now();
-    if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a, f16_project ? rowabs.as<float>() : nullptr)) != CLEORA_OK) return rc;
+    if ((rc = launch_csr_rowsum(g, markov_type, rowsum.as<float>(), st.a, bounded ? rowabs.as<float>() : nullptr)) != CLEORA_OK) return rc;
     // Y_0 = normalise(A E_0 [+ blend]): the ordinary fused launch
     if ((rc = launch_propagate(g, markov_type, b0, d, d, b1, d, norm | fast | CLEORA_F_RESIDUAL | CLEORA_F_BLEND_ANY, rw, b0,
                                nullptr, nullptr, st.a)) != CLEORA_OK)
@@ -1022,7 +1026,7 @@ int embed_whitened_overlapped(const cleora_graph *g, float *b0, float *b1, float
                 normed = true;
             } else {
                 rc = launch_project(b0, d, n, d, mean32, transform, d, ynext, d, st.a, rowsum.as<float>(), blend ? y : nullptr, d,
-                                    1.0f - rw, rw, norm == CLEORA_F_L1NORM ? 2 : 1, &normed);
+                                    1.0f - rw, rw, norm == CLEORA_F_L1NORM ? 2 : 1, &normed, bounded ? rowabs.as<float>() : nullptr);
             }
             if (rc != CLEORA_OK) return rc;
             // (a projection of several column passes — k > 256 — cannot normalise in its epilogue: one more pass over Y.  Like the

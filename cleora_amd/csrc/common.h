@@ -150,7 +150,9 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
                    const float *rowscale = nullptr, const float *x2 = nullptr, uint64_t ldx2 = 0, float alpha = 1.0f,
                    float beta = 0.0f, int norm = 0,           // norm: 1 = L2-, 2 = L1-normalise the output rows in the epilogue ...
-                   bool *norm_done = nullptr);                // ... if the shape allows (reported here); else the caller runs rowops
+                   bool *norm_done = nullptr,
+                   const float *rowbound = nullptr,           // != nullptr (and no x2): |x[r][j]| <= rowbound[r], |mean[j]| <= 1 — the split form's
+                   bool *bounded_form = nullptr);             //   three-product f16 mode (whiten.hip); *bounded_form tells whether it ran                // ... if the shape allows (reported here); else the caller runs rowops
 
 // project_f16.hip: the projection for BOUNDED operands (|x[r][j]| <= rowbound[r], |mean[j]| <= 1) at d = k = 256 — three f16 MFMAs per
 // product, the transform resident in registers; the whitened loop's intermediate iterations

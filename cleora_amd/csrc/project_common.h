@@ -27,6 +27,9 @@ struct ProjArgs {
     uint64_t ldx2;
     float alpha, beta;
     int norm;         // split form, one column pass (k <= 256): 1 = L2-normalise, 2 = L1-normalise every output row in the epilogue
+    // bounded-operand (f16, three-product) mode of the split form: per row {s_r, 2^e_r} with (B_r + |s_r|) 2^e_r < 2^14, per column 2^-st
+    const float2 *rowinfo;
+    const float *colscale;
 };
 
 static __device__ __forceinline__ float centre(float v, float mu, float s, bool scaled) {
@@ -37,6 +40,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+constexpr int PF_TOP = 14;             // bounded operands are scaled below 2^14 (f16 overflows at 65504)
+
+// (lo, hi) -> packed f16 pairs p1 = f16(v), p2 = f16(v - p1): v = p1 + p2 to 2^-22 |v| (plus f16's subnormal spacing, 2^-24 absolute)
+static __device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t &p1, uint32_t &p2) {
+    const float __attribute__((ext_vector_type(2))) v = {lo, hi};
+    const h2v a = __builtin_convertvector(v, h2v);                 // round to nearest even
+    p1 = __builtin_bit_cast(uint32_t, a);
+    const float __attribute__((ext_vector_type(2))) r = v - __builtin_convertvector(a, float __attribute__((ext_vector_type(2))));   // exact
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, h2v));
+}
+// the power of two that scales a value bounded by `bound` just below 2^PF_TOP (1 for a zero / non-finite bound)
+static __device__ __forceinline__ float pf_row_scale(float bound) {
+    int e = (bound > 0.f && bound < __builtin_inff()) ? PF_TOP - __builtin_amdgcn_frexp_expf(bound) : 0;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.0f, e);
+}
 
 constexpr int SR = 64;                 // rows per block tile
 constexpr int SN = 256;                // output columns per pass

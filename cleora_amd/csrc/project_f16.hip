@@ -46,24 +46,12 @@
 namespace cleora {
 namespace {
 
-typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 
 constexpr int PF_D = 256;              // d = k
 constexpr int PF_KS = PF_D / 16;       // k-steps
 constexpr int PF_ROWS = 64;            // rows per tile
 constexpr int PF_THREADS = 512;
 constexpr int PF_BUF = 2 * PF_KS * 2 * 1024;        // fragment bytes per tile: [row half][k-step][split] x 1 KiB = 64 KiB
-constexpr int PF_TOP = 14;             // operands are scaled below 2^14 (f16 overflows at 65504)
-
-// (lo, hi) -> packed f16 pairs p1 = f16(v), p2 = f16(v - p1): v = p1 + p2 to 2^-22 |v| (plus f16's subnormal spacing, 2^-24 absolute)
-__device__ __forceinline__ void split2h_pair(float lo, float hi, uint32_t &p1, uint32_t &p2) {
-    const f2v v = {lo, hi};
-    const h2v a = __builtin_convertvector(v, h2v);                 // round to nearest even
-    p1 = __builtin_bit_cast(uint32_t, a);
-    const f2v r = v - __builtin_convertvector(a, f2v);             // exact
-    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, h2v));
-}
 
 // T (256 x 256 row-major f32) -> per-column power-of-two scale, hi / lo f16 fragments in the consumer's register order:
 // tp[((w * 16 + ks) * 2 + sp) * 64 + lane] = 8 x f16: lane (j, h) <-> column 32 w + pi^-1(j), k = 16 ks + 8 h + e, where the fragment

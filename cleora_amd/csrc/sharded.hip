@@ -742,7 +742,8 @@ int cleora_embed_sharded(cleora_sharded *s, float *x_replica, int markov_type, u
                 } else {
                     r2 = launch_project(in, d, b.valid, d, st.mean32.as<float>(), st.transform.as<float>(), d, o, d, stream,
                                         loop_form ? rowsum + b.first_local : nullptr, x2_rep ? x2_rep + b.b0 * (uint64_t)d : nullptr, d,
-                                        loop_form ? 1.0f - rw : 1.0f, loop_form ? rw : 0.0f, norm_mode, &normed);
+                                        loop_form ? 1.0f - rw : 1.0f, loop_form ? rw : 0.0f, norm_mode, &normed,
+                                        loop_form && rowabs && !x2_rep ? rowabs + b.first_local : nullptr);
                 }
                 if (r2 != CLEORA_OK) return r2;
                 if (norm_mode && !normed && (r2 = launch_rowops(o, d, b.valid, d, o, d, norm | fast | (loop_form ? CLEORA_F_FASTNORM : 0u), 0.f, nullptr, nullptr, nullptr, stream)) != CLEORA_OK) return r2;

@@ -978,6 +978,58 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
     tp[idx] = (u32x4){w[0], w[1], w[2], w[3]};
 }
 
+// ---- the bounded-operand mode of the split form (round 6): two-way f16 splits, THREE products ---------------------------------
+// Inside the whitened loop the projection's operand is bounded row by row (abi.hip: Z = A Y with normalised rows Y, |z| <= sum |a|):
+// rows scaled by 2^e_r and T's columns by 2^st into f16's upper range are sums of two f16 values to 2^-22, and x t = x1 t1 + x1 t2 +
+// x2 t1 (project_f16.hip has the argument and the d = 256 kernel with T resident in registers).  Here the same arithmetic for every other
+// width: B stages of 16 KiB instead of 24, two A fragments instead of three, half the MFMAs; the scales are undone on the accumulators.
+constexpr int SKB16 = 2 * 8 * 64;      // 16-byte units of packed T per (pass, k-step) in this mode: 16 KiB
+
+__global__ __launch_bounds__(256) void rowinfo_f16_kernel(const float *__restrict__ rowscale, const float *__restrict__ rowbound, uint64_t n,
+                                                          float2 *__restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const float s = rowscale ? rowscale[r] : 1.f, b = rowbound ? rowbound[r] : 1.f;
+    out[r] = make_float2(s, pf_row_scale(fabsf(b) + fabsf(s)));                 // |x - s mu| <= B + |s| (|mu| <= 1)
+}
+// per column of T (d x k): 2^st with max |t| 2^st in [2^13, 2^14) (colmul) and its reciprocal (colscale); one thread per column
+__global__ __launch_bounds__(256) void colscale_f16_kernel(const float *__restrict__ t, uint32_t d, uint32_t k, float *__restrict__ colmul,
+                                                           float *__restrict__ colscale) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= k) return;
+    float m = 0.f;
+    for (uint32_t r = 0; r < d; ++r) m = fmaxf(m, fabsf(t[(uint64_t)r * k + c]));
+    const float up = pf_row_scale(m);
+    colmul[c] = up;
+    colscale[c] = __uint_as_float(0x7F000000u - __float_as_uint(up));           // the reciprocal of a power of two by its exponent field
+}
+// T -> hi / lo f16 in fragment order: tp[((pass * KS + ks) * 2 + split) * 8 + tile][lane], slot e <-> k = 16 ks + 8 (e >> 2) + 4 h + (e & 3)
+__global__ __launch_bounds__(256) void pack_transform_split_f16_kernel(const float *__restrict__ t, uint32_t d, uint32_t k, uint32_t ksteps,
+                                                                       uint32_t passes, const float *__restrict__ colmul, u32x4 *__restrict__ tp) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;     // one 16-byte unit
+    if (idx >= (uint64_t)passes * ksteps * SKB16) return;
+    const uint32_t lane = (uint32_t)(idx & 63), j = (uint32_t)((idx >> 6) & 7), sp = (uint32_t)((idx >> 9) & 1);
+    const uint64_t step = idx / SKB16;                                 // pass * ksteps + ks
+    const uint32_t ks = (uint32_t)(step % ksteps), pass = (uint32_t)(step / ksteps);
+    const uint32_t col = pass * SN + j * 32 + (lane & 31), h = lane >> 5;
+    const float up = col < k ? colmul[col] : 0.f;
+    uint32_t w[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t e = 2 * m + q;
+            const uint32_t kk = 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3);
+            v[q] = (kk < d && col < k) ? __fmul_rn(t[(uint64_t)kk * k + col], up) : 0.f;
+        }
+        uint32_t p1, p2;
+        split2h_pair(v[0], v[1], p1, p2);
+        w[m] = sp ? p2 : p1;
+    }
+    tp[idx] = (u32x4){w[0], w[1], w[2], w[3]};
+}
+
 // U = k-steps per trip of the flat loop (a divisor of ksteps, a multiple of 2 RING): the compiler copies the live part of the
 // operand ring at the loop's back edge — behind a vmcnt(0) that drains the prefetch — so the back edge is taken as rarely
 // as the shape allows (once per row tile at d = 256).
@@ -991,21 +1043,24 @@ __global__ __launch_bounds__(256) void pack_transform_split_kernel(const float *
 // three fragments in LDS (af[(g + 1) & 1][row group]: 3 KiB), both read them after the step's barrier.  Same values, same
 // order of operations: results are bit-identical to the round-3 kernel.  RING counts a wave's OWN k-steps in flight (every second).
 // PAR = wc ^ (row group >> 1), so that the two waves of a SIMD (w and w + 4) produce in opposite steps.
-template <bool SCALED, bool BLEND, int RING, int U, int RG, int PAR>
+template <bool SCALED, bool BLEND, int RING, int U, int RG, int PAR, bool F16>
 __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x4 *__restrict__ tp, uint32_t ksteps, uint64_t tiles,
                                                    unsigned char *smem) {
     static_assert(U % 2 == 0 && (U / 2) % RING == 0, "ring slots must be compile-time functions of the unrolled step");
+    static_assert(!F16 || (SCALED && !BLEND), "the bounded mode centres with the row's scale and takes no blend");
     constexpr int T = RG * 128;            // threads
-    constexpr int NB = SKB / T;            // 16-byte units of a B stage per thread (6 or 3)
+    constexpr int NS = F16 ? 2 : 3;        // splits of an operand
+    constexpr int SKBv = NS * 512;         // 16-byte units of a B stage (SKB / SKB16)
+    constexpr int NB = SKBv / T;           // ... per thread (6 or 3; bounded mode 4 or 2)
     constexpr int SRT = RG * 32;           // rows per block tile
     u32x4 *const bs = reinterpret_cast<u32x4 *>(smem);                           // [2][SKB]
-    u32x4 *const af = bs + 2 * SKB;                                              // [2][RG][3][64]: the A fragments of a k-step
-    float *const mean_s = reinterpret_cast<float *>(af + 2 * RG * 3 * 64);       // [16 ksteps]
+    u32x4 *const af = bs + 2 * SKBv;                                             // [2][RG][NS][64]: the A fragments of a k-step
+    float *const mean_s = reinterpret_cast<float *>(af + 2 * RG * NS * 64);      // [16 ksteps]
     float *const red = mean_s + 16 * ksteps;                                     // [2 RG waves][32 rows]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wr = w >> 1, wc = w & 1, i = lane & 31, h = lane >> 5;
     const uint32_t pass = blockIdx.y;
-    const u32x4 *const tpp = tp + (uint64_t)pass * ksteps * SKB;
+    const u32x4 *const tpp = tp + (uint64_t)pass * ksteps * SKBv;
     const uint64_t my_tiles = tiles > blockIdx.x ? (tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const uint64_t total = my_tiles * ksteps;                                    // a multiple of U (ksteps is)
     if (total == 0) return;
@@ -1019,6 +1074,7 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
     float4 ra[RING][2], rb[BLEND ? RING : 1][2];
     float rs[SCALED ? RING : 1];          // the row's scale travels with its operand slot (an unconditional 4-byte load per
                                           // k-step: a load behind a "first k-step of a tile" branch would cost the counted waits)
+    float2 ri[F16 ? RING : 1];            // bounded mode: {s_r, 2^e_r} instead
     uint64_t ltile = blockIdx.x;          // row tile / k-step of the NEXT load
     uint32_t lks = PAR;
     auto row_of = [&](uint64_t tile) {
@@ -1035,19 +1091,23 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
             rb[slot][0] = *reinterpret_cast<const float4 *>(p2);
             rb[slot][1] = *reinterpret_cast<const float4 *>(p2 + 8);
         }
-        if constexpr (SCALED) rs[slot] = a.rowscale[r];
+        if constexpr (F16) ri[slot] = a.rowinfo[r];
+        else if constexpr (SCALED) rs[slot] = a.rowscale[r];
         lks += 2;                                                                // ksteps is even: the parity stays
         if (lks >= ksteps) { lks -= ksteps; ltile += gridDim.x; }
     };
     // centre (block = embeddings - mean_f32, pycleora/__init__.py:161), blend, split: slot -> three bf16x8 fragments
-    auto split_a = [&](int slot, uint32_t ks, u32x4 (&as)[3]) {
+    auto split_a = [&](int slot, uint32_t ks, u32x4 (&as)[NS]) {
         const float4 m0 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 4 * h);
         const float4 m1 = *reinterpret_cast<const float4 *>(mean_s + 16 * ks + 8 + 4 * h);
         const float xv[8] = {ra[slot][0].x, ra[slot][0].y, ra[slot][0].z, ra[slot][0].w, ra[slot][1].x, ra[slot][1].y, ra[slot][1].z, ra[slot][1].w};
         const float mu[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = centre(xv[e], mu[e], SCALED ? rs[slot] : 1.f, SCALED);
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (F16) o[e] = __fmul_rn(centre(xv[e], mu[e], ri[slot].x, true), ri[slot].y);   // (x - s mu) 2^e: the scaling is exact
+            else o[e] = centre(xv[e], mu[e], SCALED ? rs[slot] : 1.f, SCALED);
+        }
         if constexpr (BLEND) {
             const int sb = BLEND ? slot : 0;
             const float x2v[8] = {rb[sb][0].x, rb[sb][0].y, rb[sb][0].z, rb[sb][0].w, rb[sb][1].x, rb[sb][1].y, rb[sb][1].z, rb[sb][1].w};
@@ -1056,14 +1116,20 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            uint32_t p1, p2, p3;
-            split3_pair(o[2 * m], o[2 * m + 1], p1, p2, p3);
-            as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
+            if constexpr (F16) {
+                uint32_t p1, p2;
+                split2h_pair(o[2 * m], o[2 * m + 1], p1, p2);
+                as[0][m] = p1; as[1][m] = p2;
+            } else {
+                uint32_t p1, p2, p3;
+                split3_pair(o[2 * m], o[2 * m + 1], p1, p2, p3);
+                as[0][m] = p1; as[1][m] = p2; as[2][m] = p3;
+            }
         }
     };
-    auto publish = [&](int buf, const u32x4 (&as)[3]) {
+    auto publish = [&](int buf, const u32x4 (&as)[NS]) {
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) af[((buf * RG + wr) * 3 + sp) * 64 + lane] = as[sp];
+        for (int sp = 0; sp < NS; ++sp) af[((buf * RG + wr) * NS + sp) * 64 + lane] = as[sp];
     };
 #pragma unroll
     for (int slot = 0; slot < RING; ++slot) issue_a(slot);                       // own k-steps PAR, PAR + 2, ...
@@ -1076,7 +1142,7 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
 
     __syncthreads();                                                             // mean_s is in place
     if constexpr (PAR == 0) {                                                    // the fragments of k-step 0
-        u32x4 first[3];
+        u32x4 first[NS];
         split_a(0, 0, first);
         publish(0, first);
     }
@@ -1094,7 +1160,7 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
             const uint32_t ksn = ks + 1 == ksteps ? 0 : ks + 1;
             u32x4 bst[NB];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) bst[u] = tpp[(uint64_t)ksn * SKB + t + T * u];
+            for (int u = 0; u < NB; ++u) bst[u] = tpp[(uint64_t)ksn * SKBv + t + T * u];
             // a step in which this wave does not produce refills the slot it emptied in the previous step (or the prologue), right
             // behind the B loads: the wait for B at the end of this step leaves exactly these loads in flight (vmcnt retires in
             // order); they are split three steps from now
@@ -1102,22 +1168,28 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
 
             // A fragments of this k-step (made by this wave or its partner during the previous step), B fragments of this wave's
             // four tiles, all three splits
-            u32x4 as_cur[3];
+            u32x4 as_cur[NS];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) as_cur[sp] = af[((buf * RG + wr) * 3 + sp) * 64 + lane];
-            u32x4 bf[3][4];
+            for (int sp = 0; sp < NS; ++sp) as_cur[sp] = af[((buf * RG + wr) * NS + sp) * 64 + lane];
+            u32x4 bf[NS][4];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
+            for (int sp = 0; sp < NS; ++sp)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bf[sp][jj] = bs[buf * SKB + (sp * 8 + wc * 4 + jj) * 64 + lane];
-            constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
-            u32x4 as_next[3];
+                for (int jj = 0; jj < 4; ++jj) bf[sp][jj] = bs[buf * SKBv + (sp * 8 + wc * 4 + jj) * 64 + lane];
+            constexpr int NP = F16 ? 3 : 6;
+            constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};      // (the first three: the bounded mode's products)
+            u32x4 as_next[NS];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
+            for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as_cur[PA[q]]),
-                                                                      __builtin_bit_cast(bf16x8, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
+                for (int jj = 0; jj < 4; ++jj) {
+                    if constexpr (F16)
+                        acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, as_cur[PA[q]]),
+                                                                         __builtin_bit_cast(h8v, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
+                    else
+                        acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as_cur[PA[q]]),
+                                                                          __builtin_bit_cast(bf16x8, bf[PB[q]][jj]), acc[jj], 0, 0, 0);
+                }
                 // the fragments of the NEXT k-step are made here, under this step's MFMAs (the matrix pipe runs them for
                 // 32 cycles each; the ~50 VALU instructions of centre + split issue in their shadow)
                 if (q == 0 && produce) split_a(((uu + 1 - PAR) / 2) % kRing, ksn, as_next);
@@ -1128,10 +1200,28 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
             // after: behind that branch the compiler cannot count the epilogue's stores and drains everything (vmcnt(0)),
             // the operand ring included, at the end of every RING-th step.
 #pragma unroll
-            for (int u = 0; u < NB; ++u) bs[(buf ^ 1) * SKB + t + T * u] = bst[u];
+            for (int u = 0; u < NB; ++u) bs[(buf ^ 1) * SKBv + t + T * u] = bst[u];
 
             if (uu == U - 1 && ks0 + U == ksteps) {
                 // ---- end of a row tile: normalise (whole rows live in this block when there is one pass), store --------
+                if constexpr (F16) {                                             // undo the column and row scales (powers of two: exact)
+                    float csl[4], un[16];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const uint32_t col = pass * SN + wc * 128 + jj * 32 + i;
+                        csl[jj] = col < a.k ? a.colscale[col] : 0.f;
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        uint64_t row = tile * SRT + (uint64_t)(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                        row = row < a.n ? row : a.n - 1;
+                        un[reg] = __uint_as_float(0x7F000000u - __float_as_uint(a.rowinfo[row].y));
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) acc[jj][reg] = (acc[jj][reg] * csl[jj]) * un[reg];
+                }
                 if (a.norm) {
                     float pr[16];
 #pragma unroll
@@ -1221,14 +1311,14 @@ __device__ __forceinline__ void project_split_body(const ProjArgs &a, const u32x
     }
 }
 
-template <bool SCALED, bool BLEND, int RING, int U, int RG = 2>
+template <bool SCALED, bool BLEND, int RING, int U, int RG = 2, bool F16 = false>
 __global__ __launch_bounds__(RG * 128, RG == 2 ? 2 : 1) void project_split_kernel(const ProjArgs a, const u32x4 *__restrict__ tp,
                                                                                    uint32_t ksteps, uint64_t tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int w = threadIdx.x >> 6;
     // whole waves take each arm; every arm meets the same barriers
-    if ((((w >> 1) >> 1) ^ w) & 1) project_split_body<SCALED, BLEND, RING, U, RG, 1>(a, tp, ksteps, tiles, smem);
-    else project_split_body<SCALED, BLEND, RING, U, RG, 0>(a, tp, ksteps, tiles, smem);
+    if ((((w >> 1) >> 1) ^ w) & 1) project_split_body<SCALED, BLEND, RING, U, RG, 1, F16>(a, tp, ksteps, tiles, smem);
+    else project_split_body<SCALED, BLEND, RING, U, RG, 0, F16>(a, tp, ksteps, tiles, smem);
 }
 
 }  // namespace
@@ -1360,8 +1450,9 @@ int launch_gram(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const doub
 int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean,
                    const float *t, uint32_t k, float *out, uint64_t ldo, hipStream_t stream,
                    const float *rowscale, const float *x2, uint64_t ldx2, float alpha, float beta, int norm,
-                   bool *norm_done) {
+                   bool *norm_done, const float *rowbound, bool *bounded_form) {
     if (norm_done) *norm_done = false;
+    if (bounded_form) *bounded_form = false;
     CL_REQUIRE(d > 0 && k > 0 && ldx >= d && ldo >= k, "bad d / k / leading dimension");
     CL_REQUIRE(x != nullptr && mean != nullptr && t != nullptr && out != nullptr,
                "x / mean / transform / out is NULL");
@@ -1392,11 +1483,6 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
     // two B stages, the A fragments of two k-steps for up to four row groups, the mean, the row-norm partials
     const size_t lds_bytes = (size_t)2 * SKB * 16 + (size_t)2 * 4 * 3 * 1024 + (size_t)16 * ksteps * sizeof(float) + 8 * 32 * sizeof(float);
     if (a.w4x && d % 32 == 0 && lds_bytes <= 160 * 1024) {
-        const uint64_t units = (uint64_t)passes * ksteps * SKB;
-        u32x4 *tp = nullptr;
-        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
-        hipLaunchKernelGGL(pack_transform_split_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, t, d, k,
-                           ksteps, passes, tp);
         static int cus = 0;
         if (!cus) {
             int dev = 0, c = 256;
@@ -1406,6 +1492,54 @@ int launch_project(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const f
         a.norm = (norm && passes == 1) ? norm : 0;                            // whole rows inside one block only
         if (norm_done) *norm_done = a.norm != 0;
         const bool scaled = rowscale != nullptr, blend = x2 != nullptr;
+        if (rowbound != nullptr && !blend) {
+            // ---- the bounded-operand mode: |x[r][j]| <= rowbound[r], |mean[j]| <= 1 (the caller's promise): three f16 products ----
+            const uint64_t units16 = (uint64_t)passes * ksteps * SKB16;
+            const size_t b_tp = units16 * sizeof(u32x4), b_ri = ((n * sizeof(float2) + 15) / 16) * 16, b_k = (((size_t)k * sizeof(float) + 15) / 16) * 16;
+            char *blk = nullptr;
+            CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&blk), b_tp + b_ri + 2 * b_k, stream));
+            u32x4 *tp16 = reinterpret_cast<u32x4 *>(blk);
+            float2 *rinfo = reinterpret_cast<float2 *>(blk + b_tp);
+            float *colmul = reinterpret_cast<float *>(blk + b_tp + b_ri), *colscale = reinterpret_cast<float *>(blk + b_tp + b_ri + b_k);
+            hipLaunchKernelGGL(rowinfo_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rowscale, rowbound, n, rinfo);
+            hipLaunchKernelGGL(colscale_f16_kernel, dim3((k + 255) / 256), dim3(256), 0, stream, t, d, k, colmul, colscale);
+            hipLaunchKernelGGL(pack_transform_split_f16_kernel, dim3((unsigned)((units16 + 255) / 256)), dim3(256), 0, stream, t, d, k, ksteps,
+                               passes, colmul, tp16);
+            a.rowinfo = rinfo;
+            a.colscale = colscale;
+            const bool wide16 = (n + 127) / 128 >= (uint64_t)cus;
+            const uint64_t tiles16 = wide16 ? (n + 127) / 128 : (n + SR - 1) / SR;
+            const uint64_t resident16 = wide16 ? (uint64_t)cus : 2ull * (uint64_t)cus;
+            const dim3 grid16((unsigned)(tiles16 < resident16 ? tiles16 : resident16), passes);
+            hipError_t e16 = hipSuccess;
+            auto go16 = [&](auto RGt) {
+                constexpr int RG = decltype(RGt)::value;
+#define CLEORA_SPLIT16_LAUNCH(RING, UU)                                                                                               \
+                do {                                                                                                                   \
+                    e16 = hipFuncSetAttribute(reinterpret_cast<const void *>(project_split_kernel<true, false, RING, UU, RG, true>),   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                            \
+                    if (e16 == hipSuccess)                                                                                             \
+                        hipLaunchKernelGGL((project_split_kernel<true, false, RING, UU, RG, true>), grid16, dim3(RG * 128), lds_bytes, \
+                                           stream, a, tp16, ksteps, tiles16);                                                          \
+                } while (0)
+                if (ksteps % 16 == 0) CLEORA_SPLIT16_LAUNCH(2, 16);
+                else if (ksteps % 4 == 0) CLEORA_SPLIT16_LAUNCH(2, 4);
+                else CLEORA_SPLIT16_LAUNCH(1, 2);
+#undef CLEORA_SPLIT16_LAUNCH
+            };
+            if (wide16) go16(std::integral_constant<int, 4>{});
+            else go16(std::integral_constant<int, 2>{});
+            const hipError_t le16 = e16 != hipSuccess ? e16 : hipGetLastError();
+            CL_HIP(hipFreeAsync(blk, stream));
+            CL_HIP(le16);
+            if (bounded_form) *bounded_form = true;
+            return CLEORA_OK;
+        }
+        const uint64_t units = (uint64_t)passes * ksteps * SKB;
+        u32x4 *tp = nullptr;
+        CL_HIP(hipMallocAsync(reinterpret_cast<void **>(&tp), units * sizeof(u32x4), stream));
+        hipLaunchKernelGGL(pack_transform_split_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream, t, d, k,
+                           ksteps, passes, tp);
         // large n: 128-row tiles, one 8-wave block per CU (RG = 4: half the B-stage traffic per MFMA); otherwise 64-row tiles,
         // two 4-wave blocks per CU
         const bool wide = (n + 127) / 128 >= (uint64_t)cus;

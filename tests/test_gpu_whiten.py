@@ -407,6 +407,45 @@ def test_bounded_projection_on_the_f16_matrix_cores(n, norm, scaled):
     assert err.max() <= 2e-6, float(err.max())
 
 
+@pytest.mark.parametrize("n", [1, 63, 130, 5003, 40_001])
+@pytest.mark.parametrize("d,k", [(128, 128), (512, 512), (1024, 1024), (96, 160), (32, 32), (320, 64)])
+@pytest.mark.parametrize("norm,scaled", [(1, True), (0, False), (2, True)])
+def test_bounded_projection_at_other_widths_takes_the_three_product_mode_of_the_split_form(n, d, k, norm, scaled):
+    """cleora_project_bounded_dev with row bounds at shapes other than d = k = 256 (config 5: d = 1024): the split form's bounded-operand
+    mode (csrc/whiten.hip: two-way f16 splits scaled by powers of two, three MFMAs per product, *form == 2) against an f64 product of the
+    same f32 inputs; row bounds and transform columns over several decades, ragged tiles, several column passes (k > 256: no norm in the
+    epilogue, *norm_done == 0).  Stated: every row within 2e-6 of its own norm."""
+    import ctypes
+    L = _hip.lib()
+    rng = np.random.default_rng(n + 7 * norm + scaled + 13 * d + k)
+    bound = np.where(rng.random(n) < 0.8, 1.0, 10 ** (rng.random(n) * 4 - 1)).astype(np.float32)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x *= (bound * (0.2 + 0.8 * rng.random(n)))[:, None].astype(np.float32)
+    x = np.minimum(np.maximum(x, -bound[:, None]), bound[:, None]).astype(np.float32)
+    rowscale = (bound * (2 * rng.random(n) - 1)).astype(np.float32)
+    mean = np.clip(rng.standard_normal(d) * 0.05, -1, 1).astype(np.float32)
+    t = (rng.standard_normal((d, k)) * 10 ** (rng.random(k) * 5 - 2)[None, :]).astype(np.float32)
+    dx, dm, dt, ds, db = (_hip.DevArray.from_host(a) for a in (x, mean, t, rowscale, bound))
+    do = _hip.DevArray.from_host(np.full((n + 1, k), 7.0, np.float32))
+    nd, form = ctypes.c_int(0), ctypes.c_int(-1)
+    _hip.check(L.cleora_project_bounded_dev(dx.ptr, d, n, d, dm.ptr, dt.ptr, k, do.ptr, k, ds.ptr if scaled else None, db.ptr, norm,
+                                            ctypes.byref(nd), ctypes.byref(form), None))
+    _hip.check(L.cleora_stream_sync(None))
+    assert form.value == 2 and nd.value == (1 if (norm and k <= 256) else 0)
+    got = do.to_host()
+    assert (got[n] == 7.0).all(), "wrote past row n"
+    got = got[:n].astype(np.float64)
+    ref = (x.astype(np.float64) - (rowscale.astype(np.float64)[:, None] if scaled else 1.0) * mean.astype(np.float64)[None, :]) @ t.astype(np.float64)
+    if nd.value and norm == 1:
+        ref /= np.maximum(np.linalg.norm(ref, axis=1, keepdims=True), 1e-10)
+    elif nd.value and norm == 2:
+        ref /= np.maximum(np.abs(ref).sum(axis=1, keepdims=True), 1e-10)
+    assert np.isfinite(got).all()
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-300)
+    assert err.max() <= 2e-6, float(err.max())
+
+
 def test_bounded_projection_falls_back_for_other_shapes_and_checks_its_arguments():
     """Any shape but d = k = 256 takes cleora_project_general_dev's kernel (*form == 0) with the same result contract."""
     import ctypes

@@ -999,7 +999,7 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
     # f16 MFMAs per product, the transform resident in registers), timed stand-alone on the SpMM's output with its column means and a
     # dense transform; `form` tells which kernel ran (1: f16; 0: the six-product bf16 form — other widths)
     proj_inter = None
-    if d == 256:
+    if d % 32 == 0:
         rsum = torch.empty(n, dtype=torch.float32, device=dev)
         rabs = torch.empty(n, dtype=torch.float32, device=dev)
         _hip.check(L.cleora_csr_rowsums_dev(gr.handle, _hip.LEFT, rsum.data_ptr(), rabs.data_ptr(), stream))
@@ -1015,6 +1015,8 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
         def proj_once():
             _hip.check(L.cleora_project_bounded_dev(mid.data_ptr(), d, n, d, mu32.data_ptr(), tr.data_ptr(), d, nxt.data_ptr(), d,
                                                     rsum.data_ptr(), rabs.data_ptr(), 1, ctypes.byref(nd_), ctypes.byref(fm_), stream))
+            if nd_.value == 0:        # several column passes (k > 256): the row pass the loop runs behind the projection (tree-sum form)
+                _hip.check(L.cleora_rowops_dev(nxt.data_ptr(), d, n, d, nxt.data_ptr(), d, _hip.F_L2NORM | _hip.F_FASTNORM, 0.0, None, None, None, stream))
         proj_once()
         e0.record()
         for _ in range(5):
@@ -1022,8 +1024,11 @@ def run_whitened(args, g, x, dev, L, iters, hashes):
         e1.record()
         torch.cuda.synchronize()
         pms = e0.elapsed_time(e1) / 5
-        pbytes = 2.0 * n * d * 4
-        proj_inter = {"kernel": "project_f16_kernel<1> (csrc/project_f16.hip)" if fm_.value == 1 else "project_split_kernel (six-product bf16 form)",
+        pbytes = 2.0 * n * d * 4 * (1 if nd_.value else 2)
+        names = {1: "project_f16_kernel<1> (csrc/project_f16.hip)",
+                 2: "project_split_kernel in its bounded-operand mode (three f16 products, csrc/whiten.hip)" + ("" if nd_.value else " + the stand-alone row normalise"),
+                 0: "project_split_kernel (six-product bf16 form)"}
+        proj_inter = {"kernel": names.get(fm_.value, str(fm_.value)),
                       "ms": pms, "bound": "hbm", "achieved": pbytes / (pms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": pbytes / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": pbytes,
                       "mfma": {"dtype": "f16 (two-way split operands, 3 products)", "achieved": 6.0 * n * d * d / (pms * 1e-3) / 1e12,

@@ -289,8 +289,10 @@ int cleora_csr_rowsums_dev(const cleora_graph *g, int markov_type, float *rowsum
  * At d = k = 256 this takes the f16 matrix cores with the transform resident in registers (csrc/project_f16.hip: operands scaled
  * into the f16 range by per-row / per-column powers of two, each f32 product from three f16 MFMAs of two-way split operands:
  * 2^-22 per product, the error class of the f32 GEMM of pycleora/__init__.py:163); *form (host, may be NULL) reports 1 when it
- * did, 0 when the call fell back to cleora_project_general_dev's kernel (any other shape).  An operand that violates its bound
- * overflows f16: the result is then inf / NaN, never silently wrong.  norm as above, always applied when *form == 1. */
+ * did.  Any other shape with rowbound != NULL and d a multiple of 32 takes the same arithmetic in the general kernel (the transform
+ * streamed through LDS: *form == 2; config 5's d = 1024); with rowbound == NULL, or d not a multiple of 32, the call is
+ * cleora_project_general_dev (*form == 0).  An operand that violates its bound overflows f16: the result is then inf / NaN, never
+ * silently wrong.  norm as above: always applied when *form == 1, as *norm_done says otherwise. */
 int cleora_project_bounded_dev(const float *x, uint64_t ldx, uint64_t n, uint32_t d, const float *mean_f32_dev,
                                const float *transform_dev, uint32_t k, float *out, uint64_t ldo, const float *rowscale_dev,
                                const float *rowbound_dev, int norm, int *norm_done, int *form, void *stream);

@@ -41,9 +41,78 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` without torchrun (the way the driver starts the N = 1 run): this process becomes the
+    launcher — it starts N copies of itself, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set the way torch.distributed.run would set them, passes rank 0's stdout (the ONE JSON line) through, sends the other
+    ranks' stdout to stderr, and exits with the first non-zero return code (the remaining ranks are terminated by PID).
+    The launcher never touches a GPU."""
+    import signal
+    import subprocess
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+
+    def stop_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+    signal.signal(signal.SIGTERM, lambda *_: (stop_all(), sys.exit(143)))
+    rc, alive = 0, set(range(n_ranks))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    stop_all()
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
+        rc = 130
+    for p in procs:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+def _gpus_requested(argv):
+    for i, arg in enumerate(argv):
+        if arg == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1]) if argv[i + 1].isdigit() else 1
+        if arg.startswith("--gpus="):
+            return int(arg.split("=", 1)[1]) if arg.split("=", 1)[1].isdigit() else 1
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_requested(sys.argv[1:]) > 1 and not {"-h", "--help"} & set(sys.argv[1:]):
+    # `python bench.py --gpus N` without torchrun: this process only launches the ranks — before numpy / torch are imported (on a box
+    # with slow storage that import is tens of seconds, and every rank pays it once more anyway)
+    raise SystemExit(self_launch(_gpus_requested(sys.argv[1:]), sys.argv[1:]))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -371,60 +440,6 @@ def c_abi_communicator(local_rank, dev, rank, world, transport="rccl"):
         return comm, ("peer-direct hipIpc transport via the C ABI (csrc/peer.hip)"
                       + (f" — the RCCL communicator was unusable: {why[:200]}" if why else " (--backend local)"))
     raise SystemExit(f"bench.py: no C-ABI communicator on rank {rank}: RCCL: {why}; peer-direct: {why2}; nothing was measured")
-
-
-def free_port():
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
-        sock.bind(("127.0.0.1", 0))
-        return sock.getsockname()[1]
-
-
-def self_launch(n_ranks, argv):
-    """`python bench.py --gpus N` without torchrun (the way the driver starts the N = 1 run): this process becomes the
-    launcher — it starts N copies of itself, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
-    set the way torch.distributed.run would set them, passes rank 0's stdout (the ONE JSON line) through, sends the other
-    ranks' stdout to stderr, and exits with the first non-zero return code (the remaining ranks are terminated by PID).
-    The launcher never touches a GPU."""
-    import signal
-    import subprocess
-    env = dict(os.environ)
-    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
-    procs = []
-    for r in range(n_ranks):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
-                                      stdout=None if r == 0 else sys.stderr))
-
-    def stop_all(*_):
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()
-    signal.signal(signal.SIGTERM, lambda *_: (stop_all(), sys.exit(143)))
-    rc, alive = 0, set(range(n_ranks))
-    try:
-        while alive:
-            for r in sorted(alive):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                alive.discard(r)
-                if code != 0 and rc == 0:
-                    rc = code
-                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
-                    stop_all()
-            time.sleep(0.05)
-    except KeyboardInterrupt:
-        stop_all()
-        rc = 130
-    for p in procs:
-        try:
-            p.wait(timeout=20)
-        except subprocess.TimeoutExpired:
-            p.kill()
-    return rc
 
 
 class native_stdout_to_stderr:

@@ -7,6 +7,15 @@
 namespace cleora {
 namespace {
 
+// Internal flag bit (never part of the ABI's flag set): the epilogue's row stores are non-temporal.  An iterate far larger than the
+// caches is written once per launch and read by nobody before the launch ends: left to the default policy its 10 GB stream through
+// L2 and Infinity Cache and take the place of the rows the gather cache policy keeps there (hot.hip).  Measured at C3 on the same
+// (X, Y) pairs, one process, builds side by side (scripts/r06/store_policy_probe.py): 30.7-31.7 ms against 31.6-33.1 with the default
+// policy in the fast placement class, 35.1-36.9 against 36.3 in the slow one; sc0 / sc1 / sc0 sc1 stores: no different from the default.
+// (Round 1 had measured +0.1 % — before there was a hot set to protect.)  Set by the launchers for outputs of 256 MiB and more.
+constexpr uint32_t kStreamStores = 1u << 30;
+constexpr uint64_t kStreamStoreMinBytes = 256ull << 20;
+
 struct RowArgs {
     float *y;
     uint64_t ldy;
@@ -64,13 +73,20 @@ __device__ __forceinline__ void load_row(const float *__restrict__ p, int gl, ui
 
 template <int G, int V, int W, bool FULL>
 __device__ __forceinline__ void store_row(float *__restrict__ p, int gl, uint32_t d,
-                                          const float (&r)[V][W]) {
+                                          const float (&r)[V][W], bool nt = false) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
         const uint32_t j = (uint32_t)(v * G + gl) * W;
         if constexpr (W == 4) {
-            if (FULL || j < d)
-                *reinterpret_cast<float4 *>(p + j) = make_float4(r[v][0], r[v][1], r[v][2], r[v][3]);
+            if (FULL || j < d) {
+                if (nt) {                                                         // streaming store: see kStreamStores
+                    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                    const nt_f4 q = {r[v][0], r[v][1], r[v][2], r[v][3]};
+                    __builtin_nontemporal_store(q, reinterpret_cast<nt_f4 *>(p + j));
+                } else {
+                    *reinterpret_cast<float4 *>(p + j) = make_float4(r[v][0], r[v][1], r[v][2], r[v][3]);
+                }
+            }
         } else {
             if (FULL || j < d) p[j] = r[v][0];
         }
@@ -165,7 +181,7 @@ __device__ __forceinline__ void finish_row(const RowArgs &ra, uint64_t row, int 
         if (gl == 0) ra.row_sqdiff[row] = ds;
     }
 
-    store_row<G, V, W, FULL>(ra.y + row * ra.ldy, gl, d, acc);
+    store_row<G, V, W, FULL>(ra.y + row * ra.ldy, gl, d, acc, (ra.flags & kStreamStores) != 0);
 }
 
 }  // namespace

@@ -121,8 +121,8 @@ __device__ __forceinline__ void accumulate(const SpmmArgs &a, uint64_t beg, uint
         uint32_t cv = 0;
         float wv = 0.f;
         if ((uint32_t)gl < cnt) {
-            cv = a.col[e + gl];
-            wv = a.val[e + gl];
+            cv = a.col[e + gl];                       // (loaded non-temporally the edge stream measured no better in the fast placement
+            wv = a.val[e + gl];                       //  class and 1-2 ms worse in the slow one: scripts/r06/store_policy_probe.py)
         }
         uint32_t k = 0;
         {
@@ -968,7 +968,7 @@ int launch_propagate(const cleora_graph *g, int kind, const float *x, uint64_t l
     a.r.row_sumsq = row_sumsq;
     a.r.rw = rw;
     a.r.alpha = 1.0f - rw;
-    a.r.flags = flags;
+    a.r.flags = flags | (g->n_rows * ldy * sizeof(float) >= kStreamStoreMinBytes ? kStreamStores : 0u);
     a.r.d = d;
 
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
@@ -1012,7 +1012,7 @@ int launch_rowops(const float *x, uint64_t ldx, uint64_t n, uint32_t d, float *y
     ra.row_sumsq = row_sumsq;
     ra.rw = rw;
     ra.alpha = 1.0f - rw;
-    ra.flags = flags;
+    ra.flags = flags | (n * ldy * sizeof(float) >= kStreamStoreMinBytes ? kStreamStores : 0u);
     ra.d = d;
     const bool w4 = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(x) && aligned16(y) &&
                     (!x_self || (aligned16(x_self) && ldxs % 4 == 0));

@@ -15,7 +15,7 @@ L = _hip.lib(); S = torch.cuda.current_stream().cuda_stream
 gr = _hip.Graph.from_device(n, n, nnz, g["rowptr"].data_ptr(), g["col"].data_ptr(), g["val_left"].data_ptr(), None, 0, keepalive=(g["rowptr"], g["col"], g["val_left"]))
 x = torch.empty((n, d), device=dev); y = torch.empty((n, d), device=dev)
 _hip.check(L.cleora_init_dev(hashes.data_ptr(), n, d, 0, x.data_ptr(), d, S))
-N = 300
+N = 60
 evs = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
 for _ in range(4):
     _hip.check(L.cleora_propagate_dev(gr.handle, _hip.LEFT, x.data_ptr(), d, d, y.data_ptr(), d, _hip.F_L2NORM, 0.0, None, None, None, S)); x, y = y, x

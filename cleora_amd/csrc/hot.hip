@@ -4,9 +4,7 @@
 // the non-temporal policy (`buffer_load ... nt`) and the most frequently referenced rows with the default
 // policy shortens the SpMM from 34.3 to 31.0 ms (-10 %): the streaming cold gathers no longer evict the
 // hot set from L2 / Infinity Cache.  The optimum is flat between 0.25M and 2M hot rows (0.25 - 2 GB of
-// X); `nt` on every row, or on the hot rows only, gains nothing; sc0 / sc1 do nothing.  Swept again in round 6 with the SpMM's own
-// stores non-temporal (scripts/r06/hot_budget_sweep.py, four destination buffers): off 39.3-40.0 / 35.9 ms (slow / fast placement class), 128 MiB
-// to 768 MiB all 35.2-36.3 / 30.8-31.1 at their best repetition — still flat; the automatic budget stays at 768 MiB.
+// X); `nt` on every row, or on the hot rows only, gains nothing; sc0 / sc1 do nothing.
 //
 // The mark is bit 31 of a private copy of the column indices (entities < 2^31), so the kernels read
 // exactly the same bytes as before.  The hot set = the K columns with the largest in-degree, K chosen
